@@ -61,8 +61,13 @@ def test_lm_trajectory_vs_numpy_golden(oracle_lib, name, dense):
     assert abs(P.compute_errors() - float(g["chi0"])) <= 1e-12 * max(1.0, float(g["chi0"]))
     r = P.optimize(10, dense=dense)
     tr = g["trace"]
-    assert len(r) == len(tr)
     tol = GOLDEN_TOL.get(name, 1e-10)
+    if name.startswith("zero_noise"):
+        # chi2 ~ 1e-25: the sign of rho is round-off, only "stays at the optimum" is defined
+        assert len(r) <= 2 and all(a["chi2"] < 1e-12 for a in r)
+        np.testing.assert_allclose(P.pose, g["pose_out"], rtol=0, atol=1e-9)
+        return
+    assert len(r) == len(tr)
     for a, t in zip(r, tr):
         assert a["trials"] == int(t[4])
         assert abs(a["chi2"] - t[1]) <= tol * max(abs(t[1]), 1e-6)

@@ -1,0 +1,27 @@
+#pragma once
+#include "../kernels/kernels.h"
+#include "chol_symbolic.h"
+#include "hip_util.h"
+
+// definition of the opaque cugo_chol of include/cugo_hip.h
+struct cugo_chol
+{
+    cugo_ctx* ctx = nullptr;
+    bool analyzed = false;
+    cugo_host::CholPlan plan;
+    std::vector<int32_t> trans32; // blk_trans widened for cugo_chol_plan_array
+    cugo_k::CholPlanDev dev{};
+    size_t lds_factor = 0, lds_backward = 0;
+
+    cugo_host::DevBuf<int32_t> d_ncb, d_nb, d_col0, d_rows_ptr, d_rows, d_child_ptr, d_child,
+        d_rel_ptr, d_rel, d_task_ptr, d_task_fronts, d_blk_front, d_blk_row, d_blk_col, d_perm,
+        d_col_front;
+    cugo_host::DevBuf<int64_t> d_off;
+    cugo_host::DevBuf<uint8_t> d_blk_trans;
+    cugo_host::DevBuf<double> d_fronts, d_xnew;
+
+    void analyze(int n, const int32_t* rowptr, const int32_t* colind);
+    void upload(hipStream_t s);
+    void factor_solve(const double* d_Hsc, double lambda, const double* d_bsc, double* d_x,
+                      int32_t* d_fail);
+};

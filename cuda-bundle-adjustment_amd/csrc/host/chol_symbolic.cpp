@@ -1,0 +1,658 @@
+// Ordering (level-set nested dissection + minimum degree leaves), elimination tree, relaxed
+// supernodes, front layout, extend-add maps and the stage/task schedule of the multifrontal
+// LL^T.  Everything here works on the BLOCK graph (one node per free pose), so even the
+// 10k-pose configuration is a 10k-node problem on the host.
+//
+// The reference delegates all of this to closed-source cuSOLVER/METIS on the scalar 6Px6P
+// pattern (ref: src/cholesky.hpp:97-98,295-296; src/cuda_linear_solver.cpp:27-42).
+#include "chol_symbolic.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <numeric>
+#include <stdexcept>
+
+namespace cugo_host
+{
+
+CholOptions CholOptions::from_env()
+{
+    CholOptions o;
+    if (const char* s = std::getenv("CUGO_ND_LEAF"))
+        o.nd_leaf = std::max(1, std::atoi(s));
+    if (const char* s = std::getenv("CUGO_MAX_SUPER_COLS"))
+        o.max_super_cols = std::max(1, std::atoi(s));
+    if (const char* s = std::getenv("CUGO_ZERO_FRAC"))
+        o.zero_frac = std::atof(s);
+    if (const char* s = std::getenv("CUGO_TARGET_TASKS"))
+        o.target_tasks = std::max(1, std::atoi(s));
+    return o;
+}
+
+namespace
+{
+
+struct Graph
+{
+    int n = 0;
+    std::vector<int> ptr, adj; // symmetric, no self loops, sorted
+};
+
+Graph build_graph(int n, const int32_t* rowptr, const int32_t* colind)
+{
+    Graph g;
+    g.n = n;
+    std::vector<int> deg(n + 1, 0);
+    for (int r = 0; r < n; r++)
+        for (int k = rowptr[r]; k < rowptr[r + 1]; k++)
+            if (colind[k] != r)
+            {
+                deg[r + 1]++;
+                deg[colind[k] + 1]++;
+            }
+    g.ptr.assign(n + 1, 0);
+    for (int i = 0; i < n; i++)
+        g.ptr[i + 1] = g.ptr[i] + deg[i + 1];
+    g.adj.resize(g.ptr[n]);
+    std::vector<int> pos(g.ptr.begin(), g.ptr.end() - 1);
+    for (int r = 0; r < n; r++)
+        for (int k = rowptr[r]; k < rowptr[r + 1]; k++)
+            if (colind[k] != r)
+            {
+                g.adj[pos[r]++] = colind[k];
+                g.adj[pos[colind[k]]++] = r;
+            }
+    for (int i = 0; i < n; i++)
+    {
+        std::sort(g.adj.begin() + g.ptr[i], g.adj.begin() + g.ptr[i + 1]);
+    }
+    return g;
+}
+
+// ------------------------------------------------------------------ nested dissection ---
+struct ND
+{
+    const Graph& g;
+    const CholOptions& opt;
+    std::vector<int> setid, level, order;
+    int next_id = 1;
+    ND(const Graph& g_, const CholOptions& o) : g(g_), opt(o), setid(g_.n, 0), level(g_.n, -1) {}
+
+    // exact minimum degree on the subgraph induced by `nodes` (small sets only)
+    void leaf_order(const std::vector<int>& nodes)
+    {
+        const int m = (int)nodes.size();
+        if (m > 512)
+        {
+            for (int v : nodes)
+                order.push_back(v);
+            return;
+        }
+        const int id = next_id++;
+        std::vector<int> local(m);
+        for (int i = 0; i < m; i++)
+            setid[nodes[i]] = id;
+        // local adjacency
+        std::vector<std::vector<int>> adj(m);
+        {
+            std::vector<int> gl2l; // map through binary search on sorted copy
+            std::vector<int> sorted(nodes);
+            std::sort(sorted.begin(), sorted.end());
+            std::vector<int> where(m);
+            for (int i = 0; i < m; i++)
+                where[std::lower_bound(sorted.begin(), sorted.end(), nodes[i]) - sorted.begin()] = i;
+            for (int i = 0; i < m; i++)
+                for (int k = g.ptr[nodes[i]]; k < g.ptr[nodes[i] + 1]; k++)
+                {
+                    const int u = g.adj[k];
+                    if (setid[u] == id)
+                        adj[i].push_back(
+                            where[std::lower_bound(sorted.begin(), sorted.end(), u) - sorted.begin()]);
+                }
+        }
+        std::vector<char> done(m, 0);
+        std::vector<int> mark(m, -1);
+        for (int step = 0; step < m; step++)
+        {
+            int best = -1;
+            for (int i = 0; i < m; i++)
+                if (!done[i] && (best < 0 || adj[i].size() < adj[best].size()))
+                    best = i;
+            done[best] = 1;
+            order.push_back(nodes[best]);
+            const std::vector<int> nb = adj[best];
+            for (int u : nb)
+            {
+                auto& au = adj[u];
+                au.erase(std::remove(au.begin(), au.end(), best), au.end());
+                for (int w : au)
+                    mark[w] = u;
+                mark[u] = u;
+                for (int v : nb)
+                    if (mark[v] != u)
+                    {
+                        au.push_back(v);
+                        mark[v] = u;
+                    }
+            }
+            adj[best].clear();
+        }
+    }
+
+    // BFS inside the set `id` from `src`; fills level[], returns visit order
+    void bfs(int src, int id, std::vector<int>& out)
+    {
+        out.clear();
+        out.push_back(src);
+        level[src] = 0;
+        for (size_t h = 0; h < out.size(); h++)
+        {
+            const int v = out[h];
+            for (int k = g.ptr[v]; k < g.ptr[v + 1]; k++)
+            {
+                const int u = g.adj[k];
+                if (setid[u] == id && level[u] < 0)
+                {
+                    level[u] = level[v] + 1;
+                    out.push_back(u);
+                }
+            }
+        }
+    }
+
+    void run(std::vector<int> nodes)
+    {
+        if ((int)nodes.size() <= opt.nd_leaf)
+        {
+            leaf_order(nodes);
+            return;
+        }
+        const int id = next_id++;
+        for (int v : nodes)
+        {
+            setid[v] = id;
+            level[v] = -1;
+        }
+        // connected components
+        std::vector<int> comp;
+        bfs(nodes[0], id, comp);
+        if (comp.size() < nodes.size())
+        {
+            std::vector<std::vector<int>> comps;
+            comps.push_back(comp);
+            for (int v : nodes)
+                if (level[v] < 0)
+                {
+                    bfs(v, id, comp);
+                    comps.push_back(comp);
+                }
+            for (auto& c : comps)
+                run(c);
+            return;
+        }
+        // pseudo-peripheral start: repeat BFS from the last-visited node
+        int src = comp.back();
+        for (int it = 0; it < 3; it++)
+        {
+            for (int v : nodes)
+                level[v] = -1;
+            bfs(src, id, comp);
+            const int far = comp.back();
+            if (it == 2 || level[far] <= 1)
+                break;
+            int depth_before = level[far];
+            (void)depth_before;
+            src = far;
+        }
+        const int h = level[comp.back()];
+        if (h < 2)
+        {
+            leaf_order(nodes);
+            return;
+        }
+        std::vector<int> cnt(h + 1, 0);
+        for (int v : nodes)
+            cnt[level[v]]++;
+        // candidate separators: levels leaving >= 30% of the nodes on each side; the smallest wins
+        const int total = (int)nodes.size();
+        int best = -1;
+        {
+            int below = 0;
+            double best_score = 1e300;
+            for (int m = 0; m <= h; m++)
+            {
+                const int above = total - below - cnt[m];
+                if (m >= 1 && m <= h - 1)
+                {
+                    const int mn = std::min(below, above);
+                    const double bal = (double)mn / total;
+                    double score = cnt[m] + (bal >= 0.3 ? 0.0 : 1e6 * (0.3 - bal));
+                    if (score < best_score)
+                    {
+                        best_score = score;
+                        best = m;
+                    }
+                }
+                below += cnt[m];
+            }
+        }
+        std::vector<int> A, B, S;
+        for (int v : comp)
+        {
+            if (level[v] < best)
+                A.push_back(v);
+            else if (level[v] > best)
+                B.push_back(v);
+            else
+            {
+                // thin the separator: a level node without a neighbour above joins A
+                bool touches_B = false;
+                for (int k = g.ptr[v]; k < g.ptr[v + 1] && !touches_B; k++)
+                {
+                    const int u = g.adj[k];
+                    if (setid[u] == id && level[u] == best + 1)
+                        touches_B = true;
+                }
+                (touches_B ? S : A).push_back(v);
+            }
+        }
+        run(A);
+        run(B);
+        for (int v : S)
+            order.push_back(v);
+    }
+};
+
+} // namespace
+
+void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const CholOptions& opt,
+                  CholPlan& P)
+{
+    P = CholPlan();
+    P.n = n;
+    if (n == 0)
+        return;
+    const Graph g = build_graph(n, rowptr, colind);
+
+    // ---- 1. fill-reducing, parallelism-exposing ordering --------------------------------
+    std::vector<int> perm;
+    {
+        ND nd(g, opt);
+        std::vector<int> all(n);
+        std::iota(all.begin(), all.end(), 0);
+        nd.run(all);
+        perm = nd.order;
+        if ((int)perm.size() != n)
+            throw std::runtime_error("cugo: ordering lost nodes");
+    }
+    std::vector<int> iperm(n);
+    for (int i = 0; i < n; i++)
+        iperm[perm[i]] = i;
+
+    // ---- 2. elimination tree (Liu, path compression) + postorder -----------------------
+    auto etree = [&](const std::vector<int>& ip, const std::vector<int>& pm, std::vector<int>& parent) {
+        parent.assign(n, -1);
+        std::vector<int> anc(n, -1);
+        for (int j = 0; j < n; j++)
+        {
+            const int vj = pm[j];
+            for (int k = g.ptr[vj]; k < g.ptr[vj + 1]; k++)
+            {
+                int i = ip[g.adj[k]];
+                while (i != -1 && i < j)
+                {
+                    const int nx = anc[i];
+                    anc[i] = j;
+                    if (nx == -1)
+                        parent[i] = j;
+                    i = nx;
+                }
+            }
+        }
+    };
+    std::vector<int> parent;
+    etree(iperm, perm, parent);
+    {
+        // children lists (ascending), iterative DFS postorder
+        std::vector<int> head(n, -1), next(n, -1);
+        for (int j = n - 1; j >= 0; j--)
+            if (parent[j] >= 0)
+            {
+                next[j] = head[parent[j]];
+                head[parent[j]] = j;
+            }
+        std::vector<int> post;
+        post.reserve(n);
+        std::vector<int> stack;
+        for (int r = 0; r < n; r++)
+        {
+            if (parent[r] != -1)
+                continue;
+            stack.push_back(r);
+            while (!stack.empty())
+            {
+                const int v = stack.back();
+                const int c = head[v];
+                if (c == -1)
+                {
+                    post.push_back(v);
+                    stack.pop_back();
+                }
+                else
+                {
+                    head[v] = next[c];
+                    stack.push_back(c);
+                }
+            }
+        }
+        std::vector<int> perm2(n);
+        for (int k = 0; k < n; k++)
+            perm2[k] = perm[post[k]];
+        perm.swap(perm2);
+        for (int i = 0; i < n; i++)
+            iperm[perm[i]] = i;
+        etree(iperm, perm, parent);
+    }
+
+    // ---- 3. column structures of L (block level) ---------------------------------------
+    std::vector<int> cptr(n + 1, 0);
+    std::vector<int> cidx; // struct(j): rows > j, sorted
+    std::vector<int> nchild(n, 0);
+    {
+        std::vector<int> head(n, -1), next(n, -1);
+        for (int j = n - 1; j >= 0; j--)
+            if (parent[j] >= 0)
+            {
+                next[j] = head[parent[j]];
+                head[parent[j]] = j;
+                nchild[parent[j]]++;
+            }
+        std::vector<int> mark(n, -1), tmp;
+        cidx.reserve((size_t)n * 16);
+        for (int j = 0; j < n; j++)
+        {
+            tmp.clear();
+            mark[j] = j;
+            const int vj = perm[j];
+            for (int k = g.ptr[vj]; k < g.ptr[vj + 1]; k++)
+            {
+                const int i = iperm[g.adj[k]];
+                if (i > j && mark[i] != j)
+                {
+                    mark[i] = j;
+                    tmp.push_back(i);
+                }
+            }
+            for (int c = head[j]; c != -1; c = next[c])
+                for (int k = cptr[c]; k < cptr[c + 1]; k++)
+                {
+                    const int i = cidx[k];
+                    if (i > j && mark[i] != j)
+                    {
+                        mark[i] = j;
+                        tmp.push_back(i);
+                    }
+                }
+            std::sort(tmp.begin(), tmp.end());
+            cidx.insert(cidx.end(), tmp.begin(), tmp.end());
+            cptr[j + 1] = (int)cidx.size();
+        }
+    }
+    auto csize = [&](int j) { return cptr[j + 1] - cptr[j]; };
+
+    // ---- 4. fundamental supernodes, then relaxed amalgamation --------------------------
+    std::vector<int> sfirst; // first column of each supernode (ascending)
+    for (int j = 0; j < n; j++)
+    {
+        const bool cont = j > 0 && parent[j - 1] == j && nchild[j] == 1 && csize(j - 1) == csize(j) + 1;
+        if (!cont)
+            sfirst.push_back(j);
+    }
+    int ns = (int)sfirst.size();
+    sfirst.push_back(n);
+    {
+        // s -> [first,last]; parent supernode via parent[last]
+        std::vector<int> first(sfirst.begin(), sfirst.end() - 1), last(ns), alive(ns, 1);
+        for (int s = 0; s < ns; s++)
+            last[s] = sfirst[s + 1] - 1;
+        std::vector<int> col2s(n);
+        for (int s = 0; s < ns; s++)
+            for (int j = first[s]; j <= last[s]; j++)
+                col2s[j] = s;
+        // zeros[s]: explicit zero blocks already accepted in supernode s
+        std::vector<double> zeros(ns, 0.0);
+        for (int p = 0; p < ns; p++)
+        {
+            if (!alive[p])
+                continue;
+            for (;;)
+            {
+                const int cl = first[p] - 1; // candidate child = supernode ending right before p
+                if (cl < 0)
+                    break;
+                const int c = col2s[cl];
+                if (!alive[c] || parent[cl] != first[p])
+                    break;
+                const int nc_c = last[c] - first[c] + 1, nc_p = last[p] - first[p] + 1;
+                if (nc_c + nc_p > opt.max_super_cols)
+                    break;
+                const int rows_p = csize(last[p]);           // boundary of p
+                const int rows_c = csize(last[c]);           // boundary of c (includes p's cols it hits)
+                const double extra = (double)nc_c * (nc_p + rows_p - rows_c);
+                const double tot_blocks = (double)(nc_c + nc_p) * (nc_c + nc_p + 1) / 2 +
+                                          (double)(nc_c + nc_p) * rows_p;
+                const double z = zeros[p] + zeros[c] + extra;
+                if (nc_c + nc_p > 2 && z > opt.zero_frac * tot_blocks)
+                    break;
+                // merge c into p
+                for (int j = first[c]; j <= last[c]; j++)
+                    col2s[j] = p;
+                first[p] = first[c];
+                zeros[p] = z;
+                alive[c] = 0;
+            }
+        }
+        std::vector<int> nf;
+        for (int s = 0; s < ns; s++)
+            if (alive[s])
+                nf.push_back(first[s]);
+        std::sort(nf.begin(), nf.end());
+        sfirst = nf;
+        ns = (int)sfirst.size();
+        sfirst.push_back(n);
+    }
+
+    P.perm.assign(perm.begin(), perm.end());
+    P.iperm.assign(iperm.begin(), iperm.end());
+    P.n_super = ns;
+    P.super_ptr.assign(sfirst.begin(), sfirst.end());
+    P.col_front.resize(n);
+    for (int s = 0; s < ns; s++)
+        for (int j = sfirst[s]; j < sfirst[s + 1]; j++)
+            P.col_front[j] = s;
+
+    // ---- 5. fronts: boundary rows, parents, relative indices ---------------------------
+    P.rows_ptr.assign(ns + 1, 0);
+    P.ncb.resize(ns), P.nb.resize(ns), P.col0.resize(ns), P.off.resize(ns), P.sparent.assign(ns, -1);
+    int64_t off = 0;
+    for (int s = 0; s < ns; s++)
+    {
+        const int lastc = sfirst[s + 1] - 1;
+        const int nr = csize(lastc);
+        P.rows_ptr[s + 1] = P.rows_ptr[s] + nr;
+        P.rows.insert(P.rows.end(), cidx.begin() + cptr[lastc], cidx.begin() + cptr[lastc + 1]);
+        P.ncb[s] = sfirst[s + 1] - sfirst[s];
+        P.nb[s] = P.ncb[s] + nr;
+        P.col0[s] = sfirst[s];
+        P.off[s] = off;
+        const int64_t ld = 6LL * P.nb[s] + 1;
+        off += ld * 6LL * P.nb[s];
+        P.ld_max = std::max<long>(P.ld_max, (long)ld);
+        if (nr > 0)
+            P.sparent[s] = P.col_front[P.rows[P.rows_ptr[s]]];
+        const double nc = 6.0 * P.ncb[s], nrs = 6.0 * nr;
+        P.nnzL += nc * (nc + 1) / 2 + nc * nrs;
+        P.flops += 2.0 * (nc * nc * nc / 6.0 + nc * nc * nrs / 2.0 + nc * nrs * nrs / 2.0) +
+                   nc * nc * nrs; // LL^T of the pivot block + TRSM + SYRK of the update
+    }
+    P.front_doubles = off;
+    // children (ascending order => fixed, deterministic extend-add order)
+    P.child_ptr.assign(ns + 1, 0);
+    for (int s = 0; s < ns; s++)
+        if (P.sparent[s] >= 0)
+            P.child_ptr[P.sparent[s] + 1]++;
+    for (int s = 0; s < ns; s++)
+        P.child_ptr[s + 1] += P.child_ptr[s];
+    P.child.resize(P.child_ptr[ns]);
+    {
+        std::vector<int> pos(P.child_ptr.begin(), P.child_ptr.end() - 1);
+        for (int s = 0; s < ns; s++)
+            if (P.sparent[s] >= 0)
+                P.child[pos[P.sparent[s]]++] = s;
+    }
+    P.rel_ptr.assign(ns + 1, 0);
+    for (int s = 0; s < ns; s++)
+        P.rel_ptr[s + 1] = P.rel_ptr[s] + (P.rows_ptr[s + 1] - P.rows_ptr[s]);
+    P.rel.resize(P.rel_ptr[ns]);
+    for (int s = 0; s < ns; s++)
+    {
+        const int p = P.sparent[s];
+        if (p < 0)
+            continue;
+        const int pf = sfirst[p], pl = sfirst[p + 1]; // parent's columns [pf,pl)
+        const int* prow = P.rows.data() + P.rows_ptr[p];
+        const int pnr = P.rows_ptr[p + 1] - P.rows_ptr[p];
+        int q = 0;
+        for (int k = P.rows_ptr[s]; k < P.rows_ptr[s + 1]; k++)
+        {
+            const int r = P.rows[k];
+            int pos;
+            if (r < pl)
+            {
+                if (r < pf)
+                    throw std::runtime_error("cugo: symbolic: child row below parent front");
+                pos = r - pf;
+            }
+            else
+            {
+                while (q < pnr && prow[q] < r)
+                    q++;
+                if (q >= pnr || prow[q] != r)
+                    throw std::runtime_error("cugo: symbolic: child row missing in parent front");
+                pos = P.ncb[p] + q;
+            }
+            P.rel[P.rel_ptr[s] + (k - P.rows_ptr[s])] = pos;
+        }
+    }
+
+    // ---- 6. assembly map of the Hsc blocks ---------------------------------------------
+    const int B = rowptr[n];
+    P.blk_front.resize(B), P.blk_row.resize(B), P.blk_col.resize(B), P.blk_trans.resize(B);
+    for (int r = 0; r < n; r++)
+        for (int k = rowptr[r]; k < rowptr[r + 1]; k++)
+        {
+            const int a = iperm[r], b = iperm[colind[k]];
+            const int lo = std::min(a, b), hi = std::max(a, b);
+            const int s = P.col_front[lo];
+            int rowpos;
+            if (hi < sfirst[s + 1])
+                rowpos = hi - sfirst[s];
+            else
+            {
+                const int* rb = P.rows.data() + P.rows_ptr[s];
+                const int* re = P.rows.data() + P.rows_ptr[s + 1];
+                const int* it = std::lower_bound(rb, re, hi);
+                if (it == re || *it != hi)
+                    throw std::runtime_error("cugo: symbolic: matrix entry outside front");
+                rowpos = P.ncb[s] + (int)(it - rb);
+            }
+            P.blk_front[k] = s;
+            P.blk_row[k] = rowpos;
+            P.blk_col[k] = lo - sfirst[s];
+            P.blk_trans[k] = (a < b) ? 1 : 0; // stored block is A(a,b); lower needs A(hi,lo)
+        }
+
+    // ---- 7. schedule: bottom subtrees -> one task each (stage 0), the rest by level ----
+    std::vector<double> work(ns), sub(ns);
+    for (int s = 0; s < ns; s++)
+    {
+        const double nc = 6.0 * P.ncb[s], nr = 6.0 * (P.nb[s] - P.ncb[s]);
+        work[s] = nc * nc * nc / 3 + nc * nc * nr + nc * nr * nr + 2000.0;
+        sub[s] = work[s];
+    }
+    for (int s = 0; s < ns; s++) // children have smaller index than parents (postorder)
+        if (P.sparent[s] >= 0)
+            sub[P.sparent[s]] += sub[s];
+    double total = 0;
+    for (int s = 0; s < ns; s++)
+        total += work[s];
+    const double wtask = total / std::max(1, opt.target_tasks);
+    // a front is "lower" if its subtree fits in one task
+    std::vector<char> lower(ns);
+    for (int s = 0; s < ns; s++)
+        lower[s] = sub[s] <= wtask;
+    std::vector<int> lvl(ns, 0);
+    int max_lvl = 0;
+    for (int s = 0; s < ns; s++)
+    {
+        if (lower[s])
+            continue;
+        int l = 1;
+        for (int k = P.child_ptr[s]; k < P.child_ptr[s + 1]; k++)
+        {
+            const int c = P.child[k];
+            l = std::max(l, lower[c] ? 1 : lvl[c] + 1);
+        }
+        lvl[s] = l;
+        max_lvl = std::max(max_lvl, l);
+    }
+    // stage 0 tasks: maximal lower subtrees (root = lower front whose parent is not lower)
+    std::vector<int> task_root_of(ns, -1);
+    std::vector<std::vector<int>> stage_tasks(max_lvl + 1);
+    P.task_ptr.assign(1, 0);
+    for (int s = ns - 1; s >= 0; s--)
+    {
+        if (!lower[s])
+            continue;
+        const int p = P.sparent[s];
+        task_root_of[s] = (p >= 0 && lower[p]) ? task_root_of[p] : s;
+    }
+    {
+        // collect fronts of each lower subtree in ascending (= post) order
+        std::vector<int> roots;
+        for (int s = 0; s < ns; s++)
+            if (lower[s] && task_root_of[s] == s)
+                roots.push_back(s);
+        std::vector<int> root_slot(ns, -1);
+        for (size_t i = 0; i < roots.size(); i++)
+            root_slot[roots[i]] = (int)i;
+        std::vector<std::vector<int>> lists(roots.size());
+        for (int s = 0; s < ns; s++)
+            if (lower[s])
+                lists[root_slot[task_root_of[s]]].push_back(s);
+        P.stage_task_ptr.assign(1, 0);
+        for (auto& l : lists)
+        {
+            P.task_fronts.insert(P.task_fronts.end(), l.begin(), l.end());
+            P.task_ptr.push_back((int)P.task_fronts.size());
+        }
+        if (!lists.empty())
+            P.stage_task_ptr.push_back((int)P.task_ptr.size() - 1);
+    }
+    for (int l = 1; l <= max_lvl; l++)
+    {
+        bool any = false;
+        for (int s = 0; s < ns; s++)
+            if (!lower[s] && lvl[s] == l)
+            {
+                P.task_fronts.push_back(s);
+                P.task_ptr.push_back((int)P.task_fronts.size());
+                any = true;
+            }
+        if (any)
+            P.stage_task_ptr.push_back((int)P.task_ptr.size() - 1);
+    }
+    P.n_stages = (int)P.stage_task_ptr.size() - 1;
+}
+
+} // namespace cugo_host

@@ -1,0 +1,51 @@
+// Host-side ordering + symbolic analysis for the multifrontal block LL^T.
+// Replaces cusolverSpXcsrmetisndHost + csrcholAnalysis (ref: src/cholesky.hpp:97-98,295-296).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace cugo_host
+{
+
+struct CholOptions
+{
+    int nd_leaf = 24;        // nested dissection stops below this many block nodes
+    int max_super_cols = 8;  // relaxed supernodes: at most this many block columns
+    double zero_frac = 0.35; // relaxed supernodes: tolerated share of explicit zero blocks
+    int target_tasks = 1024; // subtree-to-workgroup granularity of stage 0
+    static CholOptions from_env();
+};
+
+struct CholPlan
+{
+    int n = 0; // block rows/cols of the matrix
+    std::vector<int32_t> perm, iperm; // perm[new] = old
+
+    int n_super = 0;
+    std::vector<int32_t> super_ptr;      // [n_super+1] column ranges (new ordering)
+    std::vector<int32_t> rows_ptr, rows; // boundary block rows per supernode (new ordering)
+    std::vector<int32_t> sparent;        // parent supernode, -1 for roots
+    std::vector<int32_t> child_ptr, child;
+    std::vector<int32_t> rel_ptr, rel;   // per (child) supernode: block row in the parent front
+    std::vector<int32_t> ncb, nb, col0;
+    std::vector<int64_t> off;
+    int64_t front_doubles = 0;
+    std::vector<int32_t> col_front;      // new column -> supernode
+
+    int n_stages = 0;
+    std::vector<int32_t> stage_task_ptr; // [n_stages+1]
+    std::vector<int32_t> task_ptr, task_fronts;
+
+    std::vector<int32_t> blk_front, blk_row, blk_col; // per Hsc block
+    std::vector<uint8_t> blk_trans;
+
+    long ld_max = 1;
+    double nnzL = 0;  // scalars in L (incl. explicit zeros of relaxed supernodes)
+    double flops = 0; // factorisation flops (2 * multiply-adds)
+};
+
+// pattern: upper block CSR (columns ascending, diagonal included)
+void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const CholOptions& opt,
+                  CholPlan& plan);
+
+} // namespace cugo_host

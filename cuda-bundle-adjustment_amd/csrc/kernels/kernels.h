@@ -1,0 +1,87 @@
+// Host-callable launchers of the HIP kernels (internal; the public surface is include/cugo_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../../include/cugo_hip.h"
+
+namespace cugo_k
+{
+
+// scratch for deterministic two-stage reductions: partial sums per workgroup
+struct ReduceScratch
+{
+    double* d_partials; // capacity doubles
+    size_t capacity;
+};
+
+// --- edge / landmark / pose passes (ba_kernels.hip) ---------------------------------------
+void launch_errors(hipStream_t s, const cugo_edges& ev, const double* d_poses, const double* d_lms,
+                   cugo_robust rk, ReduceScratch rs, double* d_chi);
+
+void launch_build(hipStream_t s, const cugo_edges& ev, const double* d_poses, const double* d_lms,
+                  cugo_robust rk, double* d_Hpp, double* d_bp, double* d_Hll, double* d_bl,
+                  double* d_Hpl, ReduceScratch rs, double* d_chi);
+
+void launch_max_diagonal(hipStream_t s, const double* d_Hpp, int nP, const double* d_Hll, int nL,
+                         ReduceScratch rs, double* d_out);
+
+void launch_schur(hipStream_t s, const cugo_edges& ev, const cugo_hsc_struct& hs, double lambda,
+                  int damp_hsc_diag, const double* d_Hpp, const double* d_bp, const double* d_Hll,
+                  const double* d_bl, const double* d_Hpl, double* d_invHll, double* d_T,
+                  double* d_bsc, double* d_Hsc);
+
+// lambda_pose: damping used in the pose part of the scale sum (0 on ranks > 0 of a sharded run
+// so that the all-reduced scale counts lambda*|xp|^2 once)
+void launch_backsubst_update(hipStream_t s, const cugo_edges& ev, double lambda, double lambda_pose,
+                             const double* d_invHll, const double* d_bl, const double* d_bp,
+                             const double* d_Hpl, const double* d_xp, double* d_xl,
+                             const double* d_poses_in, const double* d_lms_in, double* d_poses_out,
+                             double* d_lms_out, ReduceScratch rs, double* d_scale);
+
+size_t reduce_scratch_doubles(int n_edges, int n_poses, int n_landmarks);
+
+// --- multifrontal LL^T (chol_kernels.hip) -------------------------------------------------
+// Device-side plan; all index arrays in units of 6x6 blocks unless noted.
+struct CholPlanDev
+{
+    int n_fronts;
+    // per front
+    const int32_t* ncb;        // pivot block columns
+    const int32_t* nb;         // total block rows (pivot + boundary); scalar ld = 6*nb + 1
+    const int64_t* off;        // offset (doubles) of the front matrix in `fronts`
+    const int32_t* col0;       // first pivot column (new ordering, block units)
+    const int32_t* rows_ptr;   // [n_fronts+1] into rows: boundary block rows (new ordering)
+    const int32_t* rows;
+    const int32_t* child_ptr;  // [n_fronts+1] children of each front
+    const int32_t* child;      // child front ids
+    const int32_t* rel_ptr;    // [n_fronts+1] (indexed by CHILD front) into rel
+    const int32_t* rel;        // position (block row in the parent front) of each boundary row
+    // schedule
+    int n_stages;
+    const int32_t* task_ptr;   // [n_tasks_total+1] into task_fronts
+    const int32_t* task_fronts;
+    // assembly of A (one entry per Hsc block)
+    int n_hsc_blocks;
+    const int32_t* blk_front;
+    const int32_t* blk_row;    // block row in the front
+    const int32_t* blk_col;    // block col in the front
+    const uint8_t* blk_trans;  // 1: store transposed
+    // rhs / solution mapping
+    int n;                     // block rows of the matrix
+    const int32_t* perm;       // new -> old
+    const int32_t* col_front;  // new col -> front
+};
+
+void launch_chol_assemble(hipStream_t s, const CholPlanDev& p, double* d_fronts, size_t front_doubles,
+                          const double* d_Hsc, double lambda, const double* d_bsc);
+void launch_chol_factor_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,
+                              int ntasks, size_t lds_bytes, int32_t* d_fail);
+void launch_chol_backward_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,
+                                int ntasks, size_t lds_bytes, double* d_xnew, double* d_x);
+// LDS bytes needed by the two stage kernels for a front with scalar leading dimension ld
+size_t chol_lds_factor_bytes(long ld_max);
+size_t chol_lds_backward_bytes(long ld_max);
+
+} // namespace cugo_k

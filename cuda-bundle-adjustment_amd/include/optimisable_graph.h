@@ -1,0 +1,390 @@
+// g2o-shaped graph objects of the cugo API: vertices, vertex sets, edges, edge sets.
+// Class and method names follow the reference (ref: src/optimisable_graph.h:40-816,
+// src/optimisable_graph.hpp) so ORB-SLAM2-style callers compile unchanged; the bodies are
+// host-only containers — flattening to device arrays happens in the optimiser
+// (csrc/host/graph_optimisation.cpp), nothing here touches the GPU runtime.
+//
+// Differences from the reference worth knowing:
+//  * edge containers keep insertion order (the reference iterates an unordered_set of
+//    pointers, so its device edge order — and fp64 atomic sums — vary run to run);
+//  * robust-kernel parameters are per edge set, not a process-global device object.
+#pragma once
+#include <algorithm>
+#include <array>
+#include <cassert>
+#include <cstdint>
+#include <map>
+#include <type_traits>
+#include <vector>
+
+#include "cugo_types.h"
+
+namespace cugo
+{
+
+class BaseEdge;
+class BaseEdgeSet;
+
+// ordered set of edges with O(1) insert and O(n) erase (sets are small per vertex)
+class EdgeContainer
+{
+public:
+    using iterator = std::vector<BaseEdge*>::const_iterator;
+    iterator begin() const { return v_.begin(); }
+    iterator end() const { return v_.end(); }
+    std::size_t size() const { return v_.size(); }
+    bool empty() const { return v_.empty(); }
+    std::size_t count(BaseEdge* e) const { return std::find(v_.begin(), v_.end(), e) != v_.end(); }
+    void insert(BaseEdge* e) { v_.push_back(e); }
+    void erase(BaseEdge* e)
+    {
+        auto it = std::find(v_.begin(), v_.end(), e);
+        if (it != v_.end())
+            v_.erase(it);
+    }
+    void clear() { v_.clear(); }
+    void reserve(std::size_t n) { v_.reserve(n); }
+
+private:
+    std::vector<BaseEdge*> v_;
+};
+
+// ------------------------------------------------------------------ vertices -----------
+class BaseVertex
+{
+public:
+    virtual ~BaseVertex() {}
+    virtual int getId() const noexcept = 0;
+    virtual void setId(const int id) noexcept = 0;
+    virtual EdgeContainer& getEdges() noexcept = 0;
+    virtual void addEdge(BaseEdge* edge) = 0;
+    virtual void removeEdge(BaseEdge* edge) = 0;
+    virtual void setFixed(bool status) noexcept = 0;
+    virtual bool isFixed() const noexcept = 0;
+    virtual int getIndex() const noexcept = 0;
+    virtual void setIndex(const int idx) noexcept = 0;
+    virtual bool isMarginilised() const noexcept = 0;
+    virtual void clearEdges() noexcept = 0;
+};
+
+// ref: Vertex<T, Marginilised> src/optimisable_graph.h:109-155
+template <typename T, bool Marginilised>
+class Vertex : public BaseVertex
+{
+public:
+    using EstimateType = T;
+    const bool marginilised = Marginilised;
+
+    Vertex() {}
+    Vertex(int id, const EstimateType& est, bool fixed = false) : estimate(est), fixed(fixed), id(id) {}
+    Vertex(int id, bool fixed = false) : fixed(fixed), id(id) {}
+
+    EstimateType& getEstimate() noexcept { return estimate; }
+    const EstimateType& getEstimate() const noexcept { return estimate; }
+    void setEstimate(const EstimateType& est) noexcept { estimate = est; }
+    EdgeContainer& getEdges() noexcept override { return edges; }
+    void addEdge(BaseEdge* e) override { edges.insert(e); }
+    void removeEdge(BaseEdge* e) override { edges.erase(e); }
+    void setFixed(bool s) noexcept override { fixed = s; }
+    bool isFixed() const noexcept override { return fixed; }
+    void setId(const int i) noexcept override { id = i; }
+    int getId() const noexcept override { return id; }
+    int getIndex() const noexcept override { return idx; }
+    void setIndex(const int i) noexcept override { idx = i; }
+    bool isMarginilised() const noexcept override { return Marginilised; }
+    void clearEdges() noexcept override { edges.clear(); }
+
+protected:
+    EstimateType estimate{};
+    bool fixed = false;
+    int id = -1;
+    int idx = -1; // device index, assigned by initialize(): free vertices first
+    EdgeContainer edges;
+};
+
+using PoseVertex = Vertex<Se3D, false>;
+using LandmarkVertex = Vertex<Vec3d, true>;
+
+class BaseVertexSet
+{
+public:
+    virtual ~BaseVertexSet() {}
+    virtual bool removeVertex(BaseVertex* v, BaseEdgeSet* edgeSet) = 0;
+    virtual size_t size() const noexcept = 0;
+    virtual size_t estimateDataSize() const noexcept = 0;
+    virtual size_t getDeviceEstimateSize() noexcept = 0;
+    virtual bool isMarginilised() const noexcept = 0;
+    virtual int getActiveSize() const noexcept = 0;
+    virtual void clearEstimates() noexcept = 0;
+    virtual void clearVertices() noexcept = 0;
+    // flattening hooks used by the optimiser (ascending id; free first, fixed after —
+    // ref: generateEstimateData src/optimisable_graph.hpp:84-126)
+    virtual int estimateDim() const noexcept = 0;
+    virtual void assignIndices(int firstFree, int firstFixed, int& nFree, int& nFixed) = 0;
+    virtual void gatherEstimates(double* out) const = 0;        // by index, estimateDim each
+    virtual void scatterEstimates(const double* in) = 0;        // ref: finalise() hpp:137-154
+    virtual int countFree() const noexcept = 0;
+};
+
+// ref: VertexSet<T, E> src/optimisable_graph.h:224-332
+template <typename T, typename E>
+class VertexSet : public BaseVertexSet
+{
+public:
+    using VertexType = T;
+    using EstimateType = E;
+
+    explicit VertexSet(bool marg) : marginilised(marg) {}
+
+    void addVertex(T* vertex) { vertexMap.emplace(vertex->getId(), vertex); }
+    T* getVertex(const int id) const { return vertexMap.at(id); }
+    bool removeVertex(BaseVertex* v, BaseEdgeSet* edgeSet) override;
+    size_t size() const noexcept override { return vertexMap.size(); }
+    bool isMarginilised() const noexcept override { return marginilised; }
+    std::vector<T*>& get() noexcept { return vertices; } // index order after initialize()
+    size_t estimateDataSize() const noexcept override { return vertices.size(); }
+    size_t getDeviceEstimateSize() noexcept override { return vertices.size(); }
+    int getActiveSize() const noexcept override { return activeSize; }
+    void clearEstimates() noexcept override
+    {
+        vertices.clear();
+        activeSize = 0;
+    }
+    void clearVertices() noexcept override { vertexMap.clear(); }
+
+    int estimateDim() const noexcept override { return (int)(sizeof(E) / sizeof(double)); }
+    int countFree() const noexcept override
+    {
+        int c = 0;
+        for (const auto& kv : vertexMap)
+            c += !kv.second->isFixed();
+        return c;
+    }
+    void assignIndices(int firstFree, int firstFixed, int& nFree, int& nFixed) override
+    {
+        const int total = (int)vertexMap.size();
+        const int nfree = countFree();
+        vertices.assign(total, nullptr);
+        int f = 0, x = 0;
+        for (const auto& kv : vertexMap)
+        {
+            T* v = kv.second;
+            if (!v->isFixed())
+            {
+                v->setIndex(firstFree + f);
+                vertices[f++] = v;
+            }
+            else
+            {
+                v->setIndex(firstFixed + x);
+                vertices[nfree + x++] = v;
+            }
+        }
+        activeSize = nfree;
+        nFree = nfree;
+        nFixed = x;
+    }
+    void gatherEstimates(double* out) const override
+    {
+        static_assert(std::is_trivially_copyable<E>::value, "estimate must be POD");
+        const int d = (int)(sizeof(E) / sizeof(double));
+        for (const T* v : vertices)
+        {
+            const E& e = v->getEstimate();
+            const double* src = reinterpret_cast<const double*>(&e);
+            std::copy(src, src + d, out + (size_t)v->getIndex() * d);
+        }
+    }
+    void scatterEstimates(const double* in) override
+    {
+        const int d = (int)(sizeof(E) / sizeof(double));
+        for (T* v : vertices)
+        {
+            E e;
+            std::copy(in + (size_t)v->getIndex() * d, in + (size_t)(v->getIndex() + 1) * d,
+                      reinterpret_cast<double*>(&e));
+            v->setEstimate(e);
+        }
+    }
+
+protected:
+    std::map<int, VertexType*> vertexMap; // ascending id
+    bool marginilised;
+    std::vector<VertexType*> vertices;
+    int activeSize = 0;
+};
+
+using PoseVertexSet = VertexSet<PoseVertex, Se3D>;
+using LandmarkVertexSet = VertexSet<LandmarkVertex, Vec3d>;
+
+// ------------------------------------------------------------------ edges --------------
+class BaseEdge
+{
+public:
+    using Information = Scalar;
+    virtual ~BaseEdge() {}
+    virtual BaseVertex* getVertex(const int index) = 0;
+    virtual void setVertex(BaseVertex* vertex, const int index) = 0;
+    virtual bool allVerticesFixed() const noexcept = 0;
+    virtual bool anyVerticesNotFixed() const noexcept = 0;
+    virtual bool allVerticesNotFixed() const noexcept = 0;
+    virtual void* getMeasurement() noexcept { return nullptr; }
+    virtual int dim() const noexcept = 0;
+    virtual void setInformation(const Information info) noexcept = 0;
+    virtual Information getInformation() noexcept = 0;
+    virtual void setCamera(const Camera& camera) noexcept = 0;
+    virtual Camera& getCamera() noexcept = 0;
+    virtual void inactivate() noexcept = 0;
+    virtual void setActive() noexcept = 0;
+    virtual bool isActive() const noexcept = 0;
+};
+
+// ref: Edge<DIM, E, VertexTypes...> src/optimisable_graph.h:416-503
+template <int DIM, typename E, typename... VertexTypes>
+class Edge : public BaseEdge
+{
+public:
+    using Measurement = E;
+    static constexpr auto VertexSize = sizeof...(VertexTypes);
+
+    Edge() : measurement(Measurement()), info_(0), isActive_(true)
+    {
+        for (auto& v : vertices)
+            v = nullptr;
+    }
+
+    BaseVertex* getVertex(const int index) override { return vertices[index]; }
+    void setVertex(BaseVertex* vertex, const int index) override { vertices[index] = vertex; }
+    bool allVerticesFixed() const noexcept override
+    {
+        for (auto* v : vertices)
+            if (!v->isFixed())
+                return false;
+        return true;
+    }
+    bool anyVerticesNotFixed() const noexcept override { return !allVerticesFixed(); }
+    bool allVerticesNotFixed() const noexcept override
+    {
+        for (auto* v : vertices)
+            if (v->isFixed())
+                return false;
+        return true;
+    }
+    int dim() const noexcept override { return DIM; }
+    void setMeasurement(const Measurement& m) noexcept { measurement = m; }
+    void setInformation(const Information info) noexcept override { info_ = info; }
+    Information getInformation() noexcept override { return info_; }
+    void setCamera(const Camera& camera) noexcept override { camera_ = camera; }
+    Camera& getCamera() noexcept override { return camera_; }
+    void inactivate() noexcept override { isActive_ = false; }
+    void setActive() noexcept override { isActive_ = true; }
+    bool isActive() const noexcept override { return isActive_; }
+
+protected:
+    Measurement measurement;
+    Information info_;
+    Camera camera_;
+    BaseVertex* vertices[VertexSize];
+    bool isActive_;
+};
+
+class BaseEdgeSet
+{
+public:
+    using Information = Scalar;
+    virtual ~BaseEdgeSet() {}
+    virtual void addEdge(BaseEdge* edge) = 0;
+    virtual void removeEdge(BaseEdge* edge) = 0;
+    virtual size_t nedges() const noexcept = 0;
+    virtual size_t nActiveEdges() const noexcept = 0;
+    virtual const EdgeContainer& get() noexcept = 0;
+    virtual const int dim() const noexcept = 0;
+    virtual void clearEdges() noexcept = 0;
+    virtual void setRobustKernel(const RobustKernelType type, Scalar delta) noexcept = 0;
+    virtual RobustKernel& getRobustKernel() noexcept = 0;
+    virtual void setInformation(const Information info) noexcept = 0;
+    virtual Information getInformation() noexcept = 0;
+    virtual void setCamera(const Camera& camera) noexcept = 0;
+    virtual Camera& getCamera() noexcept = 0;
+    virtual Scalar getOutlierThreshold() const noexcept = 0;
+    virtual uint32_t getOutlierCount() const noexcept = 0;
+    virtual uint32_t getInlierCount() const noexcept = 0;
+    virtual bool isDirty() const noexcept = 0;
+    virtual void setDirtyState(bool state) noexcept = 0;
+    // set by the optimiser at initialize(): number of edges with at least one free vertex
+    virtual void setActiveEdgeCount(size_t n) noexcept = 0;
+};
+
+// ref: EdgeSet<DIM, E, VertexTypes...> src/optimisable_graph.h:688-816
+template <int DIM, typename E, typename... VertexTypes>
+class EdgeSet : public BaseEdgeSet
+{
+public:
+    using MeasurementType = E;
+    static constexpr auto VertexSize = sizeof...(VertexTypes);
+
+    void addEdge(BaseEdge* edge) override
+    {
+        for (int i = 0; i < (int)VertexSize; ++i)
+            edge->getVertex(i)->addEdge(edge);
+        edges.insert(edge);
+        isDirty_ = true;
+    }
+    void removeEdge(BaseEdge* edge) override
+    {
+        for (int i = 0; i < (int)VertexSize; ++i)
+            edge->getVertex(i)->removeEdge(edge);
+        edges.erase(edge);
+        isDirty_ = true;
+    }
+    size_t nedges() const noexcept override { return edges.size(); }
+    size_t nActiveEdges() const noexcept override { return activeEdgeSize_; }
+    const EdgeContainer& get() noexcept override { return edges; }
+    const int dim() const noexcept override { return DIM; }
+    void setRobustKernel(const RobustKernelType type, Scalar delta) noexcept override
+    {
+        kernel.create(type, delta);
+    }
+    RobustKernel& getRobustKernel() noexcept override { return kernel; }
+    void clearEdges() noexcept override
+    {
+        edges.clear();
+        activeEdgeSize_ = 0;
+        isDirty_ = true;
+    }
+    void setInformation(const Information info) noexcept override { info_ = info; }
+    Information getInformation() noexcept override { return info_; }
+    void setCamera(const Camera& camera) noexcept override { camera_ = camera; }
+    Camera& getCamera() noexcept override { return camera_; }
+    void setOutlierThreshold(const Scalar t) noexcept { outlierThreshold = t; }
+    Scalar getOutlierThreshold() const noexcept override { return outlierThreshold; }
+    uint32_t getOutlierCount() const noexcept override { return 0; }
+    uint32_t getInlierCount() const noexcept override { return (uint32_t)activeEdgeSize_; }
+    bool isDirty() const noexcept override { return isDirty_; }
+    void setDirtyState(bool state) noexcept override { isDirty_ = state; }
+    void setActiveEdgeCount(size_t n) noexcept override { activeEdgeSize_ = n; }
+
+protected:
+    EdgeContainer edges;
+    size_t activeEdgeSize_ = 0;
+    RobustKernel kernel;
+    Scalar outlierThreshold = 0.0; // 0 = outlier rejection disabled (out of scope)
+    Information info_ = 0.0;
+    Camera camera_;
+    bool isDirty_ = true;
+};
+
+template <typename T, typename E>
+bool VertexSet<T, E>::removeVertex(BaseVertex* v, BaseEdgeSet* edgeSet)
+{
+    auto it = vertexMap.find(v->getId());
+    if (it == vertexMap.end())
+        return false;
+    const std::vector<BaseEdge*> es(it->second->getEdges().begin(), it->second->getEdges().end());
+    for (BaseEdge* e : es)
+        edgeSet->removeEdge(e);
+    vertexMap.erase(it);
+    return true;
+}
+
+} // namespace cugo

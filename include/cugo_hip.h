@@ -1,0 +1,257 @@
+/*
+ * cugo_hip.h — C ABI of libcugo_hip.so, the MI355X (gfx950) implementation of the bundle-
+ * adjustment hot path of KudanLimited/cuda-bundle-adjustment.
+ *
+ * Two layers, both plain C (pointers + sizes, no C++ or torch types):
+ *
+ *  (1) kernel-level entry points  cugo_*  — one per free function of the reference's
+ *      `namespace cugo::gpu` (src/cuda/cuda_block_solver.h:55-256) and per method of its
+ *      linear-solver object (src/cuda_linear_solver.h:31-53).  All pointers named d_* are
+ *      DEVICE pointers; work is enqueued on the context's HIP stream and is asynchronous
+ *      unless the function returns a host value.
+ *  (2) graph-level entry points   cugo_graph_*  — what a foreign-language binding of the
+ *      reference's public class (include/cuda_graph_optimisation.h:132-252) would call:
+ *      flat host arrays in, BatchStatistics / estimates out.
+ *
+ * Citations "ref:" are file:line in the reference repository.
+ * Every function returns CUGO_OK (0) or a negative error code; cugo_last_error() gives text.
+ * There is NO CPU fallback: without a HIP device every call fails with CUGO_ERR_NO_DEVICE.
+ */
+#ifndef CUGO_HIP_H
+#define CUGO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CUGO_OK 0
+#define CUGO_ERR_NO_DEVICE (-1)
+#define CUGO_ERR_HIP (-2)
+#define CUGO_ERR_INVALID (-3)
+#define CUGO_ERR_NUMERIC (-4) /* zero pivot: ref src/cuda_linear_solver.cpp:44-52 */
+
+/* ref: src/robust_kernel.h:12-17 */
+enum { CUGO_RK_NONE = 0, CUGO_RK_CAUCHY = 1, CUGO_RK_TUKEY = 2 };
+
+/* edge flag bits; bits 0/1 are the reference's EdgeFlag (ref: src/constants.h:28-32) */
+enum
+{
+    CUGO_EDGE_FIXED_L = 1,
+    CUGO_EDGE_FIXED_P = 2,
+    CUGO_EDGE_STEREO = 4,  /* 3-d measurement (StereoEdge) instead of 2-d (MonoEdge) */
+    CUGO_EDGE_INACTIVE = 8 /* outlier / removed: contributes nothing (ref: outliers[e]!=0) */
+};
+
+typedef struct cugo_ctx cugo_ctx; /* device + stream + scratch; replaces CudaDevice */
+
+const char* cugo_last_error(void);
+int cugo_device_count(void);
+/* ref: src/cuda_device.cpp:166-282 (device pick + streams). device<0 = current device. */
+int cugo_ctx_create(int device, cugo_ctx** out);
+void cugo_ctx_destroy(cugo_ctx* ctx);
+int cugo_ctx_sync(cugo_ctx* ctx);
+void* cugo_ctx_stream(cugo_ctx* ctx); /* hipStream_t */
+
+/* ref: src/device_buffer.h:33-276 (RAII device array) — plain allocation helpers */
+int cugo_malloc(void** d_ptr, size_t bytes);
+int cugo_free(void* d_ptr);
+int cugo_memcpy_h2d(cugo_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+int cugo_memcpy_d2h(cugo_ctx* ctx, void* h_dst, const void* d_src, size_t bytes); /* syncs */
+int cugo_memset(cugo_ctx* ctx, void* d_dst, int value, size_t bytes);
+
+/*
+ * Flattened edge data of ALL edge sets of one optimiser, landmark-major:
+ * edges are sorted by (landmark index, pose index); the edges of landmark l are
+ * [lm_ptr[l], lm_ptr[l+1]).  Mono and stereo edges share the arrays (flag bit STEREO).
+ * This replaces the per-set arrays of ref: src/optimisable_graph.hpp:474-601
+ * (measurements | edge2PL | flags | omegas | cameras) and edge2Hpl: the Hpl block of edge
+ * e is block e (identity map), valid when (flags & 3) == 0.
+ * pose_ptr/pose_edge give the same edges grouped by pose (CSR over pose index).
+ */
+typedef struct cugo_edges
+{
+    int n_edges;
+    int n_poses_total, n_landmarks_total; /* incl. fixed (indices >= n_free are fixed) */
+    int n_poses_free, n_landmarks_free;
+    const int32_t* d_pose;   /* [E] pose index      (ref edge2PL[e][0]) */
+    const int32_t* d_lm;     /* [E] landmark index  (ref edge2PL[e][1]) */
+    const double* d_meas;    /* [3][E] planar: u, v, u_right */
+    const double* d_omega;   /* [E] or [1] information (ref omegas) */
+    int n_omega;             /* E or 1  (ref: perEdgeInformation) */
+    const uint8_t* d_flags;  /* [E] CUGO_EDGE_* */
+    const uint16_t* d_cam;   /* [E] index into d_cams, or NULL when n_cams == 1 */
+    const double* d_cams;    /* [n_cams][5] fx fy cx cy bf (ref cameras, deduplicated) */
+    int n_cams;
+    const int32_t* d_lm_ptr;    /* [n_landmarks_total+1] */
+    const int32_t* d_pose_ptr;  /* [n_poses_total+1]     */
+    const int32_t* d_pose_edge; /* [E] edge ids grouped by pose, ascending landmark */
+} cugo_edges;
+
+typedef struct cugo_robust
+{
+    int type;     /* CUGO_RK_* for 2-d (mono) edges */
+    double delta; /* ref: createRkFunction src/cuda/cuda_block_solver.h:61 — passed by value */
+    int type_stereo; /* same for 3-d (stereo) edges: per edge set, not process-global */
+    double delta_stereo;
+} cugo_robust;
+
+/* ---- (1) kernel-level entry points --------------------------------------------------- */
+
+/* ref: gpu::computeActiveErrors_<2|3> (cuda_block_solver.h:179-193; .cu:1060-1133).
+ * d_poses: [n_poses_total][7] (qx qy qz qw tx ty tz), d_lms: [n_landmarks_total][3].
+ * Writes the total chi2 to d_chi[0] (device).  Deterministic (fixed reduction order). */
+int cugo_compute_active_errors(cugo_ctx* ctx, const cugo_edges* ev, const double* d_poses,
+                               const double* d_lms, cugo_robust rk, double* d_chi);
+
+/* ref: gpu::constructQuadraticForm_<2|3> (cuda_block_solver.h:159-176; .cu:1152-1220) plus
+ * the four fillZero calls of BlockSolver::buildSystem (block_solver.cpp:287-294).
+ * Outputs (all column-major blocks, reference layout):
+ *   d_Hpp [Pfree][36], d_bp [Pfree][6], d_Hll [Lfree][9], d_bl [Lfree][3], d_Hpl [E][18].
+ * Also writes chi2 at these estimates to d_chi[0] if d_chi != NULL. No atomics. */
+int cugo_construct_quadratic_form(cugo_ctx* ctx, const cugo_edges* ev, const double* d_poses,
+                                  const double* d_lms, cugo_robust rk, double* d_Hpp,
+                                  double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl,
+                                  double* d_chi);
+
+/* ref: gpu::maxDiagonal x2 (cuda_block_solver.h:78-81; block_solver.cpp:309-320).
+ * d_out[0] = max(0, max diag(Hpp), max diag(Hll)). */
+int cugo_max_diagonal(cugo_ctx* ctx, const double* d_Hpp, int n_poses, const double* d_Hll,
+                      int n_landmarks, double* d_out);
+
+/* Hsc block structure on the device (ref: HschurSparseBlockMatrix,
+ * src/sparse_block_matrix.cpp:63-156, and mulBlockIds .cu:1347-1378).
+ * Upper-triangular block CSR, diagonal block first in each row.  Off-diagonal block k has
+ * the contribution list [d_off_ptr[k], d_off_ptr[k+1]) of (edge_i, edge_j) pairs:
+ * Hsc[k] -= T[edge_i] * Hpl[edge_j]^T. (diagonal blocks use the pose's own edge list). */
+typedef struct cugo_hsc_struct
+{
+    int n_blocks;             /* B */
+    const int32_t* d_rowptr;  /* [Pfree+1] */
+    const int32_t* d_colind;  /* [B] */
+    const int32_t* d_off_ptr; /* [B+1] (empty range for diagonal blocks) */
+    const int32_t* d_off_ei;  /* [M_off] */
+    const int32_t* d_off_ej;  /* [M_off] */
+} cugo_hsc_struct;
+
+/* ref: gpu::addLambda(Hll) + gpu::computeBschure + gpu::computeHschure
+ * (cuda_block_solver.h:83-109; .cu:1256-1345).  Damping is applied on the fly (Hpp/Hll are
+ * left undamped, so no backup/restoreDiagonal pass exists).
+ *   d_invHll [Lfree][9] = (Hll + lambda I)^-1,  d_T [E][18] = Hpl * invHll,
+ *   d_bsc [Pfree][6] = bp - sum T bl,
+ *   d_Hsc [B][36] = Hpp(diag) - sum T Hpl^T            (+ lambda I on diagonal blocks when
+ *   damp_hsc_diag != 0, which reproduces the reference's damped Hsc exactly). */
+int cugo_compute_schur(cugo_ctx* ctx, const cugo_edges* ev, const cugo_hsc_struct* hs,
+                       double lambda, int damp_hsc_diag, const double* d_Hpp, const double* d_bp,
+                       const double* d_Hll, const double* d_bl, const double* d_Hpl,
+                       double* d_invHll, double* d_T, double* d_bsc, double* d_Hsc);
+
+/* Sparse block LL^T of Hsc: replaces HscSparseLinearSolver / CuSparseCholeskySolver
+ * (ref: src/cuda_linear_solver.cpp:27-57, src/cholesky.hpp:170-309 — cuSOLVER csrchol +
+ * METIS).  analyze() = ordering + symbolic (host) once per structure; factor_solve() =
+ * numeric multifrontal LL^T + triangular solves on the device per LM trial. */
+typedef struct cugo_chol cugo_chol;
+int cugo_chol_create(cugo_ctx* ctx, cugo_chol** out);
+void cugo_chol_destroy(cugo_chol* s);
+/* host pattern: upper block CSR incl. diagonal (ref: initialize(Hsc pattern)) */
+int cugo_chol_analyze(cugo_chol* s, int n_block_rows, const int32_t* h_rowptr,
+                      const int32_t* h_colind);
+/* solve (Hsc + lambda I) x = bsc.  d_Hsc [B][36] upper blocks in the analysed pattern,
+ * d_bsc / d_x [n_block_rows][6].  Asynchronous: the zero-pivot flag is written to
+ * d_fail[0] (int32 device, 0 = ok) — ref: solve()->bool, zero pivot tol 1e-14. */
+int cugo_chol_factor_solve(cugo_chol* s, const double* d_Hsc, double lambda, const double* d_bsc,
+                           double* d_x, int32_t* d_fail);
+/* statistics of the analysis: nnz(L) in scalars, factorisation flops, #supernodes, #stages */
+int cugo_chol_stats(const cugo_chol* s, double* nnzL, double* flops, int* n_supernodes,
+                    int* n_stages, double* front_bytes);
+/* symbolic plan export (host arrays) so tests can replay the plan with numpy.  A solver
+ * created with ctx == NULL is host-only: analyze() builds the plan and skips the upload. */
+int cugo_chol_plan_sizes(const cugo_chol* s, int* n, int* n_super, int* n_rows_total);
+int cugo_chol_plan_get(const cugo_chol* s, int32_t* perm, int32_t* super_ptr, int32_t* rows_ptr,
+                       int32_t* rows, int32_t* parent);
+/* named int32 plan array ("perm", "super_ptr", "rows_ptr", "rows", "sparent", "child_ptr",
+ * "child", "rel_ptr", "rel", "ncb", "nb", "col0", "col_front", "stage_task_ptr", "task_ptr",
+ * "task_fronts", "blk_front", "blk_row", "blk_col", "blk_trans"); pointer valid until the
+ * next analyze()/destroy. Returns the length or a negative error. */
+int cugo_chol_plan_array(cugo_chol* s, const char* name, const int32_t** out);
+
+/* ref: gpu::schurComplementPost + updatePoses + updateLandmarks + computeScale
+ * (cuda_block_solver.h:133-150; .cu:1419-1490).  Reads estimates from d_*_in, writes the
+ * updated ("trial") estimates to d_*_out (push/pop of block_solver.cpp:431-439 becomes a
+ * buffer swap).  d_scale[0] = sum_i x_i (lambda x_i + b_i) over [xp; xl]. */
+int cugo_backsubst_update(cugo_ctx* ctx, const cugo_edges* ev, double lambda,
+                          const double* d_invHll, const double* d_bl, const double* d_bp,
+                          const double* d_Hpl, const double* d_xp, double* d_xl,
+                          const double* d_poses_in, const double* d_lms_in, double* d_poses_out,
+                          double* d_lms_out, double* d_scale);
+
+/* ---- (2) graph-level entry points ---------------------------------------------------- */
+
+typedef struct cugo_graph cugo_graph; /* CudaGraphOptimisationImpl + its vertex/edge sets */
+
+/* ref: CudaGraphOptimisationImpl(options) include/cuda_graph_optimisation.h:206;
+ * GraphOptimisationOptions src/graph_optimisation_options.h:8-19 */
+int cugo_graph_create(int per_edge_information, int per_edge_camera, cugo_graph** out);
+void cugo_graph_destroy(cugo_graph* g);
+/* vertices: ids are caller ids (ref: PoseVertex(id, Se3D, fixed), LandmarkVertex(id, Vec3d,
+ * fixed); src/optimisable_graph.h:109-155) */
+int cugo_graph_add_poses(cugo_graph* g, int n, const int32_t* ids, const double* q_t7,
+                         const uint8_t* fixed);
+int cugo_graph_add_landmarks(cugo_graph* g, int n, const int32_t* ids, const double* xyz,
+                             const uint8_t* fixed);
+/* edges: dim = 2 -> MonoEdgeSet, 3 -> StereoEdgeSet (ref: include/ba_types.h:34-169,238-254).
+ * meas is [n][dim]; info [n]; cam [n][5] or NULL to use the set camera. */
+int cugo_graph_add_edges(cugo_graph* g, int dim, int n, const int32_t* pose_ids,
+                         const int32_t* landmark_ids, const double* meas, const double* info,
+                         const double* cam5);
+int cugo_graph_set_camera(cugo_graph* g, int dim, const double* cam5);
+int cugo_graph_set_information(cugo_graph* g, int dim, double info);
+int cugo_graph_set_robust_kernel(cugo_graph* g, int dim, int type, double delta);
+/* multi-GPU: this process handles shard `rank` of `world` (landmark ranges).  exchange() is
+ * called on the host with a DEVICE buffer that must be all-reduced in place over all ranks
+ * (op 0 = sum, 1 = max) before it returns (RCCL via torch.distributed in bench.py). */
+typedef void (*cugo_exchange_fn)(void* d_buf, size_t n_doubles, int op, void* user);
+int cugo_graph_set_shard(cugo_graph* g, int rank, int world, cugo_exchange_fn fn, void* user);
+/* the landmark index range [*l0, *l1) that shard `rank` of `world` owns, given the number
+ * of active edges of every landmark (host only; the rule cugo_graph_initialize applies) */
+int cugo_shard_range(int n_landmarks_total, const int32_t* edges_per_landmark, int rank, int world,
+                     int* l0, int* l1);
+int cugo_graph_initialize(cugo_graph* g);             /* ref: initialize() :147 */
+int cugo_graph_optimize(cugo_graph* g, int n_iters);  /* ref: optimize(n)  :153 */
+int cugo_graph_n_stats(cugo_graph* g);                /* ref: batchStatistics() :158 */
+int cugo_graph_get_stats(cugo_graph* g, int32_t* iteration, double* chi2, int cap);
+int cugo_graph_get_trace(cugo_graph* g, double* lambda, double* rho, int32_t* trials, int cap);
+int cugo_graph_get_poses(cugo_graph* g, int n, const int32_t* ids, double* q_t7);
+int cugo_graph_get_landmarks(cugo_graph* g, int n, const int32_t* ids, double* xyz);
+int cugo_graph_n_active_edges(cugo_graph* g);
+/* per-phase milliseconds accumulated since initialize(): ref getTimeProfile
+ * (block_solver.cpp:470-488).  names is a '\n' separated list written into buf. */
+int cugo_graph_time_profile(cugo_graph* g, char* names_buf, int buf_len, double* ms, int cap);
+int cugo_graph_set_verbose(cugo_graph* g, int verbose);
+/* solver statistics of the last buildStructure: B (Hsc blocks), M (block products),
+ * nnz(L), Cholesky flops, stages */
+int cugo_graph_structure_stats(cugo_graph* g, double* out8);
+
+/* seeded ORB-SLAM-style synthetic graph built directly into a graph.
+ * Returns arrays through the getters above; also usable to feed the CPU oracle. */
+typedef struct cugo_synth_params
+{
+    int n_poses, n_landmarks, n_edges; /* exact counts */
+    double stereo_fraction;            /* fraction of landmarks observed in stereo */
+    double pixel_noise, pose_rot_noise, pose_trans_noise, landmark_noise_rel;
+    int n_loop_closures;
+    uint64_t seed;
+} cugo_synth_params;
+/* fills caller-provided arrays (sizes from params): poses [P][7], lms [L][3],
+ * e_pose/e_lm [E], e_stereo [E], e_meas [E][3], e_omega [E]; cam5 [5].  ids == positions;
+ * pose 0 is the gauge (fixed). */
+int cugo_synth_generate(const cugo_synth_params* p, double* poses, double* lms, int32_t* e_pose,
+                        int32_t* e_lm, uint8_t* e_stereo, double* e_meas, double* e_omega,
+                        double* cam5);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUGO_HIP_H */

@@ -1,0 +1,268 @@
+"""CPU tests of the product's host logic (no GPU compute): library/ABI surface, synthetic
+generator, ordering + symbolic multifrontal plan (replayed with numpy), shard ranges."""
+import ctypes as C
+import importlib
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+cugo = importlib.import_module("cuda-bundle-adjustment_amd")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    cugo.build()
+    return cugo.lib()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "cugo_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = sorted(set(re.findall(r"\b(cugo_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) > 40
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_fails_loudly_without_gpu(lib):
+    if cugo.device_count() > 0:
+        pytest.skip("a GPU is present")
+    g = C.c_void_p()
+    rc = lib.cugo_graph_create(1, 1, C.byref(g))
+    assert rc == -1  # CUGO_ERR_NO_DEVICE
+    assert b"no HIP device" in lib.cugo_last_error()
+    ctx = C.c_void_p()
+    assert lib.cugo_ctx_create(-1, C.byref(ctx)) == -1
+
+
+def test_synthetic_generator_shapes_and_determinism(lib, oracle_lib):
+    P, L, E = 200, 900, 3600
+    a = cugo.synth(P, L, E, seed=7, n_loop_closures=40)
+    b = cugo.synth(P, L, E, seed=7, n_loop_closures=40)
+    c = cugo.synth(P, L, E, seed=8, n_loop_closures=40)
+    for k in a:
+        assert np.array_equal(a[k], b[k])
+    assert not np.array_equal(a["e_meas"], c["e_meas"])
+    assert len(a["e_pose"]) == E and a["e_pose"].max() < P and a["e_lm"].max() == L - 1
+    pairs = a["e_pose"].astype(np.int64) * L + a["e_lm"]
+    assert len(np.unique(pairs)) == E                      # no duplicate (pose, landmark) edges
+    assert np.bincount(a["e_lm"], minlength=L).min() >= 2  # every landmark seen twice or more
+    # quaternions normalised, w >= 0
+    assert np.allclose(np.linalg.norm(a["pose"][:, :4], axis=1), 1.0) and (a["pose"][:, 3] >= 0).all()
+    # the CPU oracle reduces chi2 on it (the graph is a sane BA problem)
+    prob = oracle_lib.Problem(a["pose"], a["pose_fixed"], a["lm"], a["lm_fixed"], a["e_pose"], a["e_lm"],
+                              a["e_stereo"], a["e_meas"], a["e_omega"], a["e_cam"])
+    chi0 = prob.compute_errors()
+    r = prob.optimize(6)
+    assert r[-1]["chi2"] < 0.05 * chi0
+    assert r[-1]["chi2"] < 4.0 * E  # ~ noise level (1 px, 2-3 dof per edge, information <= 1)
+
+
+def covis_pattern(n_poses_free, e_pose_idx, e_lm_idx):
+    """upper block CSR (diag first, ascending) of the Schur complement pattern"""
+    rows = [set([p]) for p in range(n_poses_free)]
+    order = np.argsort(e_lm_idx, kind="stable")
+    lm_sorted = e_lm_idx[order]
+    starts = np.flatnonzero(np.r_[True, lm_sorted[1:] != lm_sorted[:-1], True])
+    for a, b in zip(starts[:-1], starts[1:]):
+        ps = sorted(set(int(p) for p in e_pose_idx[order[a:b]] if p < n_poses_free))
+        for i, p in enumerate(ps):
+            rows[p].update(ps[i:])
+    rowptr, colind = [0], []
+    for p in range(n_poses_free):
+        colind += sorted(rows[p])
+        rowptr.append(len(colind))
+    return np.array(rowptr, np.int32), np.array(colind, np.int32)
+
+
+def random_spd_bsr(rowptr, colind, rng):
+    n = len(rowptr) - 1
+    A = np.zeros((6 * n, 6 * n))
+    vals = np.zeros((len(colind), 36))
+    deg = np.zeros(n)
+    for r in range(n):
+        for k in range(rowptr[r], rowptr[r + 1]):
+            c = colind[k]
+            if c != r:
+                B = rng.normal(size=(6, 6))
+                A[6 * r:6 * r + 6, 6 * c:6 * c + 6] = B
+                A[6 * c:6 * c + 6, 6 * r:6 * r + 6] = B.T
+                vals[k] = B.T.reshape(-1)  # column-major
+                deg[r] += 1
+                deg[c] += 1
+    for r in range(n):
+        M = rng.normal(size=(6, 6))
+        D = M @ M.T + (8.0 * deg[r] + 6.0) * np.eye(6)
+        A[6 * r:6 * r + 6, 6 * r:6 * r + 6] = D
+        vals[rowptr[r]] = D.T.reshape(-1)
+    return A, vals
+
+
+def plan_arrays(lib, s):
+    out = {}
+    for name in ["perm", "super_ptr", "rows_ptr", "rows", "sparent", "child_ptr", "child", "rel_ptr",
+                 "rel", "ncb", "nb", "col0", "col_front", "stage_task_ptr", "task_ptr", "task_fronts",
+                 "blk_front", "blk_row", "blk_col", "blk_trans"]:
+        p = C.POINTER(C.c_int32)()
+        n = lib.cugo_chol_plan_array(s, name.encode(), C.byref(p))
+        assert n >= 0, name
+        out[name] = np.ctypeslib.as_array(p, shape=(n,)).copy() if n else np.zeros(0, np.int32)
+    return out
+
+
+def replay_multifrontal(pl, vals, lam, b):
+    """numpy replay of the device algorithm using ONLY the plan's maps (assembly, extend-add
+    through rel, stage/task order, rhs-row trick, backward pass)."""
+    ns = len(pl["ncb"])
+    n = len(pl["perm"])
+    F = []
+    for f in range(ns):
+        nb = pl["nb"][f]
+        F.append(np.zeros((6 * nb + 1, 6 * nb)))
+    for k in range(len(pl["blk_front"])):
+        f, rb, cb, tr = pl["blk_front"][k], pl["blk_row"][k], pl["blk_col"][k], pl["blk_trans"][k]
+        B = vals[k].reshape(6, 6).T  # stored column-major
+        if rb == cb:
+            Bl = np.tril(B) + lam * np.eye(6)
+            F[f][6 * rb:6 * rb + 6, 6 * cb:6 * cb + 6] = Bl
+        else:
+            F[f][6 * rb:6 * rb + 6, 6 * cb:6 * cb + 6] = B.T if tr else B
+    for j in range(n):
+        f = pl["col_front"][j]
+        lc = 6 * (j - pl["col0"][f])
+        F[f][-1, lc:lc + 6] = b[6 * pl["perm"][j]:6 * pl["perm"][j] + 6]
+    done = np.zeros(ns, bool)
+    order = []
+    for st in range(len(pl["stage_task_ptr"]) - 1):
+        for t in range(pl["stage_task_ptr"][st], pl["stage_task_ptr"][st + 1]):
+            for f in pl["task_fronts"][pl["task_ptr"][t]:pl["task_ptr"][t + 1]]:
+                order.append(f)
+                # children must be complete (earlier stage, or earlier in the same task)
+                for c in pl["child"][pl["child_ptr"][f]:pl["child_ptr"][f + 1]]:
+                    assert done[c]
+                    ncb, nb = pl["ncb"][c], pl["nb"][c]
+                    rel = pl["rel"][pl["rel_ptr"][c]:pl["rel_ptr"][c + 1]]
+                    assert len(rel) == nb - ncb
+                    idx = np.concatenate([6 * np.repeat(rel, 6) + np.tile(np.arange(6), len(rel)),
+                                          [F[f].shape[0] - 1]]).astype(int)
+                    U = F[c][6 * ncb:, 6 * ncb:]
+                    Ul = np.tril(U[:-1]) if U.shape[1] else U[:-1]
+                    F[f][np.ix_(idx[:-1], idx[:-1])] += Ul
+                    F[f][-1, idx[:-1]] += U[-1]
+                nc = 6 * pl["ncb"][f]
+                A11 = np.tril(F[f][:nc, :nc]); A11 = A11 + np.tril(A11, -1).T
+                L11 = np.linalg.cholesky(A11)
+                L21 = np.linalg.solve(L11, F[f][nc:, :nc].T).T
+                F[f][:nc, :nc] = L11
+                F[f][nc:, :nc] = L21
+                S = L21 @ L21[:-1].T
+                F[f][nc:, nc:] -= S
+                done[f] = True
+    assert done.all() and len(order) == ns
+    xnew = np.zeros(6 * n)
+    for f in reversed(order):
+        nc = 6 * pl["ncb"][f]
+        rows = pl["rows"][pl["rows_ptr"][f]:pl["rows_ptr"][f + 1]]
+        ridx = (6 * np.repeat(rows, 6) + np.tile(np.arange(6), len(rows))).astype(int)
+        y = F[f][-1, :nc].copy()
+        L21 = F[f][nc:-1, :nc]
+        v = y - L21.T @ xnew[ridx]
+        xj = np.linalg.solve(F[f][:nc, :nc].T, v)
+        c0 = 6 * pl["col0"][f]
+        xnew[c0:c0 + nc] = xj
+    x = np.zeros(6 * n)
+    for j in range(n):
+        x[6 * pl["perm"][j]:6 * pl["perm"][j] + 6] = xnew[6 * j:6 * j + 6]
+    return x
+
+
+def patterns():
+    rng = np.random.default_rng(0)
+    out = {}
+    # banded chain
+    n = 70
+    rows = [[c for c in range(r, min(n, r + 5))] for r in range(n)]
+    out["band"] = rows
+    # chain + loop closures
+    rows2 = [list(r) for r in rows]
+    for _ in range(12):
+        a, b = sorted(rng.integers(0, n, 2))
+        if a != b and b not in rows2[a]:
+            rows2[a].append(int(b))
+    out["band_loops"] = [sorted(r) for r in rows2]
+    # random sparse
+    n3 = 40
+    rows3 = [[r] for r in range(n3)]
+    for _ in range(100):
+        a, b = sorted(rng.integers(0, n3, 2))
+        if a != b and b not in rows3[a]:
+            rows3[a].append(int(b))
+    out["random"] = [sorted(r) for r in rows3]
+    out["dense"] = [list(range(r, 9)) for r in range(9)]
+    out["diag_only"] = [[r] for r in range(7)]
+    out["single"] = [[0]]
+    # two disconnected chains
+    rows4 = [[r] + ([r + 1] if (r + 1) % 15 else []) for r in range(30)]
+    out["two_components"] = [sorted(set(c for c in r if c < 30)) for r in rows4]
+    return out
+
+
+@pytest.mark.parametrize("name", list(patterns().keys()) + ["synthetic"])
+@pytest.mark.parametrize("env", [{}, {"CUGO_ND_LEAF": "4", "CUGO_MAX_SUPER_COLS": "3", "CUGO_TARGET_TASKS": "4"},
+                                 {"CUGO_ND_LEAF": "1000", "CUGO_MAX_SUPER_COLS": "1", "CUGO_TARGET_TASKS": "100000"}])
+def test_symbolic_plan_replay_solves_the_system(lib, name, env, monkeypatch):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(1)
+    if name == "synthetic":
+        d = cugo.synth(120, 1500, 6200, seed=3, n_loop_closures=60)
+        # pose 0 is fixed -> indices: free poses are ids 1..P-1 -> index id-1
+        ep = d["e_pose"].astype(np.int64) - 1
+        ep[ep < 0] = 10**6
+        rowptr, colind = covis_pattern(119, ep, d["e_lm"])
+    else:
+        rows = patterns()[name]
+        rowptr = np.array([0] + list(np.cumsum([len(r) for r in rows])), np.int32)
+        colind = np.array([c for r in rows for c in r], np.int32)
+    n = len(rowptr) - 1
+    A, vals = random_spd_bsr(rowptr, colind, rng)
+    s = C.c_void_p()
+    assert lib.cugo_chol_create(None, C.byref(s)) == 0
+    rc = lib.cugo_chol_analyze(s, n, rowptr.ctypes.data_as(C.POINTER(C.c_int32)),
+                               colind.ctypes.data_as(C.POINTER(C.c_int32)))
+    assert rc == 0, lib.cugo_last_error()
+    pl = plan_arrays(lib, s)
+    # permutation is a permutation, supernodes tile the columns, children precede parents
+    assert sorted(pl["perm"]) == list(range(n))
+    assert pl["super_ptr"][0] == 0 and pl["super_ptr"][-1] == n and (np.diff(pl["super_ptr"]) > 0).all()
+    for f, p in enumerate(pl["sparent"]):
+        assert p == -1 or p > f
+    lam = 0.37
+    b = rng.normal(size=6 * n)
+    x = replay_multifrontal(pl, vals, lam, b)
+    xref = np.linalg.solve(A + lam * np.eye(6 * n), b)
+    np.testing.assert_allclose(x, xref, rtol=1e-9, atol=1e-11)
+    nnzL, flops, nsup, nst, fb = C.c_double(), C.c_double(), C.c_int(), C.c_int(), C.c_double()
+    lib.cugo_chol_stats(s, C.byref(nnzL), C.byref(flops), C.byref(nsup), C.byref(nst), C.byref(fb))
+    assert nsup.value == len(pl["ncb"]) and nst.value == len(pl["stage_task_ptr"]) - 1
+    assert nnzL.value >= 21 * n and flops.value > 0
+    lib.cugo_chol_destroy(s)
+
+
+def test_shard_ranges_partition_all_landmarks(lib):
+    rng = np.random.default_rng(2)
+    cnt = rng.integers(0, 9, 1000).astype(np.int32)
+    for world in (1, 2, 3, 8):
+        prev = 0
+        loads = []
+        for r in range(world):
+            a, b = cugo.shard_range(cnt, r, world)
+            assert a == prev and b >= a
+            prev = b
+            loads.append(int(cnt[a:b].sum()))
+        assert prev == len(cnt)
+        assert max(loads) - min(loads) <= 2 * cnt.max() + 1

@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py — 10-iteration bundle adjustment on MI355X.
+
+One "step" = optimize(10) (structure build + ordering/symbolic + 10 LM iterations) on the
+kitti_00-shaped synthetic graph (BASELINE.json configs[1]: 1322 poses / 133 383 landmarks /
+561 116 edges, fp64) with the flattened graph already resident in HBM (initialize() is timed
+separately and reported as init_ms).  value = edge*iterations per second over the whole job.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload kitti00|kitti07|synth10k]
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): the graph is sharded by
+landmark ranges, ranks all-reduce the Schur system (RCCL) each LM trial, the sparse LL^T is
+replicated — strong scaling on a fixed graph.
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+WORKLOADS = {
+    # name: (poses, landmarks, edges, seed, loop-closure landmarks, stereo fraction)
+    "kitti00": (1322, 133383, 561116, 0, 4000, 0.7),
+    "kitti07": (248, 26127, 95037, 7, 500, 0.7),
+    "synth10k": (10000, 1000000, 5000000, 10000, 0, 0.0),
+}
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_PEAK_TFLOPS = 78.6    # MI355X fp64 vector / matrix peak
+
+
+def algorithmic_bytes(group, E, P, L, B):
+    """SURVEY.md §8(d) per-unit figures (mono, per-edge information + camera) x units per launch"""
+    if group == "build":
+        return 249.0 * E + 336.0 * P + 96.0 * L
+    if group == "errors":
+        return 124.0 * E + 56.0 * P + 24.0 * L
+    if group == "schur":
+        return (292.0 + 288.0) * E + 172.0 * L + 288.0 * B
+    if group == "backsubst_update":
+        return 148.0 * E + 120.0 * L + 200.0 * P + 120.0 * L
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="kitti00", choices=sorted(WORKLOADS))
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    ndev = torch.cuda.device_count()
+    dev = torch.device("cuda", local_rank % ndev)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
+
+    cugo = importlib.import_module("cuda-bundle-adjustment_amd")
+    P, L, E, seed, nlc, stereo = WORKLOADS[args.workload]
+    data = cugo.synth(P, L, E, seed=seed, n_loop_closures=nlc, stereo_fraction=stereo)
+
+    class _DevPtr:
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"data": (int(ptr), False), "shape": (int(n),),
+                                             "typestr": "<f8", "version": 2}
+
+    def exchange(ptr, n, op):
+        t = torch.as_tensor(_DevPtr(ptr, n), device=dev)
+        rop = dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX
+        if args.backend == "nccl":
+            dist.all_reduce(t, op=rop)
+        else:  # gloo rehearsal: stage through the host
+            h = t.cpu()
+            dist.all_reduce(h, op=rop)
+            t.copy_(h)
+        torch.cuda.synchronize()
+
+    def make_graph():
+        g = cugo.graph_from_arrays(data)
+        if world > 1:
+            g.set_shard(rank, world, exchange)
+        t0 = time.perf_counter()
+        g.initialize()
+        return g, (time.perf_counter() - t0) * 1e3
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    graphs, init_ms = [], []
+    for _ in range(args.warmup + args.steps):
+        g, ms = make_graph()
+        graphs.append(g)
+        init_ms.append(ms)
+    for g in graphs[:args.warmup]:
+        g.optimize(args.iters)
+    barrier()
+    t0 = time.perf_counter()
+    for g in graphs[args.warmup:]:
+        g.optimize(args.iters)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    timed = graphs[args.warmup:]
+    stats = [g.stats() for g in timed]
+    iters_total = sum(len(s) for s in stats)
+    nedges = timed[0].n_active_edges()
+    sstats = timed[0].structure_stats()
+    profile = timed[0].time_profile()
+    gpu_chi = [s["chi2"] for s in stats[0]]
+    gpu_pose, gpu_lm = timed[0].poses(), timed[0].landmarks()
+
+    # ---- per-kernel-group device time (HIP events on the solver's stream), separate pass ----
+    for g in graphs:
+        g.close()
+    gk, _ = make_graph()
+    gk.set_kernel_timing(True)
+    gk.optimize(args.iters)
+    ktimes = gk.kernel_times()
+    gk.close()
+    shard = max(1, world)
+    groups = {}
+    for name, kt in ktimes.items():
+        if kt["launches"] == 0:
+            continue
+        avg_ms = kt["ms"] / kt["launches"]
+        ent = {"avg_ms": avg_ms, "launches": kt["launches"], "total_ms": kt["ms"]}
+        ab = algorithmic_bytes(name, nedges / shard, P - 1, L / shard, sstats["hsc_blocks"])
+        if ab is not None:
+            ent.update(bound="hbm", achieved=ab / (avg_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+        elif name == "cholesky":
+            ent.update(bound="mfma", achieved=sstats["chol_flops"] / (avg_ms * 1e-3) / 1e12,
+                       peak=FP64_PEAK_TFLOPS, unit="TFLOP/s")
+        if "achieved" in ent:
+            ent["frac"] = ent["achieved"] / ent["peak"]
+        groups[name] = ent
+    dominant = max(groups, key=lambda k: groups[k]["total_ms"]) if groups else None
+    roofline = None
+    if dominant and "achieved" in groups[dominant]:
+        d = groups[dominant]
+        roofline = {"kernel": dominant, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
+                    "unit": d["unit"], "frac": d["frac"], "traffic": None,
+                    "avg_launch_ms": d["avg_ms"], "launches": d["launches"]}
+
+    # ---- CPU baseline: the oracle (port of the g2o-style path), 1 thread, same graph ---------
+    cpu = None
+    parity = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle
+        prob = oracle.Problem(data["pose"], data["pose_fixed"], data["lm"], data["lm_fixed"], data["e_pose"],
+                              data["e_lm"], data["e_stereo"], data["e_meas"], data["e_omega"], data["e_cam"])
+        cpu_iters = args.iters if E <= 1000000 else 2
+        tc = time.perf_counter()
+        ref = prob.optimize(cpu_iters)
+        cpu_s = time.perf_counter() - tc
+        cpu = {"value": nedges * len(ref) / cpu_s, "unit": "edge*iter/s", "cores": 1, "kind": "port",
+               "seconds": cpu_s,
+               "sample": "%s-shaped graph, %d LM iterations incl. structure build, oracle/ba_oracle.c, 1 thread"
+                         % (args.workload, len(ref))}
+        nref = min(len(ref), len(gpu_chi))
+        rel = max(abs(gpu_chi[i] - ref[i]["chi2"]) / abs(ref[i]["chi2"]) for i in range(nref))
+        parity = {"max_rel_chi2_diff_vs_cpu": rel, "iterations_compared": nref}
+        if cpu_iters == args.iters:
+            parity.update(rmse_rotation=float(np.sqrt(np.mean((gpu_pose[:, :4] - prob.pose[:, :4]) ** 2))),
+                          rmse_translation=float(np.sqrt(np.mean((gpu_pose[:, 4:] - prob.pose[:, 4:]) ** 2))),
+                          rmse_landmark=float(np.sqrt(np.mean((gpu_lm - prob.lm) ** 2))))
+
+    if rank == 0:
+        out = {
+            "metric": "ba_edge_iterations_per_sec", "value": nedges * iters_total / elapsed,
+            "unit": "edge*iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s-shaped synthetic graph: %d poses / %d landmarks / %d edges, %d LM iterations"
+                                   % (args.workload, P, L, nedges, args.iters),
+                       "parallelism": "landmark-sharded x%d, replicated LL^T" % world if world > 1 else "single GPU",
+                       "lm_iterations_per_step": iters_total / args.steps},
+            "ba_10iter_seconds": elapsed / args.steps,
+            "init_ms": float(np.median(init_ms)),
+            "ba_10iter_seconds_incl_initialize": elapsed / args.steps + float(np.median(init_ms)) * 1e-3,
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "parity": parity,
+            "kernel_groups": groups,
+            "structure": sstats,
+            "host_phase_ms": profile,
+            "chi2": gpu_chi,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

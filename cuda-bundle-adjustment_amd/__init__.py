@@ -220,6 +220,15 @@ class Graph:
         names = buf.value.decode().split("\n")[:n]
         return dict(zip(names, ms[:n].tolist()))
 
+    def set_kernel_timing(self, on):
+        lib().cugo_graph_set_kernel_timing(self._g, int(on))
+
+    def kernel_times(self):
+        buf = C.create_string_buffer(2048); ms = np.zeros(32); cnt = np.zeros(32, np.int32)
+        n = lib().cugo_graph_kernel_times(self._g, buf, 2048, _p(ms, _f64p), _p(cnt, _i32p), 32)
+        names = buf.value.decode().split("\n")[:n]
+        return {names[i]: dict(ms=float(ms[i]), launches=int(cnt[i])) for i in range(n)}
+
     def structure_stats(self):
         o = np.zeros(8)
         lib().cugo_graph_structure_stats(self._g, _p(o, _f64p))

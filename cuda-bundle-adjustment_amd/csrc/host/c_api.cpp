@@ -497,6 +497,39 @@ int cugo_graph_set_verbose(cugo_graph* g, int v)
     g->opt->setVerbose(v != 0);
     return CUGO_OK;
 }
+int cugo_graph_set_kernel_timing(cugo_graph* g, int on)
+{
+    g->opt->setKernelTiming(on != 0);
+    return CUGO_OK;
+}
+int cugo_graph_kernel_times(cugo_graph* g, char* names, int buf_len, double* ms, int32_t* launches, int cap)
+{
+    std::vector<std::string> nm;
+    std::vector<double> t;
+    std::vector<int> c;
+    g->opt->kernelTimes(nm, t, c);
+    std::string all;
+    int n = 0;
+    for (; n < (int)nm.size() && n < cap; n++)
+    {
+        all += nm[n] + "\n";
+        ms[n] = t[n];
+        launches[n] = c[n];
+    }
+    if (names && buf_len > 0)
+    {
+        std::strncpy(names, all.c_str(), buf_len - 1);
+        names[buf_len - 1] = 0;
+    }
+    return n;
+}
+int cugo_memcpy_d2d(cugo_ctx* ctx, void* d, const void* s, size_t bytes)
+{
+    return guarded([&] {
+        CUGO_HIP(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        CUGO_HIP(hipStreamSynchronize(ctx->stream));
+    });
+}
 int cugo_graph_structure_stats(cugo_graph* g, double* out8)
 {
     const auto v = g->opt->structureStats();

@@ -84,6 +84,61 @@ struct Engine::Impl
     cugo_hsc_struct hs{};
     bool structure_dirty = true;
 
+    // optional HIP-event timing of kernel groups
+    bool ktiming = false;
+    struct KEv
+    {
+        int label;
+        hipEvent_t a, b;
+    };
+    std::vector<KEv> kev;
+    std::vector<std::string> klabels;
+    std::vector<double> kms;
+    std::vector<int> kcount;
+    int klabel(const char* name)
+    {
+        for (size_t i = 0; i < klabels.size(); i++)
+            if (klabels[i] == name)
+                return (int)i;
+        klabels.push_back(name);
+        kms.push_back(0);
+        kcount.push_back(0);
+        return (int)klabels.size() - 1;
+    }
+    template <typename F>
+    void timed(const char* name, F&& f)
+    {
+        if (!ktiming)
+        {
+            f();
+            return;
+        }
+        KEv e;
+        e.label = klabel(name);
+        CUGO_HIP(hipEventCreate(&e.a));
+        CUGO_HIP(hipEventCreate(&e.b));
+        CUGO_HIP(hipEventRecord(e.a, ctx.stream));
+        f();
+        CUGO_HIP(hipEventRecord(e.b, ctx.stream));
+        kev.push_back(e);
+    }
+    void collect_times()
+    {
+        if (kev.empty())
+            return;
+        CUGO_HIP(hipStreamSynchronize(ctx.stream));
+        for (auto& e : kev)
+        {
+            float ms = 0;
+            CUGO_HIP(hipEventElapsedTime(&ms, e.a, e.b));
+            kms[e.label] += ms;
+            kcount[e.label]++;
+            (void)hipEventDestroy(e.a);
+            (void)hipEventDestroy(e.b);
+        }
+        kev.clear();
+    }
+
     double* bp() { return d_b.data(); }
     double* bl() { return d_b.data() + 6 * (size_t)P; }
     double* xp() { return d_x.data(); }
@@ -141,6 +196,16 @@ Engine::~Engine()
         }
         delete impl_;
     }
+}
+
+void Engine::set_kernel_timing(bool on) { impl_->ktiming = on; }
+
+std::vector<Engine::KernelTime> Engine::kernel_times() const
+{
+    std::vector<KernelTime> out;
+    for (size_t i = 0; i < impl_->klabels.size(); i++)
+        out.push_back({impl_->klabels[i], impl_->kms[i], impl_->kcount[i]});
+    return out;
 }
 
 void Engine::set_shard(int rank, int world, cugo_exchange_fn fn, void* user)
@@ -445,9 +510,11 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
         // computeErrors + buildSystem fused: chi2 at the current estimates comes out of the
         // build pass (ref: cuda_graph_optimisation.cpp:64-67)
         auto tb = Clock::now();
-        cugo_k::launch_build(s, m.ev, m.d_poses[m.cur].data(), m.d_lms[m.cur].data(), m.rk,
-                             m.d_Hpp.data(), m.bp(), m.d_Hll.data(), m.bl(), m.d_Hpl.data(), m.rs(),
-                             m.d_scal.data());
+        m.timed("build", [&] {
+            cugo_k::launch_build(s, m.ev, m.d_poses[m.cur].data(), m.d_lms[m.cur].data(), m.rk,
+                                 m.d_Hpp.data(), m.bp(), m.d_Hll.data(), m.bl(), m.d_Hpl.data(),
+                                 m.rs(), m.d_scal.data());
+        });
         sync_prof(PROF_BUILD_SYSTEM, tb);
         if (iteration == 0)
         {
@@ -480,25 +547,33 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
         for (; q < maxq && rho < 0; q++)
         {
             auto ts = Clock::now();
-            cugo_k::launch_schur(s, m.ev, m.hs, lambda, 0, m.d_Hpp.data(), m.bp(), m.d_Hll.data(),
-                                 m.bl(), m.d_Hpl.data(), m.d_invHll.data(), m.d_T.data(), m.bsc(),
-                                 m.Hsc());
+            m.timed("schur", [&] {
+                cugo_k::launch_schur(s, m.ev, m.hs, lambda, 0, m.d_Hpp.data(), m.bp(),
+                                     m.d_Hll.data(), m.bl(), m.d_Hpl.data(), m.d_invHll.data(),
+                                     m.d_T.data(), m.bsc(), m.Hsc());
+            });
             if (sharded)
                 m.exchange(m.d_sys.data(), 36 * (size_t)m.hs.n_blocks + 6 * (size_t)m.P, 0);
             sync_prof(PROF_SCHUR, ts);
             auto tn = Clock::now();
-            m.chol.factor_solve(m.Hsc(), lambda, m.bsc(), m.xp(), m.d_fail.data());
+            m.timed("cholesky", [&] {
+                m.chol.factor_solve(m.Hsc(), lambda, m.bsc(), m.xp(), m.d_fail.data());
+            });
             sync_prof(PROF_NUMERIC, tn);
             auto tu = Clock::now();
             const int nxt = m.cur ^ 1;
-            cugo_k::launch_backsubst_update(
-                s, m.ev, lambda, (m.rank == 0 ? lambda : 0.0), m.d_invHll.data(), m.bl(), m.bp(), m.d_Hpl.data(), m.xp(), m.xl(),
-                m.d_poses[m.cur].data(), m.d_lms[m.cur].data(), m.d_poses[nxt].data(),
-                m.d_lms[nxt].data(), m.rs(), m.d_scal.data() + 3);
+            m.timed("backsubst_update", [&] {
+                cugo_k::launch_backsubst_update(
+                    s, m.ev, lambda, (m.rank == 0 ? lambda : 0.0), m.d_invHll.data(), m.bl(), m.bp(),
+                    m.d_Hpl.data(), m.xp(), m.xl(), m.d_poses[m.cur].data(), m.d_lms[m.cur].data(),
+                    m.d_poses[nxt].data(), m.d_lms[nxt].data(), m.rs(), m.d_scal.data() + 3);
+            });
             sync_prof(PROF_UPDATE, tu);
             auto te = Clock::now();
-            cugo_k::launch_errors(s, m.ev, m.d_poses[nxt].data(), m.d_lms[nxt].data(), m.rk, m.rs(),
-                                  m.d_scal.data() + 2);
+            m.timed("errors", [&] {
+                cugo_k::launch_errors(s, m.ev, m.d_poses[nxt].data(), m.d_lms[nxt].data(), m.rk,
+                                      m.rs(), m.d_scal.data() + 2);
+            });
             sync_prof(PROF_COMPUTE_ERROR, te);
             if (sharded)
                 m.exchange(m.d_scal.data() + 2, 2, 0);
@@ -539,6 +614,7 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
         if (q == maxq || rho < 1e-6 || !std::isfinite(lambda))
             break;
     }
+    m.collect_times();
 }
 
 void Engine::download(std::vector<double>& poses, std::vector<double>& lms)

@@ -78,6 +78,16 @@ public:
     const StructureStats& structure_stats() const { return sstats_; }
     const double* profile_ms() const { return prof_; }
     static const char* profile_name(int i);
+    // per-kernel-group device times measured with HIP events on the engine's stream
+    // (enabled by set_kernel_timing; adds event overhead, so not used inside timed runs)
+    void set_kernel_timing(bool on);
+    struct KernelTime
+    {
+        std::string name;
+        double ms;
+        int launches;
+    };
+    std::vector<KernelTime> kernel_times() const;
     // device views for kernel-level tests / the C ABI
     struct Impl;
     Impl* impl() { return impl_; }

@@ -44,6 +44,20 @@ std::vector<double> CudaGraphOptimisationImpl::structureStats() const
             s.supernodes, s.stages,   s.front_bytes, s.offdiag_products};
 }
 
+void CudaGraphOptimisationImpl::setKernelTiming(bool on) { engine_->set_kernel_timing(on); }
+
+void CudaGraphOptimisationImpl::kernelTimes(std::vector<std::string>& names, std::vector<double>& ms,
+                                            std::vector<int>& launches) const
+{
+    names.clear(), ms.clear(), launches.clear();
+    for (const auto& k : engine_->kernel_times())
+    {
+        names.push_back(k.name);
+        ms.push_back(k.ms);
+        launches.push_back(k.launches);
+    }
+}
+
 static int rk_code(RobustKernelType t)
 {
     switch (t)

@@ -126,6 +126,9 @@ public:
     int nActiveEdges() const;
     /** B, M, nnz(L), flops, supernodes, stages, front bytes, off-diagonal products */
     std::vector<double> structureStats() const;
+    /** HIP-event timing of kernel groups on the solver's stream (diagnostic; adds overhead) */
+    void setKernelTiming(bool on);
+    void kernelTimes(std::vector<std::string>& names, std::vector<double>& ms, std::vector<int>& launches) const;
 
 private:
     bool verbose = false;

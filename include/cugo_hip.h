@@ -230,6 +230,13 @@ int cugo_graph_n_active_edges(cugo_graph* g);
  * (block_solver.cpp:470-488).  names is a '\n' separated list written into buf. */
 int cugo_graph_time_profile(cugo_graph* g, char* names_buf, int buf_len, double* ms, int cap);
 int cugo_graph_set_verbose(cugo_graph* g, int verbose);
+/* HIP-event timing of the kernel groups (build, errors, schur, cholesky, backsubst_update) on
+ * the solver's own stream; diagnostic (adds event overhead). names: '\n' separated. */
+int cugo_graph_set_kernel_timing(cugo_graph* g, int on);
+int cugo_graph_kernel_times(cugo_graph* g, char* names_buf, int buf_len, double* ms,
+                            int32_t* launches, int cap);
+/* device-to-device copy on the context stream (used by exchange callbacks) */
+int cugo_memcpy_d2d(cugo_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
 /* solver statistics of the last buildStructure: B (Hsc blocks), M (block products),
  * nnz(L), Cholesky flops, stages */
 int cugo_graph_structure_stats(cugo_graph* g, double* out8);

@@ -18,6 +18,7 @@ void cugo_chol::upload(hipStream_t s)
     d_blk_front.upload(P.blk_front, s), d_blk_row.upload(P.blk_row, s);
     d_blk_col.upload(P.blk_col, s), d_blk_trans.upload(P.blk_trans, s);
     d_perm.upload(P.perm, s), d_col_front.upload(P.col_front, s);
+    d_wl.upload(P.wl, s);
     d_fronts.resize((size_t)P.front_doubles + 16);
     d_xnew.resize((size_t)6 * P.n + 16);
     CUGO_HIP(hipStreamSynchronize(s)); // host vectors may be reused after return
@@ -34,17 +35,18 @@ void cugo_chol::upload(hipStream_t s)
     D.blk_front = d_blk_front.data(), D.blk_row = d_blk_row.data();
     D.blk_col = d_blk_col.data(), D.blk_trans = d_blk_trans.data();
     D.n = P.n, D.perm = d_perm.data(), D.col_front = d_col_front.data();
-    lds_factor = cugo_k::chol_lds_factor_bytes(P.ld_max);
-    lds_backward = cugo_k::chol_lds_backward_bytes(P.ld_max);
+    lds_factor = cugo_k::chol_lds_factor_bytes(P.nc_max);
+    lds_backward = cugo_k::chol_lds_backward_bytes(P.nc_max, P.ld_max);
 }
 
 void cugo_chol::analyze(int n, const int32_t* rowptr, const int32_t* colind)
 {
     chol_analyze(n, rowptr, colind, CholOptions::from_env(), plan);
     trans32.assign(plan.blk_trans.begin(), plan.blk_trans.end());
-    if (cugo_k::chol_lds_factor_bytes(plan.ld_max) > 160 * 1024)
-        throw std::runtime_error("cugo: a front exceeds the LDS panel budget (ld=" +
-                                 std::to_string(plan.ld_max) + ")");
+    if (cugo_k::chol_lds_factor_bytes(plan.nc_max) > 160 * 1024 ||
+        cugo_k::chol_lds_backward_bytes(plan.nc_max, plan.ld_max) > 160 * 1024)
+        throw std::runtime_error("cugo: a front exceeds the LDS budget (nc=" +
+                                 std::to_string(plan.nc_max) + ", ld=" + std::to_string(plan.ld_max) + ")");
     if (ctx)
         upload(ctx->stream);
     analyzed = true;
@@ -60,7 +62,14 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
     for (int st = 0; st < plan.n_stages; st++)
     {
         const int t0 = plan.stage_task_ptr[st], t1 = plan.stage_task_ptr[st + 1];
-        cugo_k::launch_chol_factor_stage(s, dev, d_fronts.data(), t0, t1 - t0, lds_factor, d_fail);
+        if (plan.has_subtree_stage && st == 0)
+            cugo_k::launch_chol_subtree_stage(s, dev, d_fronts.data(), t0, t1 - t0, lds_factor, d_fail);
+        else
+            cugo_k::launch_chol_upper_stage(
+                s, dev, d_fronts.data(), t0, t1 - t0, d_wl.data(), plan.ea_ptr[st],
+                plan.ea_ptr[st + 1] - plan.ea_ptr[st], plan.trsm_ptr[st],
+                plan.trsm_ptr[st + 1] - plan.trsm_ptr[st], plan.syrk_ptr[st],
+                plan.syrk_ptr[st + 1] - plan.syrk_ptr[st], lds_factor, d_fail);
     }
     for (int st = plan.n_stages - 1; st >= 0; st--)
     {

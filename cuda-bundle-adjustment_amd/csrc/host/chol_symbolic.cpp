@@ -26,6 +26,8 @@ CholOptions CholOptions::from_env()
         o.zero_frac = std::atof(s);
     if (const char* s = std::getenv("CUGO_TARGET_TASKS"))
         o.target_tasks = std::max(1, std::atoi(s));
+    if (const char* s = std::getenv("CUGO_MAX_FRONT_COLS"))
+        o.max_front_cols = std::min(16, std::max(1, std::atoi(s)));
     return o;
 }
 
@@ -457,7 +459,18 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
             if (alive[s])
                 nf.push_back(first[s]);
         std::sort(nf.begin(), nf.end());
-        sfirst = nf;
+        nf.push_back(n);
+        // split supernodes wider than the LDS cap into a chain of panels (each panel's
+        // boundary is the rest of the supernode plus the original boundary: still nested)
+        sfirst.clear();
+        for (size_t i = 0; i + 1 < nf.size(); i++)
+        {
+            const int a = nf[i], b = nf[i + 1];
+            const int w = b - a;
+            const int parts = (w + opt.max_front_cols - 1) / opt.max_front_cols;
+            for (int q = 0; q < parts; q++)
+                sfirst.push_back(a + (int)((int64_t)w * q / parts));
+        }
         ns = (int)sfirst.size();
         sfirst.push_back(n);
     }
@@ -653,6 +666,56 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
             P.stage_task_ptr.push_back((int)P.task_ptr.size() - 1);
     }
     P.n_stages = (int)P.stage_task_ptr.size() - 1;
+    P.has_subtree_stage = false;
+    for (int s = 0; s < ns; s++)
+        if (lower[s])
+            P.has_subtree_stage = true;
+
+    // ---- 8. work items of the batched upper-stage kernels ------------------------------
+    P.nc_max = 6;
+    for (int s = 0; s < ns; s++)
+        P.nc_max = std::max(P.nc_max, 6 * P.ncb[s]);
+    P.ea_ptr.assign(1, 0), P.trsm_ptr.assign(1, 0), P.syrk_ptr.assign(1, 0);
+    std::vector<int32_t> ea, tr, sy;
+    for (int st = 0; st < P.n_stages; st++)
+    {
+        const bool subtree = P.has_subtree_stage && st == 0;
+        if (!subtree)
+            for (int t = P.stage_task_ptr[st]; t < P.stage_task_ptr[st + 1]; t++)
+            {
+                const int f = P.task_fronts[P.task_ptr[t]];
+                const int nb = P.nb[f], ncb = P.ncb[f];
+                if (P.child_ptr[f + 1] > P.child_ptr[f])
+                    for (int c0 = 0; c0 < nb; c0 += 8)
+                    {
+                        ea.push_back(f), ea.push_back(c0), ea.push_back(std::min(nb, c0 + 8));
+                    }
+                const int nbelow = 6 * (nb - ncb) + 1; // boundary rows + rhs row
+                for (int r0 = 0; r0 < nbelow; r0 += 64)
+                {
+                    tr.push_back(f), tr.push_back(r0), tr.push_back(std::min(nbelow, r0 + 64));
+                }
+                const int nrs = 6 * (nb - ncb);
+                const int nti = (nbelow + 63) / 64, ntj = (nrs + 63) / 64;
+                for (int tj = 0; tj < ntj; tj++)
+                    for (int ti = tj; ti < nti; ti++)
+                    {
+                        sy.push_back(f), sy.push_back(ti), sy.push_back(tj);
+                    }
+            }
+        P.ea_ptr.push_back((int)ea.size() / 3);
+        P.trsm_ptr.push_back((int)tr.size() / 3);
+        P.syrk_ptr.push_back((int)sy.size() / 3);
+    }
+    // one array: [ea | trsm | syrk]; the ptr arrays index items within their own section
+    P.wl.clear();
+    P.wl.insert(P.wl.end(), ea.begin(), ea.end());
+    P.wl.insert(P.wl.end(), tr.begin(), tr.end());
+    P.wl.insert(P.wl.end(), sy.begin(), sy.end());
+    for (auto& v : P.trsm_ptr)
+        v += (int)ea.size() / 3;
+    for (auto& v : P.syrk_ptr)
+        v += (int)(ea.size() + tr.size()) / 3;
 }
 
 } // namespace cugo_host

@@ -13,6 +13,7 @@ struct CholOptions
     int max_super_cols = 8;  // relaxed supernodes: at most this many block columns
     double zero_frac = 0.35; // relaxed supernodes: tolerated share of explicit zero blocks
     int target_tasks = 1024; // subtree-to-workgroup granularity of stage 0
+    int max_front_cols = 16; // hard cap on pivot block columns of a front (LDS-resident L11)
     static CholOptions from_env();
 };
 
@@ -35,6 +36,15 @@ struct CholPlan
     int n_stages = 0;
     std::vector<int32_t> stage_task_ptr; // [n_stages+1]
     std::vector<int32_t> task_ptr, task_fronts;
+    bool has_subtree_stage = false; // stage 0 = multi-front subtree tasks (one workgroup each)
+    // upper stages: every task is one front processed by four batched kernels; their work
+    // items are triples (front, a, b) in `wl`:
+    //   extend-add  : parent block columns [a, b)
+    //   trsm        : scalar rows [a, b) below the pivot block (relative to row 6*ncb)
+    //   syrk        : 64x64 tile (row tile a, col tile b), a >= b
+    std::vector<int32_t> wl;
+    std::vector<int32_t> ea_ptr, trsm_ptr, syrk_ptr; // [n_stages+1] item ranges per stage
+    int nc_max = 6; // widest pivot block in scalars (LDS sizing)
 
     std::vector<int32_t> blk_front, blk_row, blk_col; // per Hsc block
     std::vector<uint8_t> blk_trans;

@@ -1,16 +1,24 @@
 // Multifrontal block-sparse LL^T of the Schur complement on gfx950 (fp64).
 //
 // Replaces cuSOLVER's csrchol (ref: src/cholesky.hpp:97-155) — closed source there, written
-// from scratch here.  The host (csrc/host/chol_symbolic.cpp) orders the 6x6-block graph,
-// builds supernodes and a schedule of STAGES; a stage is one kernel launch in which every
-// TASK (= one workgroup) processes a list of fronts sequentially:
-//      front F = [ pivot block columns | boundary block rows | 1 rhs row ]   (dense, col-major)
-//      1. extend-add the children's update matrices        (fixed child order: deterministic)
-//      2. partial LL^T of the pivot columns, right-looking, 6-wide panels staged in LDS
-//      3. the trailing part is the update matrix for the parent
-// The right-hand side rides along as the last row of every front, so the forward
-// substitution L y = b is a by-product of the factorisation (y ends up in the rhs row of the
-// pivot columns); only the backward substitution needs its own top-down pass.
+// from scratch here.  The host (csrc/host/chol_symbolic.cpp) orders the 6x6-block graph
+// (nested dissection), builds supernodes ("fronts", pivot width <= 96 scalars so that L11
+// lives in LDS) and a schedule of STAGES:
+//
+//   front F = [ pivot block columns | boundary block rows | 1 rhs row ]   dense, column-major
+//
+//   stage 0 (optional)  : whole bottom subtrees, one workgroup per subtree, fronts in postorder
+//   upper stages        : one etree level per stage, four batched kernels per level so that a
+//                         big front is spread over many workgroups (256 CUs / 8 XCDs):
+//        extend-add  children update matrices -> parent front (fixed child order)
+//        potrf       L11 = chol(F11) in LDS                       (1 workgroup / front)
+//        trsm        L21 = F21 L11^-T, 64-row tiles, L11 + tile in LDS
+//        syrk        U = F22 - L21 L21^T, 64x64 tiles on the f64 matrix cores
+//                    (v_mfma_f64_16x16x4_f64), lower tiles only
+//
+// The right-hand side rides along as the last row of every front, so L y = b is a by-product
+// of the factorisation (y ends in the rhs row of the pivot columns); only the backward
+// substitution needs its own top-down pass.  All sums have a fixed order: bit-reproducible.
 // A pivot <= 1e-14 (or NaN) raises *fail (ref: csrcholZeroPivot tol, src/cholesky.hpp:85).
 #include "kernels.h"
 
@@ -19,8 +27,10 @@ namespace
 
 constexpr int CBS = 256;
 constexpr double PIVOT_TOL = 1e-14;
+constexpr int TR = 64; // trsm / syrk tile edge
 
 using cugo_k::CholPlanDev;
+typedef double double4_t __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------- assembly -------------
 __global__ __launch_bounds__(CBS) void k_assemble_blocks(CholPlanDev p, double* __restrict__ fronts,
@@ -64,8 +74,11 @@ __global__ __launch_bounds__(CBS) void k_assemble_rhs(CholPlanDev p, double* __r
     fronts[p.off[f] + lc * ld + (ld - 1)] = bsc[6L * p.perm[jb] + comp];
 }
 
-// ---------------------------------------------------------------- factor ---------------
-__device__ void front_extend_add(const CholPlanDev& p, double* __restrict__ fronts, int f)
+// ---------------------------------------------------------------- device building blocks
+// children -> parent, restricted to parent block columns [cb0, cb1); children one after the
+// other (barrier in between) so every parent entry is summed in child order
+__device__ void dev_extend_add(const CholPlanDev& p, double* __restrict__ fronts, int f, int cb0,
+                               int cb1)
 {
     const long ldp = 6L * p.nb[f] + 1;
     double* Fp = fronts + p.off[f];
@@ -73,136 +86,381 @@ __device__ void front_extend_add(const CholPlanDev& p, double* __restrict__ fron
     {
         const int c = p.child[ci];
         const int ncb = p.ncb[c], nbr = p.nb[c] - ncb;
-        if (nbr == 0)
-            continue;
-        const long ldc = 6L * p.nb[c] + 1;
-        const double* U = fronts + p.off[c] + (6L * ncb) * ldc + 6L * ncb; // (0,0) of update
         const int32_t* rel = p.rel + p.rel_ptr[c];
-        const int nru = 6 * nbr + 1, ncu = 6 * nbr;
-        for (int idx = threadIdx.x; idx < nru * ncu; idx += CBS)
+        // child update block columns whose parent column falls in [cb0, cb1) (rel is ascending)
+        int jlo = 0, jhi = nbr;
+        while (jlo < nbr && rel[jlo] < cb0)
+            jlo++;
+        jhi = jlo;
+        while (jhi < nbr && rel[jhi] < cb1)
+            jhi++;
+        if (jhi > jlo)
         {
-            const int j = idx / nru, i = idx % nru;
-            if (i < j)
-                continue;
-            const long pj = 6L * rel[j / 6] + (j % 6);
-            const long pi = (i == nru - 1) ? (ldp - 1) : 6L * rel[i / 6] + (i % 6);
-            Fp[pj * ldp + pi] += U[(long)j * ldc + i];
+            const long ldc = 6L * p.nb[c] + 1;
+            const double* U = fronts + p.off[c] + (6L * ncb) * ldc + 6L * ncb; // (0,0) of update
+            const int nru = 6 * nbr + 1;
+            const int j0 = 6 * jlo, ncolsj = 6 * (jhi - jlo);
+            const int nrowsj = nru - j0; // rows j0 .. nru-1 can be below the diagonal
+            for (int idx = threadIdx.x; idx < ncolsj * nrowsj; idx += CBS)
+            {
+                const int j = j0 + idx / nrowsj, i = j0 + idx % nrowsj;
+                if (i < j)
+                    continue;
+                const long pj = 6L * rel[j / 6] + (j % 6);
+                const long pi = (i == nru - 1) ? (ldp - 1) : 6L * rel[i / 6] + (i % 6);
+                Fp[pj * ldp + pi] += U[(long)j * ldc + i];
+            }
         }
-        __syncthreads(); // children are added one after the other
+        __syncthreads();
     }
 }
 
-__device__ void front_factor(const CholPlanDev& p, double* __restrict__ fronts, int f,
-                             double* __restrict__ lds, int32_t* __restrict__ fail)
+// L11 = chol(F11) in LDS (Ls: nc x nc, leading dimension nc+1), blocked by 6 columns.
+// On return Ls holds L11 (lower) and F11 in global memory is overwritten with it.
+__device__ void dev_potrf(double* __restrict__ F, long ld, int nc, double* __restrict__ Ls,
+                          int32_t* __restrict__ fail)
 {
-    const int ncb = p.ncb[f], nb = p.nb[f];
-    const long ld = 6L * nb + 1;
-    const int ncols = 6 * nb;
-    double* F = fronts + p.off[f];
-    double* D = lds;        // 36 : diagonal block / its factor
-    double* Pn = lds + 40;  // panel rows [nrows_below][6]
-    for (int kb = 0; kb < ncb; kb++)
+    const int lds = nc + 1;
+    for (int idx = threadIdx.x; idx < nc * nc; idx += CBS)
     {
-        const long j0 = 6L * kb;
-        if (threadIdx.x < 36)
-        {
-            const int r = threadIdx.x % 6, c = threadIdx.x / 6;
-            D[c * 6 + r] = F[(j0 + c) * ld + j0 + r];
-        }
-        __syncthreads();
+        const int r = idx % nc, c = idx / nc;
+        Ls[c * lds + r] = (r >= c) ? F[(long)c * ld + r] : 0.0;
+    }
+    __syncthreads();
+    for (int j0 = 0; j0 < nc; j0 += 6)
+    {
         if (threadIdx.x == 0)
-        {
+        { // 6x6 diagonal block, sequential
             bool bad = false;
-            for (int j = 0; j < 6; j++)
+            for (int j = j0; j < j0 + 6; j++)
             {
-                double d = D[j * 6 + j];
-                for (int k = 0; k < j; k++)
-                    d -= D[k * 6 + j] * D[k * 6 + j];
+                double d = Ls[j * lds + j];
+                for (int k = j0; k < j; k++)
+                    d -= Ls[k * lds + j] * Ls[k * lds + j];
                 if (!(d > PIVOT_TOL))
                 {
                     bad = true;
-                    d = 1.0; // keep going with finite numbers; the step is rejected anyway
+                    d = 1.0; // keep finite numbers flowing; the LM step is rejected anyway
                 }
                 d = sqrt(d);
-                D[j * 6 + j] = d;
+                Ls[j * lds + j] = d;
                 const double inv = 1.0 / d;
-                for (int i = j + 1; i < 6; i++)
+                for (int i = j + 1; i < j0 + 6; i++)
                 {
-                    double s = D[j * 6 + i];
-                    for (int k = 0; k < j; k++)
-                        s -= D[k * 6 + i] * D[k * 6 + j];
-                    D[j * 6 + i] = s * inv;
+                    double s = Ls[j * lds + i];
+                    for (int k = j0; k < j; k++)
+                        s -= Ls[k * lds + i] * Ls[k * lds + j];
+                    Ls[j * lds + i] = s * inv;
                 }
             }
             if (bad)
                 *fail = 1;
         }
         __syncthreads();
-        if (threadIdx.x < 36)
-        {
-            const int r = threadIdx.x % 6, c = threadIdx.x / 6;
-            if (r >= c)
-                F[(j0 + c) * ld + j0 + r] = D[c * 6 + r];
-        }
-        // panel: rows below the diagonal block (including the rhs row)
-        const int nbelow = (int)(ld - (j0 + 6));
-        for (int i = threadIdx.x; i < nbelow; i += CBS)
-        {
-            const long row = j0 + 6 + i;
+        const int m = nc - (j0 + 6); // rows below the diagonal block inside F11
+        for (int i = threadIdx.x; i < m; i += CBS)
+        { // panel rows: x L_D^T = a
+            const int row = j0 + 6 + i;
             double x[6];
 #pragma unroll
             for (int c = 0; c < 6; c++)
             {
-                double s = F[(j0 + c) * ld + row];
+                double s = Ls[(j0 + c) * lds + row];
 #pragma unroll
                 for (int k = 0; k < 6; k++)
                     if (k < c)
-                        s -= x[k] * D[k * 6 + c];
-                x[c] = s / D[c * 6 + c];
+                        s -= x[k] * Ls[(j0 + k) * lds + j0 + c];
+                x[c] = s / Ls[(j0 + c) * lds + j0 + c];
             }
 #pragma unroll
             for (int c = 0; c < 6; c++)
-            {
-                F[(j0 + c) * ld + row] = x[c];
-                Pn[i * 6 + c] = x[c];
-            }
+                Ls[(j0 + c) * lds + row] = x[c];
         }
         __syncthreads();
-        // trailing update: F[i,j] -= Pn[i]·Pn[j] for j in [j0+6, ncols), i >= j (and rhs row)
-        const int nc2 = ncols - (int)(j0 + 6);
-        const long total = (long)nbelow * nc2;
-        for (long idx = threadIdx.x; idx < total; idx += CBS)
-        {
-            const int j = (int)(idx / nbelow), i = (int)(idx % nbelow);
-            if (i < j)
+        for (int idx = threadIdx.x; idx < m * m; idx += CBS)
+        { // trailing update inside F11 (lower part)
+            const int c = j0 + 6 + idx / m, r = j0 + 6 + idx % m;
+            if (r < c)
                 continue;
-            const double* a = Pn + i * 6;
-            const double* b = Pn + j * 6;
-            const double s = a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] +
-                             a[5] * b[5];
-            F[(j0 + 6 + j) * ld + (j0 + 6 + i)] -= s;
+            double s = 0;
+#pragma unroll
+            for (int k = 0; k < 6; k++)
+                s += Ls[(j0 + k) * lds + r] * Ls[(j0 + k) * lds + c];
+            Ls[c * lds + r] -= s;
         }
         __syncthreads();
     }
+    for (int idx = threadIdx.x; idx < nc * nc; idx += CBS)
+    {
+        const int r = idx % nc, c = idx / nc;
+        if (r >= c)
+            F[(long)c * ld + r] = Ls[c * lds + r];
+    }
 }
 
-__global__ __launch_bounds__(CBS) void k_factor_stage(CholPlanDev p, double* __restrict__ fronts,
-                                                      int task0, int32_t* __restrict__ fail)
+__device__ void dev_load_l11(const double* __restrict__ F, long ld, int nc, double* __restrict__ Ls)
+{
+    const int lds = nc + 1;
+    for (int idx = threadIdx.x; idx < nc * nc; idx += CBS)
+    {
+        const int r = idx % nc, c = idx / nc;
+        Ls[c * lds + r] = (r >= c) ? F[(long)c * ld + r] : 0.0;
+    }
+}
+
+// rows [row0, row0+nrows) (absolute scalar rows, nrows <= TR) of F21: X L11^T = B.
+// Ls holds L11; Bt is a TR x (nc+1) LDS tile.  4 threads per row share the update work.
+__device__ void dev_trsm_tile(double* __restrict__ F, long ld, int nc, long row0, int nrows,
+                              const double* __restrict__ Ls, double* __restrict__ Bt)
+{
+    const int lds = nc + 1;
+    for (int idx = threadIdx.x; idx < nrows * nc; idx += CBS)
+    {
+        const int r = idx % nrows, c = idx / nrows;
+        Bt[r * lds + c] = F[(long)c * ld + row0 + r];
+    }
+    __syncthreads();
+    const int r = threadIdx.x >> 2, g = threadIdx.x & 3; // row in tile, column group
+    for (int j0 = 0; j0 < nc; j0 += 6)
+    {
+        if (g == 0 && r < nrows)
+        {
+            double x[6];
+#pragma unroll
+            for (int c = 0; c < 6; c++)
+            {
+                double s = Bt[r * lds + j0 + c];
+#pragma unroll
+                for (int k = 0; k < 6; k++)
+                    if (k < c)
+                        s -= x[k] * Ls[(j0 + k) * lds + j0 + c];
+                x[c] = s / Ls[(j0 + c) * lds + j0 + c];
+            }
+#pragma unroll
+            for (int c = 0; c < 6; c++)
+                Bt[r * lds + j0 + c] = x[c];
+        }
+        __syncthreads();
+        if (r < nrows)
+        {
+            double x[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++)
+                x[k] = Bt[r * lds + j0 + k];
+            for (int c = j0 + 6 + g; c < nc; c += 4)
+            {
+                double s = 0;
+#pragma unroll
+                for (int k = 0; k < 6; k++)
+                    s += x[k] * Ls[(j0 + k) * lds + c];
+                Bt[r * lds + c] -= s;
+            }
+        }
+        __syncthreads();
+    }
+    for (int idx = threadIdx.x; idx < nrows * nc; idx += CBS)
+    {
+        const int rr = idx % nrows, c = idx / nrows;
+        F[(long)c * ld + row0 + rr] = Bt[rr * lds + c];
+    }
+    __syncthreads();
+}
+
+// U(ti,tj) -= L21(ti rows) L21(tj rows)^T for one 64x64 tile on the f64 matrix cores.
+// L21 = F[ncs.., 0..ncs) (column-major, rows contiguous); U = F[ncs.., ncs..).
+// nt = trailing rows (boundary + rhs row), nrs = trailing columns.  Wave w owns the 16
+// U-columns [64 tj + 16 w, +16) and all 64 U-rows of the tile (4 accumulators).
+// MFMA operand map (v_mfma_f64_16x16x4_f64): lane l supplies A[m = l&15][k = l>>4] and
+// B[k = l>>4][n = l&15]; result reg q holds D[m = (l>>4) + 4q][n = l&15].  With m = U column
+// and n = U row the 16 lanes l&15 hit consecutive rows of one column: 128-B segments.
+__device__ void dev_syrk_tile(double* __restrict__ F, long ld, int ncs, int nt, int nrs, int ti,
+                              int tj)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int ln = lane & 15, lk = lane >> 4;
+    const double* L21 = F + ncs; // row offset; element (row i, col k) = L21[k*ld + i]
+    const int jc = 64 * tj + 16 * w + ln; // U column supplied by this lane (A operand)
+    const bool jc_ok = jc < nrs;
+    double4_t acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+        acc[t] = double4_t{0, 0, 0, 0};
+    int irow[4];
+    bool iok[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+    {
+        irow[t] = 64 * ti + 16 * t + ln; // U row supplied by this lane (B operand)
+        iok[t] = irow[t] < nt;
+    }
+    for (int k0 = 0; k0 < ncs; k0 += 4)
+    {
+        const int k = k0 + lk;
+        const bool kok = k < ncs;
+        const double a = (kok && jc_ok) ? L21[(long)k * ld + jc] : 0.0;
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+        {
+            const double b = (kok && iok[t]) ? L21[(long)k * ld + irow[t]] : 0.0;
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+        }
+    }
+    double* U = F + (long)ncs * ld + ncs;
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+    {
+        const int i = irow[t];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            const int j = 64 * tj + 16 * w + lk + 4 * q;
+            if (i < nt && j < nrs && i >= j)
+                U[(long)j * ld + i] -= acc[t][q];
+        }
+    }
+}
+
+// backward substitution of one front: x_J = L11^-T (y_J - L21^T x_R)
+__device__ void dev_backward(const CholPlanDev& p, const double* __restrict__ fronts, int f,
+                             double* __restrict__ lds, double* __restrict__ xnew,
+                             double* __restrict__ xout)
+{
+    const int ncb = p.ncb[f], nb = p.nb[f];
+    const long ld = 6L * nb + 1;
+    const int ncs = 6 * ncb, nrs = 6 * (nb - ncb);
+    const double* F = fronts + p.off[f];
+    const int ldsl = ncs + 1;
+    double* Ls = lds;                  // ncs*(ncs+1)
+    double* vs = lds + ncs * ldsl;     // ncs
+    double* xr = vs + ncs;             // nrs
+    const int32_t* rows = p.rows + p.rows_ptr[f];
+    dev_load_l11(F, ld, ncs, Ls);
+    for (int i = threadIdx.x; i < nrs; i += CBS)
+        xr[i] = xnew[6L * rows[i / 6] + (i % 6)];
+    __syncthreads();
+    { // v_j = y_j - sum_i L21[i,j] x_R[i]: one wave per column, lanes stride the rows
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        for (int j = w; j < ncs; j += CBS / 64)
+        {
+            const double* col = F + (long)j * ld + ncs;
+            double s = 0;
+            for (int i = lane; i < nrs; i += 64)
+                s += col[i] * xr[i];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1)
+                s += __shfl_down(s, off, 64);
+            if (lane == 0)
+                vs[j] = F[(long)j * ld + (ld - 1)] - s;
+        }
+    }
+    __syncthreads();
+    for (int j0 = ncs - 6; j0 >= 0; j0 -= 6)
+    { // L11^T x = v, 6 unknowns at a time (upper-triangular 6x6 solve by one thread)
+        if (threadIdx.x == 0)
+        {
+            for (int j = j0 + 5; j >= j0; j--)
+            {
+                double s = vs[j];
+                for (int k = j + 1; k < j0 + 6; k++)
+                    s -= Ls[j * ldsl + k] * vs[k];
+                vs[j] = s / Ls[j * ldsl + j];
+            }
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < j0; t += CBS)
+        {
+            double s = 0;
+#pragma unroll
+            for (int k = 0; k < 6; k++)
+                s += Ls[t * ldsl + j0 + k] * vs[j0 + k];
+            vs[t] -= s;
+        }
+        __syncthreads();
+    }
+    const int c0 = p.col0[f];
+    for (int j = threadIdx.x; j < ncs; j += CBS)
+    {
+        const int jb = j / 6, comp = j % 6;
+        const double v = vs[j];
+        xnew[6L * (c0 + jb) + comp] = v;
+        xout[6L * p.perm[c0 + jb] + comp] = v;
+    }
+    __threadfence_block();
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------- stage 0: subtrees ----
+__global__ __launch_bounds__(CBS) void k_subtree_factor(CholPlanDev p, double* __restrict__ fronts,
+                                                        int task0, int32_t* __restrict__ fail)
 {
     extern __shared__ double lds[];
     const int task = task0 + blockIdx.x;
     for (int fi = p.task_ptr[task]; fi < p.task_ptr[task + 1]; fi++)
     {
         const int f = p.task_fronts[fi];
-        front_extend_add(p, fronts, f);
+        const int ncb = p.ncb[f], nb = p.nb[f];
+        const long ld = 6L * nb + 1;
+        const int ncs = 6 * ncb, nrs = 6 * (nb - ncb), nt = nrs + 1;
+        double* F = fronts + p.off[f];
+        double* Ls = lds;
+        double* Bt = lds + ncs * (ncs + 1);
+        dev_extend_add(p, fronts, f, 0, nb);
+        dev_potrf(F, ld, ncs, Ls, fail);
         __syncthreads();
-        front_factor(p, fronts, f, lds, fail);
+        for (int r0 = 0; r0 < nt; r0 += TR)
+            dev_trsm_tile(F, ld, ncs, ncs + r0, min(TR, nt - r0), Ls, Bt);
+        __threadfence_block();
+        __syncthreads();
+        const int nti = (nt + 63) / 64, ntj = (nrs + 63) / 64;
+        for (int tj = 0; tj < ntj; tj++)
+            for (int ti = tj; ti < nti; ti++)
+                dev_syrk_tile(F, ld, ncs, nt, nrs, ti, tj);
         __threadfence_block();
         __syncthreads();
     }
 }
 
-// ---------------------------------------------------------------- backward -------------
+// ---------------------------------------------------------------- upper stages ---------
+__global__ __launch_bounds__(CBS) void k_up_extend_add(CholPlanDev p, double* __restrict__ fronts,
+                                                       const int32_t* __restrict__ wl)
+{
+    const int32_t* it = wl + 3 * blockIdx.x;
+    dev_extend_add(p, fronts, it[0], it[1], it[2]);
+}
+
+__global__ __launch_bounds__(CBS) void k_up_potrf(CholPlanDev p, double* __restrict__ fronts,
+                                                  int task0, int32_t* __restrict__ fail)
+{
+    extern __shared__ double lds[];
+    const int f = p.task_fronts[p.task_ptr[task0 + blockIdx.x]];
+    dev_potrf(fronts + p.off[f], 6L * p.nb[f] + 1, 6 * p.ncb[f], lds, fail);
+}
+
+__global__ __launch_bounds__(CBS) void k_up_trsm(CholPlanDev p, double* __restrict__ fronts,
+                                                 const int32_t* __restrict__ wl)
+{
+    extern __shared__ double lds[];
+    const int32_t* it = wl + 3 * blockIdx.x;
+    const int f = it[0];
+    const int ncs = 6 * p.ncb[f];
+    const long ld = 6L * p.nb[f] + 1;
+    double* F = fronts + p.off[f];
+    double* Ls = lds;
+    double* Bt = lds + ncs * (ncs + 1);
+    dev_load_l11(F, ld, ncs, Ls);
+    __syncthreads();
+    dev_trsm_tile(F, ld, ncs, ncs + it[1], it[2] - it[1], Ls, Bt);
+}
+
+__global__ __launch_bounds__(CBS) void k_up_syrk(CholPlanDev p, double* __restrict__ fronts,
+                                                 const int32_t* __restrict__ wl)
+{
+    const int32_t* it = wl + 3 * blockIdx.x;
+    const int f = it[0];
+    const int ncs = 6 * p.ncb[f], nrs = 6 * (p.nb[f] - p.ncb[f]);
+    dev_syrk_tile(fronts + p.off[f], 6L * p.nb[f] + 1, ncs, nrs + 1, nrs, it[1], it[2]);
+}
+
 __global__ __launch_bounds__(CBS) void k_backward_stage(CholPlanDev p,
                                                         const double* __restrict__ fronts,
                                                         int task0, double* __restrict__ xnew,
@@ -211,48 +469,13 @@ __global__ __launch_bounds__(CBS) void k_backward_stage(CholPlanDev p,
     extern __shared__ double lds[];
     const int task = task0 + blockIdx.x;
     for (int fi = p.task_ptr[task + 1] - 1; fi >= p.task_ptr[task]; fi--)
-    {
-        const int f = p.task_fronts[fi];
-        const int ncb = p.ncb[f], nb = p.nb[f];
-        const long ld = 6L * nb + 1;
-        const int ncs = 6 * ncb, nrs = 6 * (nb - ncb);
-        const double* F = fronts + p.off[f];
-        double* xr = lds;        // nrs
-        double* vs = lds + nrs;  // ncs
-        const int32_t* rows = p.rows + p.rows_ptr[f];
-        for (int i = threadIdx.x; i < nrs; i += CBS)
-            xr[i] = xnew[6L * rows[i / 6] + (i % 6)];
-        __syncthreads();
-        for (int j = threadIdx.x; j < ncs; j += CBS)
-        {
-            const double* col = F + (long)j * ld;
-            double s = col[ld - 1]; // y_j
-            for (int i = 0; i < nrs; i++)
-                s -= col[ncs + i] * xr[i];
-            vs[j] = s;
-        }
-        __syncthreads();
-        for (int j = ncs - 1; j >= 0; j--)
-        {
-            if (threadIdx.x == 0)
-                vs[j] /= F[(long)j * ld + j];
-            __syncthreads();
-            const double xj = vs[j];
-            for (int t = threadIdx.x; t < j; t += CBS)
-                vs[t] -= F[(long)t * ld + j] * xj;
-            __syncthreads();
-        }
-        const int c0 = p.col0[f];
-        for (int j = threadIdx.x; j < ncs; j += CBS)
-        {
-            const int jb = j / 6, comp = j % 6;
-            const double v = vs[j];
-            xnew[6L * (c0 + jb) + comp] = v;
-            xout[6L * p.perm[c0 + jb] + comp] = v;
-        }
-        __threadfence_block();
-        __syncthreads();
-    }
+        dev_backward(p, fronts, p.task_fronts[fi], lds, xnew, xout);
+}
+
+void ensure_lds(const void* fn, size_t bytes)
+{
+    if (bytes > 48 * 1024)
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
 } // namespace
@@ -260,13 +483,13 @@ __global__ __launch_bounds__(CBS) void k_backward_stage(CholPlanDev p,
 namespace cugo_k
 {
 
-size_t chol_lds_factor_bytes(long ld_max) { return (size_t)(40 + 6 * ld_max) * sizeof(double); }
-size_t chol_lds_backward_bytes(long ld_max) { return (size_t)(ld_max + 8) * sizeof(double); }
-
-static void ensure_lds(const void* fn, size_t bytes)
+size_t chol_lds_factor_bytes(int nc_max)
 {
-    if (bytes > 64 * 1024)
-        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    return (size_t)(nc_max * (nc_max + 1) + TR * (nc_max + 1) + 8) * sizeof(double);
+}
+size_t chol_lds_backward_bytes(int nc_max, long ld_max)
+{
+    return (size_t)(nc_max * (nc_max + 1) + nc_max + ld_max + 8) * sizeof(double);
 }
 
 void launch_chol_assemble(hipStream_t s, const CholPlanDev& p, double* d_fronts,
@@ -283,14 +506,34 @@ void launch_chol_assemble(hipStream_t s, const CholPlanDev& p, double* d_fronts,
                            d_fronts, d_bsc);
 }
 
-void launch_chol_factor_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,
-                              int ntasks, size_t lds_bytes, int32_t* d_fail)
+void launch_chol_subtree_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,
+                               int ntasks, size_t lds_bytes, int32_t* d_fail)
 {
     if (ntasks <= 0)
         return;
-    ensure_lds(reinterpret_cast<const void*>(k_factor_stage), lds_bytes);
-    hipLaunchKernelGGL(k_factor_stage, dim3(ntasks), dim3(CBS), lds_bytes, s, p, d_fronts, task0,
+    ensure_lds(reinterpret_cast<const void*>(k_subtree_factor), lds_bytes);
+    hipLaunchKernelGGL(k_subtree_factor, dim3(ntasks), dim3(CBS), lds_bytes, s, p, d_fronts, task0,
                        d_fail);
+}
+
+void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,
+                             int ntasks, const int32_t* d_wl, int ea0, int nea, int tr0, int ntr,
+                             int sy0, int nsy, size_t lds_bytes, int32_t* d_fail)
+{
+    if (ntasks <= 0)
+        return;
+    if (nea > 0)
+        hipLaunchKernelGGL(k_up_extend_add, dim3(nea), dim3(CBS), 0, s, p, d_fronts, d_wl + 3L * ea0);
+    ensure_lds(reinterpret_cast<const void*>(k_up_potrf), lds_bytes);
+    hipLaunchKernelGGL(k_up_potrf, dim3(ntasks), dim3(CBS), lds_bytes, s, p, d_fronts, task0, d_fail);
+    if (ntr > 0)
+    {
+        ensure_lds(reinterpret_cast<const void*>(k_up_trsm), lds_bytes);
+        hipLaunchKernelGGL(k_up_trsm, dim3(ntr), dim3(CBS), lds_bytes, s, p, d_fronts,
+                           d_wl + 3L * tr0);
+    }
+    if (nsy > 0)
+        hipLaunchKernelGGL(k_up_syrk, dim3(nsy), dim3(CBS), 0, s, p, d_fronts, d_wl + 3L * sy0);
 }
 
 void launch_chol_backward_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,

@@ -76,12 +76,16 @@ struct CholPlanDev
 
 void launch_chol_assemble(hipStream_t s, const CholPlanDev& p, double* d_fronts, size_t front_doubles,
                           const double* d_Hsc, double lambda, const double* d_bsc);
-void launch_chol_factor_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,
-                              int ntasks, size_t lds_bytes, int32_t* d_fail);
+void launch_chol_subtree_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,
+                               int ntasks, size_t lds_bytes, int32_t* d_fail);
+// one etree level: extend-add / potrf / trsm / syrk kernels over the work items d_wl[...]
+void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,
+                             int ntasks, const int32_t* d_wl, int ea0, int nea, int tr0, int ntr,
+                             int sy0, int nsy, size_t lds_bytes, int32_t* d_fail);
 void launch_chol_backward_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,
                                 int ntasks, size_t lds_bytes, double* d_xnew, double* d_x);
-// LDS bytes needed by the two stage kernels for a front with scalar leading dimension ld
-size_t chol_lds_factor_bytes(long ld_max);
-size_t chol_lds_backward_bytes(long ld_max);
+// LDS bytes of the factor kernels (L11 + one 64-row tile) and of the backward kernel
+size_t chol_lds_factor_bytes(int nc_max);
+size_t chol_lds_backward_bytes(int nc_max, long ld_max);
 
 } // namespace cugo_k

@@ -20,6 +20,8 @@
 // of the factorisation (y ends in the rhs row of the pivot columns); only the backward
 // substitution needs its own top-down pass.  All sums have a fixed order: bit-reproducible.
 // A pivot <= 1e-14 (or NaN) raises *fail (ref: csrcholZeroPivot tol, src/cholesky.hpp:85).
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace
@@ -76,22 +78,24 @@ __global__ __launch_bounds__(CBS) void k_assemble_rhs(CholPlanDev p, double* __r
 
 // ---------------------------------------------------------------- device building blocks
 // children -> parent, restricted to parent block columns [cb0, cb1); children one after the
-// other (barrier in between) so every parent entry is summed in child order
+// other (barrier in between) so every parent entry is summed in child order.  One wave per
+// child column, lanes stride the rows: coalesced reads of U, 8-B scattered RMW on the parent.
 __device__ void dev_extend_add(const CholPlanDev& p, double* __restrict__ fronts, int f, int cb0,
                                int cb1)
 {
     const long ldp = 6L * p.nb[f] + 1;
     double* Fp = fronts + p.off[f];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int ci = p.child_ptr[f]; ci < p.child_ptr[f + 1]; ci++)
     {
         const int c = p.child[ci];
         const int ncb = p.ncb[c], nbr = p.nb[c] - ncb;
         const int32_t* rel = p.rel + p.rel_ptr[c];
         // child update block columns whose parent column falls in [cb0, cb1) (rel is ascending)
-        int jlo = 0, jhi = nbr;
+        int jlo = 0;
         while (jlo < nbr && rel[jlo] < cb0)
             jlo++;
-        jhi = jlo;
+        int jhi = jlo;
         while (jhi < nbr && rel[jhi] < cb1)
             jhi++;
         if (jhi > jlo)
@@ -99,20 +103,67 @@ __device__ void dev_extend_add(const CholPlanDev& p, double* __restrict__ fronts
             const long ldc = 6L * p.nb[c] + 1;
             const double* U = fronts + p.off[c] + (6L * ncb) * ldc + 6L * ncb; // (0,0) of update
             const int nru = 6 * nbr + 1;
-            const int j0 = 6 * jlo, ncolsj = 6 * (jhi - jlo);
-            const int nrowsj = nru - j0; // rows j0 .. nru-1 can be below the diagonal
-            for (int idx = threadIdx.x; idx < ncolsj * nrowsj; idx += CBS)
+            for (int j = 6 * jlo + wv; j < 6 * jhi; j += CBS / 64)
             {
-                const int j = j0 + idx / nrowsj, i = j0 + idx % nrowsj;
-                if (i < j)
-                    continue;
                 const long pj = 6L * rel[j / 6] + (j % 6);
-                const long pi = (i == nru - 1) ? (ldp - 1) : 6L * rel[i / 6] + (i % 6);
-                Fp[pj * ldp + pi] += U[(long)j * ldc + i];
+                const double* ucol = U + (long)j * ldc;
+                double* pcol = Fp + pj * ldp;
+                for (int i = j + lane; i < nru; i += 64)
+                {
+                    const long pi = (i == nru - 1) ? (ldp - 1) : 6L * rel[i / 6] + (i % 6);
+                    pcol[pi] += ucol[i];
+                }
             }
         }
         __syncthreads();
     }
+}
+
+// in-register Cholesky of the 6x6 diagonal block at (j0,j0) of an LDS matrix (one thread)
+__device__ __forceinline__ bool chol6_lds(double* __restrict__ Ls, int lds, int j0)
+{
+    double a[6][6];
+#pragma unroll
+    for (int c = 0; c < 6; c++)
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+            a[r][c] = (r >= c) ? Ls[(j0 + c) * lds + j0 + r] : 0.0;
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 6; j++)
+    {
+        double d = a[j][j];
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+            if (k < j)
+                d -= a[j][k] * a[j][k];
+        if (!(d > PIVOT_TOL))
+        {
+            bad = true;
+            d = 1.0; // keep finite numbers flowing; the LM step is rejected anyway
+        }
+        d = sqrt(d);
+        a[j][j] = d;
+        const double inv = 1.0 / d;
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+            if (i > j)
+            {
+                double s = a[i][j];
+#pragma unroll
+                for (int k = 0; k < 6; k++)
+                    if (k < j)
+                        s -= a[i][k] * a[j][k];
+                a[i][j] = s * inv;
+            }
+    }
+#pragma unroll
+    for (int c = 0; c < 6; c++)
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+            if (r >= c)
+                Ls[(j0 + c) * lds + j0 + r] = a[r][c];
+    return bad;
 }
 
 // L11 = chol(F11) in LDS (Ls: nc x nc, leading dimension nc+1), blocked by 6 columns.
@@ -130,30 +181,8 @@ __device__ void dev_potrf(double* __restrict__ F, long ld, int nc, double* __res
     for (int j0 = 0; j0 < nc; j0 += 6)
     {
         if (threadIdx.x == 0)
-        { // 6x6 diagonal block, sequential
-            bool bad = false;
-            for (int j = j0; j < j0 + 6; j++)
-            {
-                double d = Ls[j * lds + j];
-                for (int k = j0; k < j; k++)
-                    d -= Ls[k * lds + j] * Ls[k * lds + j];
-                if (!(d > PIVOT_TOL))
-                {
-                    bad = true;
-                    d = 1.0; // keep finite numbers flowing; the LM step is rejected anyway
-                }
-                d = sqrt(d);
-                Ls[j * lds + j] = d;
-                const double inv = 1.0 / d;
-                for (int i = j + 1; i < j0 + 6; i++)
-                {
-                    double s = Ls[j * lds + i];
-                    for (int k = j0; k < j; k++)
-                        s -= Ls[k * lds + i] * Ls[k * lds + j];
-                    Ls[j * lds + i] = s * inv;
-                }
-            }
-            if (bad)
+        {
+            if (chol6_lds(Ls, lds, j0))
                 *fail = 1;
         }
         __syncthreads();
@@ -209,7 +238,15 @@ __device__ void dev_load_l11(const double* __restrict__ F, long ld, int nc, doub
 }
 
 // rows [row0, row0+nrows) (absolute scalar rows, nrows <= TR) of F21: X L11^T = B.
-// Ls holds L11; Bt is a TR x (nc+1) LDS tile.  4 threads per row share the update work.
+// Ls holds L11; Bt is a TR x (nc+1) LDS tile.  4 adjacent lanes share one row, so a row
+// never leaves its wave: LDS operations of one wave execute in order, a wave-level fence is
+// all the synchronisation the column loop needs.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
 __device__ void dev_trsm_tile(double* __restrict__ F, long ld, int nc, long row0, int nrows,
                               const double* __restrict__ Ls, double* __restrict__ Bt)
 {
@@ -221,43 +258,42 @@ __device__ void dev_trsm_tile(double* __restrict__ F, long ld, int nc, long row0
     }
     __syncthreads();
     const int r = threadIdx.x >> 2, g = threadIdx.x & 3; // row in tile, column group
-    for (int j0 = 0; j0 < nc; j0 += 6)
+    if (r < nrows)
     {
-        if (g == 0 && r < nrows)
+        double* row = Bt + r * lds;
+        for (int j0 = 0; j0 < nc; j0 += 6)
         {
+            // every lane of the row solves the 6x6 system redundantly (same inputs, same result)
             double x[6];
 #pragma unroll
             for (int c = 0; c < 6; c++)
             {
-                double s = Bt[r * lds + j0 + c];
+                double s = row[j0 + c];
 #pragma unroll
                 for (int k = 0; k < 6; k++)
                     if (k < c)
                         s -= x[k] * Ls[(j0 + k) * lds + j0 + c];
                 x[c] = s / Ls[(j0 + c) * lds + j0 + c];
             }
+            wave_lds_sync(); // all 4 lanes have read the old values
+            if (g == 0)
+            {
 #pragma unroll
-            for (int c = 0; c < 6; c++)
-                Bt[r * lds + j0 + c] = x[c];
-        }
-        __syncthreads();
-        if (r < nrows)
-        {
-            double x[6];
-#pragma unroll
-            for (int k = 0; k < 6; k++)
-                x[k] = Bt[r * lds + j0 + k];
+                for (int c = 0; c < 6; c++)
+                    row[j0 + c] = x[c];
+            }
             for (int c = j0 + 6 + g; c < nc; c += 4)
             {
                 double s = 0;
 #pragma unroll
                 for (int k = 0; k < 6; k++)
                     s += x[k] * Ls[(j0 + k) * lds + c];
-                Bt[r * lds + c] -= s;
+                row[c] -= s;
             }
+            wave_lds_sync(); // updates visible to the row's other lanes
         }
-        __syncthreads();
     }
+    __syncthreads();
     for (int idx = threadIdx.x; idx < nrows * nc; idx += CBS)
     {
         const int rr = idx % nrows, c = idx / nrows;
@@ -268,40 +304,52 @@ __device__ void dev_trsm_tile(double* __restrict__ F, long ld, int nc, long row0
 
 // U(ti,tj) -= L21(ti rows) L21(tj rows)^T for one 64x64 tile on the f64 matrix cores.
 // L21 = F[ncs.., 0..ncs) (column-major, rows contiguous); U = F[ncs.., ncs..).
-// nt = trailing rows (boundary + rhs row), nrs = trailing columns.  Wave w owns the 16
-// U-columns [64 tj + 16 w, +16) and all 64 U-rows of the tile (4 accumulators).
+// nt = trailing rows (boundary + rhs row), nrs = trailing columns.
+// Both 64 x ncs row panels are staged in LDS by the whole workgroup in one pass (all loads in
+// flight at once: the K loop then runs from LDS without touching memory latency), k-major
+// with an 80-double stride so the two 16-lane halves of a ds_read_b64 hit different banks.
+// Wave w owns the 16 U-columns [64 tj + 16 w, +16) and all 64 U-rows (4 accumulators).
 // MFMA operand map (v_mfma_f64_16x16x4_f64): lane l supplies A[m = l&15][k = l>>4] and
 // B[k = l>>4][n = l&15]; result reg q holds D[m = (l>>4) + 4q][n = l&15].  With m = U column
 // and n = U row the 16 lanes l&15 hit consecutive rows of one column: 128-B segments.
+constexpr int PST = 80; // LDS panel stride (doubles) per k
 __device__ void dev_syrk_tile(double* __restrict__ F, long ld, int ncs, int nt, int nrs, int ti,
-                              int tj)
+                              int tj, double* __restrict__ lds)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int ln = lane & 15, lk = lane >> 4;
-    const double* L21 = F + ncs; // row offset; element (row i, col k) = L21[k*ld + i]
-    const int jc = 64 * tj + 16 * w + ln; // U column supplied by this lane (A operand)
-    const bool jc_ok = jc < nrs;
+    const double* L21 = F + ncs; // element (row i, col k) = L21[k*ld + i]
+    double* Pi = lds;                 // rows of tile ti : Pi[k*PST + r]
+    double* Pj = lds + ncs * PST;     // rows of tile tj (aliases Pi on diagonal tiles)
+    const bool diag = ti == tj;
+    if (diag)
+        Pj = Pi;
+    for (int idx = threadIdx.x; idx < 64 * ncs; idx += CBS)
+    {
+        const int r = idx & 63, k = idx >> 6;
+        const int gi = 64 * ti + r;
+        Pi[k * PST + r] = gi < nt ? L21[(long)k * ld + gi] : 0.0;
+        if (!diag)
+        {
+            const int gj = 64 * tj + r;
+            Pj[k * PST + r] = gj < nt ? L21[(long)k * ld + gj] : 0.0;
+        }
+    }
+    __syncthreads();
     double4_t acc[4];
 #pragma unroll
     for (int t = 0; t < 4; t++)
         acc[t] = double4_t{0, 0, 0, 0};
-    int irow[4];
-    bool iok[4];
-#pragma unroll
-    for (int t = 0; t < 4; t++)
-    {
-        irow[t] = 64 * ti + 16 * t + ln; // U row supplied by this lane (B operand)
-        iok[t] = irow[t] < nt;
-    }
-    for (int k0 = 0; k0 < ncs; k0 += 4)
+    const int kend = (ncs + 3) & ~3;
+    for (int k0 = 0; k0 < kend; k0 += 4)
     {
         const int k = k0 + lk;
         const bool kok = k < ncs;
-        const double a = (kok && jc_ok) ? L21[(long)k * ld + jc] : 0.0;
+        const double a = kok ? Pj[k * PST + 16 * w + ln] : 0.0;
 #pragma unroll
         for (int t = 0; t < 4; t++)
         {
-            const double b = (kok && iok[t]) ? L21[(long)k * ld + irow[t]] : 0.0;
+            const double b = kok ? Pi[k * PST + 16 * t + ln] : 0.0;
             acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
         }
     }
@@ -309,7 +357,7 @@ __device__ void dev_syrk_tile(double* __restrict__ F, long ld, int ncs, int nt, 
 #pragma unroll
     for (int t = 0; t < 4; t++)
     {
-        const int i = irow[t];
+        const int i = 64 * ti + 16 * t + ln;
 #pragma unroll
         for (int q = 0; q < 4; q++)
         {
@@ -318,6 +366,7 @@ __device__ void dev_syrk_tile(double* __restrict__ F, long ld, int ncs, int nt, 
                 U[(long)j * ld + i] -= acc[t][q];
         }
     }
+    __syncthreads(); // panels are reused by the next tile of this workgroup
 }
 
 // backward substitution of one front: x_J = L11^-T (y_J - L21^T x_R)
@@ -358,13 +407,28 @@ __device__ void dev_backward(const CholPlanDev& p, const double* __restrict__ fr
     { // L11^T x = v, 6 unknowns at a time (upper-triangular 6x6 solve by one thread)
         if (threadIdx.x == 0)
         {
-            for (int j = j0 + 5; j >= j0; j--)
+            double l[6][6], v[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++)
             {
-                double s = vs[j];
-                for (int k = j + 1; k < j0 + 6; k++)
-                    s -= Ls[j * ldsl + k] * vs[k];
-                vs[j] = s / Ls[j * ldsl + j];
+                v[j] = vs[j0 + j];
+#pragma unroll
+                for (int k = 0; k < 6; k++)
+                    l[k][j] = (k >= j) ? Ls[(j0 + j) * ldsl + j0 + k] : 0.0; // L[row k][col j]
             }
+#pragma unroll
+            for (int j = 5; j >= 0; j--)
+            {
+                double s = v[j];
+#pragma unroll
+                for (int k = 0; k < 6; k++)
+                    if (k > j)
+                        s -= l[k][j] * v[k];
+                v[j] = s / l[j][j];
+            }
+#pragma unroll
+            for (int j = 0; j < 6; j++)
+                vs[j0 + j] = v[j];
         }
         __syncthreads();
         for (int t = threadIdx.x; t < j0; t += CBS)
@@ -414,7 +478,7 @@ __global__ __launch_bounds__(CBS) void k_subtree_factor(CholPlanDev p, double* _
         const int nti = (nt + 63) / 64, ntj = (nrs + 63) / 64;
         for (int tj = 0; tj < ntj; tj++)
             for (int ti = tj; ti < nti; ti++)
-                dev_syrk_tile(F, ld, ncs, nt, nrs, ti, tj);
+                dev_syrk_tile(F, ld, ncs, nt, nrs, ti, tj, lds);
         __threadfence_block();
         __syncthreads();
     }
@@ -455,10 +519,11 @@ __global__ __launch_bounds__(CBS) void k_up_trsm(CholPlanDev p, double* __restri
 __global__ __launch_bounds__(CBS) void k_up_syrk(CholPlanDev p, double* __restrict__ fronts,
                                                  const int32_t* __restrict__ wl)
 {
+    extern __shared__ double lds[];
     const int32_t* it = wl + 3 * blockIdx.x;
     const int f = it[0];
     const int ncs = 6 * p.ncb[f], nrs = 6 * (p.nb[f] - p.ncb[f]);
-    dev_syrk_tile(fronts + p.off[f], 6L * p.nb[f] + 1, ncs, nrs + 1, nrs, it[1], it[2]);
+    dev_syrk_tile(fronts + p.off[f], 6L * p.nb[f] + 1, ncs, nrs + 1, nrs, it[1], it[2], lds);
 }
 
 __global__ __launch_bounds__(CBS) void k_backward_stage(CholPlanDev p,
@@ -485,7 +550,9 @@ namespace cugo_k
 
 size_t chol_lds_factor_bytes(int nc_max)
 {
-    return (size_t)(nc_max * (nc_max + 1) + TR * (nc_max + 1) + 8) * sizeof(double);
+    const size_t trsm = (size_t)nc_max * (nc_max + 1) + (size_t)TR * (nc_max + 1);
+    const size_t syrk = 2 * (size_t)nc_max * PST;
+    return (std::max(trsm, syrk) + 8) * sizeof(double);
 }
 size_t chol_lds_backward_bytes(int nc_max, long ld_max)
 {
@@ -533,7 +600,11 @@ void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fron
                            d_wl + 3L * tr0);
     }
     if (nsy > 0)
-        hipLaunchKernelGGL(k_up_syrk, dim3(nsy), dim3(CBS), 0, s, p, d_fronts, d_wl + 3L * sy0);
+    {
+        ensure_lds(reinterpret_cast<const void*>(k_up_syrk), lds_bytes);
+        hipLaunchKernelGGL(k_up_syrk, dim3(nsy), dim3(CBS), lds_bytes, s, p, d_fronts,
+                           d_wl + 3L * sy0);
+    }
 }
 
 void launch_chol_backward_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,

@@ -211,6 +211,14 @@ class Graph:
         check(lib().cugo_graph_get_landmarks(self._g, len(ids), _p(ids, _i32p), _p(out, _f64p)))
         return out
 
+    def set_poses(self, ids, q_t7):
+        ids = np.ascontiguousarray(ids, np.int32); q = np.ascontiguousarray(q_t7, np.float64)
+        check(lib().cugo_graph_set_poses(self._g, len(ids), _p(ids, _i32p), _p(q, _f64p)))
+
+    def set_landmarks(self, ids, xyz):
+        ids = np.ascontiguousarray(ids, np.int32); x = np.ascontiguousarray(xyz, np.float64)
+        check(lib().cugo_graph_set_landmarks(self._g, len(ids), _p(ids, _i32p), _p(x, _f64p)))
+
     def n_active_edges(self):
         return lib().cugo_graph_n_active_edges(self._g)
 

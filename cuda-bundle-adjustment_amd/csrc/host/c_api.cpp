@@ -472,6 +472,20 @@ int cugo_graph_get_landmarks(cugo_graph* g, int n, const int32_t* ids, double* x
             g->lms.getVertex(ids[i])->getEstimate().copyTo(xyz + 3 * (size_t)i);
     });
 }
+int cugo_graph_set_poses(cugo_graph* g, int n, const int32_t* ids, const double* qt)
+{
+    return guarded([&] {
+        for (int i = 0; i < n; i++)
+            g->poses.getVertex(ids[i])->setEstimate(cugo::Se3D(qt + 7 * (size_t)i, qt + 7 * (size_t)i + 4));
+    });
+}
+int cugo_graph_set_landmarks(cugo_graph* g, int n, const int32_t* ids, const double* xyz)
+{
+    return guarded([&] {
+        for (int i = 0; i < n; i++)
+            g->lms.getVertex(ids[i])->setEstimate(cugo::Vec3d(xyz + 3 * (size_t)i));
+    });
+}
 int cugo_graph_n_active_edges(cugo_graph* g) { return g->opt->nActiveEdges(); }
 int cugo_graph_time_profile(cugo_graph* g, char* names, int buf_len, double* ms, int cap)
 {

@@ -685,10 +685,12 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
             {
                 const int f = P.task_fronts[P.task_ptr[t]];
                 const int nb = P.nb[f], ncb = P.ncb[f];
+                // extend-add of the boundary columns (the pivot columns are done by the potrf
+                // workgroup itself)
                 if (P.child_ptr[f + 1] > P.child_ptr[f])
-                    for (int c0 = 0; c0 < nb; c0 += 8)
+                    for (int c0 = ncb; c0 < nb; c0 += 4)
                     {
-                        ea.push_back(f), ea.push_back(c0), ea.push_back(std::min(nb, c0 + 8));
+                        ea.push_back(f), ea.push_back(c0), ea.push_back(std::min(nb, c0 + 4));
                     }
                 const int nbelow = 6 * (nb - ncb) + 1; // boundary rows + rhs row
                 for (int r0 = 0; r0 < nbelow; r0 += 64)
@@ -697,10 +699,11 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
                 }
                 const int nrs = 6 * (nb - ncb);
                 const int nti = (nbelow + 63) / 64, ntj = (nrs + 63) / 64;
+                int tile = 0; // linear index, column-major over the lower triangle of tiles
                 for (int tj = 0; tj < ntj; tj++)
-                    for (int ti = tj; ti < nti; ti++)
+                    for (int ti = tj; ti < nti; ti++, tile++)
                     {
-                        sy.push_back(f), sy.push_back(ti), sy.push_back(tj);
+                        sy.push_back(f), sy.push_back(tile), sy.push_back(tj);
                     }
             }
         P.ea_ptr.push_back((int)ea.size() / 3);

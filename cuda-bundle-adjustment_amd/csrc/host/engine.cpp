@@ -83,6 +83,7 @@ struct Engine::Impl
     cugo_edges ev{};
     cugo_hsc_struct hs{};
     bool structure_dirty = true;
+    uint64_t structure_sig = 0; // hash of the flattened topology the structure was built for
 
     // optional HIP-event timing of kernel groups
     bool ktiming = false;
@@ -351,7 +352,30 @@ void Engine::initialize(FlatGraph&& g)
     ev.d_cam = m.n_cams > 1 ? m.d_cam.data() : nullptr, ev.d_cams = m.d_cams.data();
     ev.n_cams = m.n_cams, ev.d_lm_ptr = m.d_lm_ptr.data(), ev.d_pose_ptr = m.d_pose_ptr.data();
     ev.d_pose_edge = m.d_pose_edge.data();
-    m.structure_dirty = true;
+    // Re-use of the Hsc structure, ordering and symbolic factor across optimize() calls when
+    // the topology is unchanged (ref: the isDirty logic of BlockSolver::buildStructure,
+    // block_solver.cpp:151-216, which skips the rebuild for clean edge sets).  Decided by a
+    // hash of the flattened topology, so a changed fixed flag is noticed too.
+    {
+        uint64_t h = 1469598103934665603ull;
+        auto mix = [&h](const void* p, size_t n) {
+            const uint64_t* w = static_cast<const uint64_t*>(p);
+            for (size_t i = 0; i < n / 8; i++)
+                h = (h ^ w[i]) * 1099511628211ull;
+            const unsigned char* c = static_cast<const unsigned char*>(p) + (n & ~size_t(7));
+            for (size_t i = 0; i < (n & 7); i++)
+                h = (h ^ c[i]) * 1099511628211ull;
+        };
+        const int dims[8] = {m.Pall, m.Lall, m.P, m.L, E, m.rank, m.world, Etot};
+        mix(dims, sizeof dims);
+        mix(m.h_e_pose.data(), sizeof(int32_t) * m.h_e_pose.size());
+        mix(m.h_e_lm.data(), sizeof(int32_t) * m.h_e_lm.size());
+        mix(m.h_flags.data(), m.h_flags.size());
+        mix(m.cov_pose.data(), sizeof(int32_t) * m.cov_pose.size());
+        if (h != m.structure_sig || std::getenv("CUGO_NO_STRUCTURE_REUSE"))
+            m.structure_dirty = true;
+        m.structure_sig = h;
+    }
     prof_[PROF_INITIALIZE] += ms_since(t0);
 }
 
@@ -405,58 +429,54 @@ void Engine::build_structure()
         m.hsc_rowptr[p + 1] = (int32_t)m.hsc_colind.size();
     }
     const int B = (int)m.hsc_colind.size();
-    // contribution lists of the off-diagonal blocks from the LOCAL edges
-    std::vector<int32_t> slot; // per local product, in generation order
-    std::vector<int32_t> off_cnt(B + 1, 0);
+    // contribution lists of the off-diagonal blocks from the LOCAL edges, built row by row
+    // (pose-major): pos[q] gives the slot of column q in the current row, so every product is
+    // placed with O(1) work; inside a block the contributions are in ascending landmark order.
     auto free_free = [&](int e) {
         return (m.h_flags[e] & (CUGO_EDGE_FIXED_L | CUGO_EDGE_FIXED_P | CUGO_EDGE_INACTIVE)) == 0;
     };
-    for (int l = 0; l < L; l++)
+    std::vector<int32_t> off_cnt(B + 1, 0);
+    std::vector<int32_t> pos(P, -1);
+    for (int p = 0; p < P; p++)
     {
-        const int e0 = m.h_lm_ptr[l], e1 = m.h_lm_ptr[l + 1];
-        for (int a = e0; a < e1; a++)
+        const int r0 = m.hsc_rowptr[p], r1 = m.hsc_rowptr[p + 1];
+        for (int k = r0; k < r1; k++)
+            pos[m.hsc_colind[k]] = k;
+        for (int i = m.h_pose_ptr[p]; i < m.h_pose_ptr[p + 1]; i++)
         {
+            const int a = m.h_pose_edge[i];
             if (!free_free(a))
                 continue;
-            const int pa = m.h_e_pose[a];
-            const int32_t* rb = m.hsc_colind.data() + m.hsc_rowptr[pa];
-            const int32_t* re = m.hsc_colind.data() + m.hsc_rowptr[pa + 1];
-            const int32_t* it = rb;
+            const int e1 = m.h_lm_ptr[m.h_e_lm[a] + 1];
             for (int b = a + 1; b < e1; b++)
-            {
-                if (!free_free(b))
-                    continue;
-                const int pb = m.h_e_pose[b];
-                it = std::lower_bound(it, re, pb);
-                const int k = (int)(it - m.hsc_colind.data());
-                slot.push_back(k);
-                off_cnt[k + 1]++;
-            }
+                if (free_free(b))
+                    off_cnt[pos[m.h_e_pose[b]] + 1]++;
         }
     }
     for (int k = 0; k < B; k++)
         off_cnt[k + 1] += off_cnt[k];
-    const size_t Moff = slot.size();
+    const size_t Moff = (size_t)off_cnt[B];
     std::vector<int32_t> off_ei(Moff), off_ej(Moff);
     {
-        std::vector<int32_t> pos(off_cnt.begin(), off_cnt.end() - 1);
-        size_t t = 0;
-        for (int l = 0; l < L; l++)
+        std::vector<int32_t> fill(off_cnt.begin(), off_cnt.end() - 1);
+        for (int p = 0; p < P; p++)
         {
-            const int e0 = m.h_lm_ptr[l], e1 = m.h_lm_ptr[l + 1];
-            for (int a = e0; a < e1; a++)
+            const int r0 = m.hsc_rowptr[p], r1 = m.hsc_rowptr[p + 1];
+            for (int k = r0; k < r1; k++)
+                pos[m.hsc_colind[k]] = k;
+            for (int i = m.h_pose_ptr[p]; i < m.h_pose_ptr[p + 1]; i++)
             {
+                const int a = m.h_pose_edge[i];
                 if (!free_free(a))
                     continue;
+                const int e1 = m.h_lm_ptr[m.h_e_lm[a] + 1];
                 for (int b = a + 1; b < e1; b++)
-                {
-                    if (!free_free(b))
-                        continue;
-                    const int k = slot[t++];
-                    const int q = pos[k]++;
-                    off_ei[q] = a;
-                    off_ej[q] = b;
-                }
+                    if (free_free(b))
+                    {
+                        const int q = fill[pos[m.h_e_pose[b]]]++;
+                        off_ei[q] = a;
+                        off_ej[q] = b;
+                    }
             }
         }
     }

@@ -537,13 +537,24 @@ __global__ __launch_bounds__(BS) void k_hsc_offdiag(int nblocks,
             my_i = off_ei[base + lane];
             my_j = off_ej[base + lane];
         }
-#pragma unroll 4
-        for (int j = 0; j < n; j++)
+        // four products per round: all 24 gathers of a round are issued before the first use
+        for (int j = 0; j < n; j += 4)
         {
-            const int ei = __shfl(my_i, j, 64), ej = __shfl(my_j, j, 64);
-            const double* Tt = T + 18 * (size_t)ei;
-            const double* H = Hpl + 18 * (size_t)ej;
-            acc += Tt[r] * H[c] + Tt[6 + r] * H[6 + c] + Tt[12 + r] * H[12 + c];
+            double t[4][3], h[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+            {
+                const int jj = min(j + u, n - 1);
+                const int ei = __shfl(my_i, jj, 64), ej = __shfl(my_j, jj, 64);
+                const double* Tt = T + 18 * (size_t)ei;
+                const double* H = Hpl + 18 * (size_t)ej;
+                t[u][0] = Tt[r], t[u][1] = Tt[6 + r], t[u][2] = Tt[12 + r];
+                h[u][0] = H[c], h[u][1] = H[6 + c], h[u][2] = H[12 + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (j + u < n)
+                    acc += t[u][0] * h[u][0] + t[u][1] * h[u][1] + t[u][2] * h[u][2];
         }
     }
     if (lane < 36)

@@ -225,6 +225,10 @@ int cugo_graph_get_stats(cugo_graph* g, int32_t* iteration, double* chi2, int ca
 int cugo_graph_get_trace(cugo_graph* g, double* lambda, double* rho, int32_t* trials, int cap);
 int cugo_graph_get_poses(cugo_graph* g, int n, const int32_t* ids, double* q_t7);
 int cugo_graph_get_landmarks(cugo_graph* g, int n, const int32_t* ids, double* xyz);
+/* overwrite estimates of existing vertices (ref: Vertex::setEstimate,
+ * src/optimisable_graph.h:128); takes effect at the next cugo_graph_initialize() */
+int cugo_graph_set_poses(cugo_graph* g, int n, const int32_t* ids, const double* q_t7);
+int cugo_graph_set_landmarks(cugo_graph* g, int n, const int32_t* ids, const double* xyz);
 int cugo_graph_n_active_edges(cugo_graph* g);
 /* per-phase milliseconds accumulated since initialize(): ref getTimeProfile
  * (block_solver.cpp:470-488).  names is a '\n' separated list written into buf. */

@@ -67,7 +67,8 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
         else
             cugo_k::launch_chol_upper_stage(
                 s, dev, d_fronts.data(), t0, t1 - t0, d_wl.data(), plan.ea_ptr[st],
-                plan.ea_ptr[st + 1] - plan.ea_ptr[st], plan.trsm_ptr[st],
+                plan.ea_ptr[st + 1] - plan.ea_ptr[st], plan.eab_ptr[st],
+                plan.eab_ptr[st + 1] - plan.eab_ptr[st], plan.trsm_ptr[st],
                 plan.trsm_ptr[st + 1] - plan.trsm_ptr[st], plan.syrk_ptr[st],
                 plan.syrk_ptr[st + 1] - plan.syrk_ptr[st], lds_factor, d_fail);
     }

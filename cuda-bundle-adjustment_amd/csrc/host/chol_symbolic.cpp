@@ -675,8 +675,8 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
     P.nc_max = 6;
     for (int s = 0; s < ns; s++)
         P.nc_max = std::max(P.nc_max, 6 * P.ncb[s]);
-    P.ea_ptr.assign(1, 0), P.trsm_ptr.assign(1, 0), P.syrk_ptr.assign(1, 0);
-    std::vector<int32_t> ea, tr, sy;
+    P.ea_ptr.assign(1, 0), P.eab_ptr.assign(1, 0), P.trsm_ptr.assign(1, 0), P.syrk_ptr.assign(1, 0);
+    std::vector<int32_t> ea, eab, tr, sy;
     for (int st = 0; st < P.n_stages; st++)
     {
         const bool subtree = P.has_subtree_stage && st == 0;
@@ -688,10 +688,16 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
                 // extend-add of the boundary columns (the pivot columns are done by the potrf
                 // workgroup itself)
                 if (P.child_ptr[f + 1] > P.child_ptr[f])
+                {
+                    for (int c0 = 0; c0 < ncb; c0 += 2)
+                    {
+                        ea.push_back(f), ea.push_back(c0), ea.push_back(std::min(ncb, c0 + 2));
+                    }
                     for (int c0 = ncb; c0 < nb; c0 += 4)
                     {
-                        ea.push_back(f), ea.push_back(c0), ea.push_back(std::min(nb, c0 + 4));
+                        eab.push_back(f), eab.push_back(c0), eab.push_back(std::min(nb, c0 + 4));
                     }
+                }
                 const int nbelow = 6 * (nb - ncb) + 1; // boundary rows + rhs row
                 for (int r0 = 0; r0 < nbelow; r0 += 64)
                 {
@@ -707,18 +713,22 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
                     }
             }
         P.ea_ptr.push_back((int)ea.size() / 3);
+        P.eab_ptr.push_back((int)eab.size() / 3);
         P.trsm_ptr.push_back((int)tr.size() / 3);
         P.syrk_ptr.push_back((int)sy.size() / 3);
     }
-    // one array: [ea | trsm | syrk]; the ptr arrays index items within their own section
+    // one array: [ea | eab | trsm | syrk]; the ptr arrays index items within their own section
     P.wl.clear();
     P.wl.insert(P.wl.end(), ea.begin(), ea.end());
+    P.wl.insert(P.wl.end(), eab.begin(), eab.end());
     P.wl.insert(P.wl.end(), tr.begin(), tr.end());
     P.wl.insert(P.wl.end(), sy.begin(), sy.end());
-    for (auto& v : P.trsm_ptr)
+    for (auto& v : P.eab_ptr)
         v += (int)ea.size() / 3;
+    for (auto& v : P.trsm_ptr)
+        v += (int)(ea.size() + eab.size()) / 3;
     for (auto& v : P.syrk_ptr)
-        v += (int)(ea.size() + tr.size()) / 3;
+        v += (int)(ea.size() + eab.size() + tr.size()) / 3;
 }
 
 } // namespace cugo_host

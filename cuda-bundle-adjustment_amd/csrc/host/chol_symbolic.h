@@ -43,7 +43,9 @@ struct CholPlan
     //   trsm        : scalar rows [a, b) below the pivot block (relative to row 6*ncb)
     //   syrk        : 64x64 tile (row tile a, col tile b), a >= b
     std::vector<int32_t> wl;
-    std::vector<int32_t> ea_ptr, trsm_ptr, syrk_ptr; // [n_stages+1] item ranges per stage
+    std::vector<int32_t> ea_ptr, eab_ptr, trsm_ptr, syrk_ptr; // [n_stages+1] item ranges per stage
+    // ea = extend-add of the pivot block columns (before potrf), eab = of the boundary columns
+    // (same launch as trsm)
     int nc_max = 6; // widest pivot block in scalars (LDS sizing)
 
     std::vector<int32_t> blk_front, blk_row, blk_col; // per Hsc block

@@ -485,6 +485,15 @@ __device__ void dev_syrk_tiles(double* __restrict__ F, long ld, int ncs, int nt,
     }
 }
 
+// value of a double held by lane `src` (wave-uniform, in an SGPR): two v_readlane_b32
+__device__ __forceinline__ double readlane_f64(double v, int src)
+{
+    const int s = __builtin_amdgcn_readfirstlane(src);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), s);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), s);
+    return __hiloint2double(hi, lo);
+}
+
 // backward substitution of one front: x_J = L11^-T (y_J - L21^T x_R)
 __device__ void dev_backward(const CholPlanDev& p, const double* __restrict__ fronts, int f,
                              double* __restrict__ lds, double* __restrict__ xnew,
@@ -514,8 +523,20 @@ __device__ void dev_backward(const CholPlanDev& p, const double* __restrict__ fr
         {
             const double* col = F + (long)j * ld + ncs;
             double s = 0;
-            for (int i = l16; i < nrs; i += 16)
-                s += col[i] * xr[i];
+            for (int i = l16; i < nrs; i += 64)
+            { // four independent loads in flight per lane
+                const double a0 = col[i];
+                const double a1 = i + 16 < nrs ? col[i + 16] : 0.0;
+                const double a2 = i + 32 < nrs ? col[i + 32] : 0.0;
+                const double a3 = i + 48 < nrs ? col[i + 48] : 0.0;
+                s += a0 * xr[i];
+                if (i + 16 < nrs)
+                    s += a1 * xr[i + 16];
+                if (i + 32 < nrs)
+                    s += a2 * xr[i + 32];
+                if (i + 48 < nrs)
+                    s += a3 * xr[i + 48];
+            }
 #pragma unroll
             for (int off = 8; off > 0; off >>= 1)
                 s += __shfl_down(s, off, 16);
@@ -524,45 +545,48 @@ __device__ void dev_backward(const CholPlanDev& p, const double* __restrict__ fr
         }
     }
     __syncthreads();
-    for (int j0 = ncs - 6; j0 >= 0; j0 -= 6)
-    { // L11^T x = v, 6 unknowns at a time (upper-triangular 6x6 solve by one thread)
-        if (threadIdx.x == 0)
+    // L11^T x = v by ONE wave, wave-synchronously: lane t keeps v[t] and v[t+64] in registers,
+    // x_j is broadcast with a lane read, the row of L for the next step is prefetched from LDS
+    // (stride ncs+1 doubles: conflict-free).  No workgroup barrier inside the 6*ncb steps.
+    if (threadIdx.x < 64)
+    {
+        const int lane = threadIdx.x;
+        double v0 = lane < ncs ? vs[lane] : 0.0;
+        double v1 = lane + 64 < ncs ? vs[lane + 64] : 0.0;
+        int j = ncs - 1;
+        double l0 = lane < j ? Ls[lane * ldsl + j] : 0.0;
+        double l1 = lane + 64 < j ? Ls[(lane + 64) * ldsl + j] : 0.0;
+        double dj = dinv[j];
+        for (; j >= 0; j--)
         {
-            double l[6][6], v[6];
-#pragma unroll
-            for (int j = 0; j < 6; j++)
+            // prefetch row j-1
+            const int jn = j - 1;
+            double n0 = 0.0, n1 = 0.0, dn = 0.0;
+            if (jn >= 0)
             {
-                v[j] = vs[j0 + j];
-#pragma unroll
-                for (int k = 0; k < 6; k++)
-                    l[k][j] = (k >= j) ? Ls[(j0 + j) * ldsl + j0 + k] : 0.0; // L[row k][col j]
+                n0 = lane < jn ? Ls[lane * ldsl + jn] : 0.0;
+                n1 = lane + 64 < jn ? Ls[(lane + 64) * ldsl + jn] : 0.0;
+                dn = dinv[jn];
             }
-#pragma unroll
-            for (int j = 5; j >= 0; j--)
+            const double vj = j < 64 ? readlane_f64(v0, j) : readlane_f64(v1, j - 64);
+            const double xj = vj * dj;
+            v0 -= l0 * xj;
+            v1 -= l1 * xj;
+            if (lane == (j & 63))
             {
-                double s = v[j];
-#pragma unroll
-                for (int k = 0; k < 6; k++)
-                    if (k > j)
-                        s -= l[k][j] * v[k];
-                v[j] = s * dinv[j0 + j];
+                if (j < 64)
+                    v0 = xj;
+                else
+                    v1 = xj;
             }
-#pragma unroll
-            for (int j = 0; j < 6; j++)
-                vs[j0 + j] = v[j];
+            l0 = n0, l1 = n1, dj = dn;
         }
-        __syncthreads();
-        if ((int)threadIdx.x < j0)
-        {
-            const int t = threadIdx.x;
-            double s = 0;
-#pragma unroll
-            for (int k = 0; k < 6; k++)
-                s += Ls[t * ldsl + j0 + k] * vs[j0 + k];
-            vs[t] -= s;
-        }
-        __syncthreads();
+        if (lane < ncs)
+            vs[lane] = v0;
+        if (lane + 64 < ncs)
+            vs[lane + 64] = v1;
     }
+    __syncthreads();
     const int c0 = p.col0[f];
     for (int j = threadIdx.x; j < ncs; j += blockDim.x)
     {
@@ -624,7 +648,6 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
     extern __shared__ double lds[];
     const int f = p.task_fronts[p.task_ptr[task0 + blockIdx.x]];
     const int ncs = 6 * p.ncb[f];
-    dev_extend_add(p, fronts, f, 0, p.ncb[f]); // children -> pivot columns (all rows)
     dev_potrf(fronts + p.off[f], 6L * p.nb[f] + 1, ncs, lds, lds + ncs * (ncs + 1), fail);
 }
 
@@ -726,11 +749,14 @@ void launch_chol_subtree_stage(hipStream_t s, const CholPlanDev& p, double* d_fr
 }
 
 void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,
-                             int ntasks, const int32_t* d_wl, int ea0, int nea, int tr0, int ntr,
-                             int sy0, int nsy, size_t lds_bytes, int32_t* d_fail)
+                             int ntasks, const int32_t* d_wl, int eap0, int neap, int ea0, int nea,
+                             int tr0, int ntr, int sy0, int nsy, size_t lds_bytes, int32_t* d_fail)
 {
     if (ntasks <= 0)
         return;
+    if (neap > 0) // children -> pivot columns, one workgroup per 2 block columns
+        hipLaunchKernelGGL(k_up_extend_add, dim3(neap), dim3(CBS), 0, s, p, d_fronts,
+                           d_wl + 3L * eap0);
     ensure_lds(reinterpret_cast<const void*>(k_up_potrf), lds_bytes);
     hipLaunchKernelGGL(k_up_potrf, dim3(ntasks), dim3(BIG), lds_bytes, s, p, d_fronts, task0, d_fail);
     if (ntr + nea > 0)

@@ -80,8 +80,8 @@ void launch_chol_subtree_stage(hipStream_t s, const CholPlanDev& p, double* d_fr
                                int ntasks, size_t lds_bytes, int32_t* d_fail);
 // one etree level: extend-add / potrf / trsm / syrk kernels over the work items d_wl[...]
 void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,
-                             int ntasks, const int32_t* d_wl, int ea0, int nea, int tr0, int ntr,
-                             int sy0, int nsy, size_t lds_bytes, int32_t* d_fail);
+                             int ntasks, const int32_t* d_wl, int eap0, int neap, int ea0, int nea,
+                             int tr0, int ntr, int sy0, int nsy, size_t lds_bytes, int32_t* d_fail);
 void launch_chol_backward_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,
                                 int ntasks, size_t lds_bytes, double* d_xnew, double* d_x);
 // LDS bytes of the factor kernels (L11 + one 64-row tile) and of the backward kernel

@@ -238,11 +238,12 @@ class Graph:
         return {names[i]: dict(ms=float(ms[i]), launches=int(cnt[i])) for i in range(n)}
 
     def structure_stats(self):
-        o = np.zeros(8)
-        lib().cugo_graph_structure_stats(self._g, _p(o, _f64p))
+        o = np.zeros(16)
+        n = lib().cugo_graph_structure_stats(self._g, _p(o, _f64p), 16)
         keys = ["hsc_blocks", "products", "nnzL", "chol_flops", "supernodes", "stages", "front_bytes",
-                "offdiag_products"]
-        return dict(zip(keys, o.tolist()))
+                "offdiag_products", "up_potrf_flops", "up_trsm_flops", "up_syrk_flops", "up_ea_bytes",
+                "backward_bytes"]
+        return dict(zip(keys[:n], o[:n].tolist()))
 
 
 def graph_from_arrays(d, per_edge_information=True, per_edge_camera=True, rk=(RK_NONE, 1.0),

@@ -544,12 +544,13 @@ int cugo_memcpy_d2d(cugo_ctx* ctx, void* d, const void* s, size_t bytes)
         CUGO_HIP(hipStreamSynchronize(ctx->stream));
     });
 }
-int cugo_graph_structure_stats(cugo_graph* g, double* out8)
+int cugo_graph_structure_stats(cugo_graph* g, double* out, int cap)
 {
     const auto v = g->opt->structureStats();
-    for (int i = 0; i < 8; i++)
-        out8[i] = v[i];
-    return CUGO_OK;
+    int n = 0;
+    for (; n < (int)v.size() && n < cap; n++)
+        out[n] = v[n];
+    return n;
 }
 
 } // extern "C"

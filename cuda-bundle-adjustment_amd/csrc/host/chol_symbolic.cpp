@@ -666,6 +666,11 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
             P.stage_task_ptr.push_back((int)P.task_ptr.size() - 1);
     }
     P.n_stages = (int)P.stage_task_ptr.size() - 1;
+    for (int s = 0; s < ns; s++)
+    {
+        const double nc = 6.0 * P.ncb[s], nr = 6.0 * (P.nb[s] - P.ncb[s]);
+        P.backward_bytes += 8.0 * (nc * (nc + 1) / 2 + nc * nr + 3 * nc + nr);
+    }
     P.has_subtree_stage = false;
     for (int s = 0; s < ns; s++)
         if (lower[s])
@@ -685,6 +690,17 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
             {
                 const int f = P.task_fronts[P.task_ptr[t]];
                 const int nb = P.nb[f], ncb = P.ncb[f];
+                {
+                    const double nc = 6.0 * ncb, nr = 6.0 * (nb - ncb);
+                    P.up_potrf_flops += nc * nc * nc / 3.0;
+                    P.up_trsm_flops += nc * nc * (nr + 1);
+                    P.up_syrk_flops += 2.0 * nc * (nr * (nr + 1) / 2 + nr);
+                    for (int k = P.child_ptr[f]; k < P.child_ptr[f + 1]; k++)
+                    {
+                        const double cr = 6.0 * (P.nb[P.child[k]] - P.ncb[P.child[k]]);
+                        P.up_ea_bytes += 24.0 * (cr * (cr + 1) / 2 + cr); // read U, read+write parent
+                    }
+                }
                 // extend-add of the boundary columns (the pivot columns are done by the potrf
                 // workgroup itself)
                 if (P.child_ptr[f + 1] > P.child_ptr[f])

@@ -54,6 +54,8 @@ struct CholPlan
     long ld_max = 1;
     double nnzL = 0;  // scalars in L (incl. explicit zeros of relaxed supernodes)
     double flops = 0; // factorisation flops (2 * multiply-adds)
+    // algorithmic work of the batched upper-stage kernels (per factorisation)
+    double up_potrf_flops = 0, up_trsm_flops = 0, up_syrk_flops = 0, up_ea_bytes = 0, backward_bytes = 0;
 };
 
 // pattern: upper block CSR (columns ascending, diagonal included)

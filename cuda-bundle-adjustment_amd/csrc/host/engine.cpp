@@ -47,7 +47,7 @@ void shard_range(const std::vector<int32_t>& lm_cnt, int rank, int world, int& l
 void set_last_error(const std::string& s) { g_last_error = s; }
 const char* get_last_error() { return g_last_error.c_str(); }
 
-struct Engine::Impl
+struct Engine::Impl : cugo_k::LaunchHook
 {
     cugo_ctx ctx;
     cugo_chol chol;
@@ -123,6 +123,24 @@ struct Engine::Impl
         CUGO_HIP(hipEventRecord(e.b, ctx.stream));
         kev.push_back(e);
     }
+    // per-kernel events (LaunchHook): nested inside the group scopes above
+    std::vector<KEv> kev_open;
+    void begin(const char* kernel, hipStream_t st) override
+    {
+        KEv e;
+        e.label = klabel(kernel);
+        CUGO_HIP(hipEventCreate(&e.a));
+        CUGO_HIP(hipEventCreate(&e.b));
+        CUGO_HIP(hipEventRecord(e.a, st));
+        kev_open.push_back(e);
+    }
+    void end(const char*, hipStream_t st) override
+    {
+        KEv e = kev_open.back();
+        kev_open.pop_back();
+        CUGO_HIP(hipEventRecord(e.b, st));
+        kev.push_back(e);
+    }
     void collect_times()
     {
         if (kev.empty())
@@ -190,6 +208,8 @@ Engine::~Engine()
 {
     if (impl_)
     {
+        if (cugo_k::launch_hook() == impl_)
+            cugo_k::set_launch_hook(nullptr);
         if (impl_->ctx.stream)
         {
             (void)hipStreamSynchronize(impl_->ctx.stream);
@@ -199,7 +219,11 @@ Engine::~Engine()
     }
 }
 
-void Engine::set_kernel_timing(bool on) { impl_->ktiming = on; }
+void Engine::set_kernel_timing(bool on)
+{
+    impl_->ktiming = on;
+    cugo_k::set_launch_hook(on ? impl_ : nullptr);
+}
 
 std::vector<Engine::KernelTime> Engine::kernel_times() const
 {
@@ -502,6 +526,11 @@ void Engine::build_structure()
     sstats_.supernodes = m.chol.plan.n_super;
     sstats_.stages = m.chol.plan.n_stages;
     sstats_.front_bytes = 8.0 * (double)m.chol.plan.front_doubles;
+    sstats_.up_potrf_flops = m.chol.plan.up_potrf_flops;
+    sstats_.up_trsm_flops = m.chol.plan.up_trsm_flops;
+    sstats_.up_syrk_flops = m.chol.plan.up_syrk_flops;
+    sstats_.up_ea_bytes = m.chol.plan.up_ea_bytes;
+    sstats_.backward_bytes = m.chol.plan.backward_bytes;
     m.structure_dirty = false;
 }
 

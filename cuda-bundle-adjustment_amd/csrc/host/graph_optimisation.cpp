@@ -40,8 +40,9 @@ int CudaGraphOptimisationImpl::nActiveEdges() const { return engine_->n_active_e
 std::vector<double> CudaGraphOptimisationImpl::structureStats() const
 {
     const auto& s = engine_->structure_stats();
-    return {s.hsc_blocks, s.products, s.nnzL,        s.chol_flops,
-            s.supernodes, s.stages,   s.front_bytes, s.offdiag_products};
+    return {s.hsc_blocks,     s.products,      s.nnzL,          s.chol_flops,  s.supernodes,
+            s.stages,         s.front_bytes,   s.offdiag_products, s.up_potrf_flops,
+            s.up_trsm_flops,  s.up_syrk_flops, s.up_ea_bytes,   s.backward_bytes};
 }
 
 void CudaGraphOptimisationImpl::setKernelTiming(bool on) { engine_->set_kernel_timing(on); }

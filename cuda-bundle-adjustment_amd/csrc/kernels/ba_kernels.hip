@@ -511,8 +511,12 @@ __global__ __launch_bounds__(BS) void k_hsc_diag(EV ev, const int32_t* __restric
 }
 
 // ---------------------------------------------------------------- Schur: off-diagonal --
-// one wave per Hsc block k: Hsc[k] = - sum_{(ei,ej)} T[ei] Hpl[ej]^T, fixed list order
-// (ref: computeHschureKernel .cu:1327-1345, which uses 36 atomics per product instead)
+// one wave per Hsc block k: Hsc[k] = - sum_{(ei,ej)} T[ei] Hpl[ej]^T
+// (ref: computeHschureKernel .cu:1327-1345, which uses 36 atomics per product instead).
+// Each LANE takes whole products (lane, lane+64, ... of the block's contribution list): its
+// two 144-B operands are contiguous, so they are fetched with 16-B loads that are all in flight
+// at once, and the 6x6 result is accumulated in 36 registers.  The 64 per-lane partial blocks
+// are then summed with a fixed xor-butterfly (bit-reproducible) and stored by lanes 0..35.
 __global__ __launch_bounds__(BS) void k_hsc_offdiag(int nblocks,
                                                     const int32_t* __restrict__ off_ptr,
                                                     const int32_t* __restrict__ off_ei,
@@ -526,39 +530,42 @@ __global__ __launch_bounds__(BS) void k_hsc_offdiag(int nblocks,
     if (k >= nblocks)
         return;
     const int beg = off_ptr[k], end = off_ptr[k + 1];
-    const int r = lane % 6, c = (lane / 6) % 6; // lanes >= 36 compute a duplicate, not stored
-    double acc = 0;
-    for (int base = beg; base < end; base += 64)
+    double acc[36];
+#pragma unroll
+    for (int i = 0; i < 36; i++)
+        acc[i] = 0;
+    for (int idx = beg + lane; idx < end; idx += 64)
     {
-        const int n = min(64, end - base);
-        int my_i = 0, my_j = 0;
-        if (lane < n)
-        {
-            my_i = off_ei[base + lane];
-            my_j = off_ej[base + lane];
-        }
-        // four products per round: all 24 gathers of a round are issued before the first use
-        for (int j = 0; j < n; j += 4)
-        {
-            double t[4][3], h[4][3];
+        const int ei = off_ei[idx], ej = off_ej[idx];
+        const double2* pt = reinterpret_cast<const double2*>(T + 18 * (size_t)ei);
+        const double2* ph = reinterpret_cast<const double2*>(Hpl + 18 * (size_t)ej);
+        double t[18], h[18];
 #pragma unroll
-            for (int u = 0; u < 4; u++)
-            {
-                const int jj = min(j + u, n - 1);
-                const int ei = __shfl(my_i, jj, 64), ej = __shfl(my_j, jj, 64);
-                const double* Tt = T + 18 * (size_t)ei;
-                const double* H = Hpl + 18 * (size_t)ej;
-                t[u][0] = Tt[r], t[u][1] = Tt[6 + r], t[u][2] = Tt[12 + r];
-                h[u][0] = H[c], h[u][1] = H[6 + c], h[u][2] = H[12 + c];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++)
-                if (j + u < n)
-                    acc += t[u][0] * h[u][0] + t[u][1] * h[u][1] + t[u][2] * h[u][2];
+        for (int i = 0; i < 9; i++)
+        {
+            const double2 a = pt[i], b = ph[i];
+            t[2 * i] = a.x, t[2 * i + 1] = a.y;
+            h[2 * i] = b.x, h[2 * i + 1] = b.y;
         }
+#pragma unroll
+        for (int c = 0; c < 6; c++)
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+                acc[c * 6 + r] += t[r] * h[c] + t[6 + r] * h[6 + c] + t[12 + r] * h[12 + c];
+    }
+    double mine = 0;
+#pragma unroll
+    for (int v = 0; v < 36; v++)
+    {
+        double sum = acc[v];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+            sum += __shfl_xor(sum, off, 64);
+        if (lane == v)
+            mine = sum;
     }
     if (lane < 36)
-        Hsc[36 * (size_t)k + lane] = -acc;
+        Hsc[36 * (size_t)k + lane] = -mine;
 }
 
 // ---------------------------------------------------------------- back-substitution ----
@@ -650,6 +657,10 @@ inline int div_up(long a, int b) { return (int)((a + b - 1) / b); }
 namespace cugo_k
 {
 
+static LaunchHook* g_hook = nullptr;
+void set_launch_hook(LaunchHook* h) { g_hook = h; }
+LaunchHook* launch_hook() { return g_hook; }
+
 size_t reduce_scratch_doubles(int n_edges, int n_poses, int n_landmarks)
 {
     return (size_t)div_up(n_edges, BS) + div_up(n_poses, BS) + div_up(n_landmarks, BS) + 4096;
@@ -661,9 +672,9 @@ void launch_errors(hipStream_t s, const cugo_edges& e, const double* d_poses, co
     const EV ev = make_ev(e);
     const int nb = div_up(ev.E, BS);
     if (nb > 0)
-        hipLaunchKernelGGL(k_errors, dim3(nb), dim3(BS), 0, s, ev, d_poses, d_lms,
+        CUGO_LAUNCH(k_errors, dim3(nb), dim3(BS), 0, s, ev, d_poses, d_lms,
                            Robust2{{rk.type, rk.delta}, {rk.type_stereo, rk.delta_stereo}}, rs.d_partials);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BS), 0, s, rs.d_partials, nb, d_chi);
+    CUGO_LAUNCH(k_sum_partials, dim3(1), dim3(BS), 0, s, rs.d_partials, nb, d_chi);
 }
 
 void launch_build(hipStream_t s, const cugo_edges& e, const double* d_poses, const double* d_lms,
@@ -674,15 +685,15 @@ void launch_build(hipStream_t s, const cugo_edges& e, const double* d_poses, con
     const Robust2 r{{rk.type, rk.delta}, {rk.type_stereo, rk.delta_stereo}};
     const int nb = div_up(ev.E, BS);
     if (nb > 0)
-        hipLaunchKernelGGL(k_build_edges, dim3(nb), dim3(BS), 0, s, ev, d_poses, d_lms, r, d_Hpl,
+        CUGO_LAUNCH(k_build_edges, dim3(nb), dim3(BS), 0, s, ev, d_poses, d_lms, r, d_Hpl,
                            rs.d_partials);
     if (d_chi)
-        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BS), 0, s, rs.d_partials, nb, d_chi);
+        CUGO_LAUNCH(k_sum_partials, dim3(1), dim3(BS), 0, s, rs.d_partials, nb, d_chi);
     if (ev.L > 0)
-        hipLaunchKernelGGL(k_build_landmarks, dim3(div_up(ev.L, BS)), dim3(BS), 0, s, ev, d_poses,
+        CUGO_LAUNCH(k_build_landmarks, dim3(div_up(ev.L, BS)), dim3(BS), 0, s, ev, d_poses,
                            d_lms, r, d_Hll, d_bl);
     if (ev.P > 0)
-        hipLaunchKernelGGL(k_build_poses, dim3(ev.P), dim3(BS), (27 * BS + 32) * sizeof(double), s,
+        CUGO_LAUNCH(k_build_poses, dim3(ev.P), dim3(BS), (27 * BS + 32) * sizeof(double), s,
                            ev, d_poses, d_lms, r, d_Hpp, d_bp);
 }
 
@@ -695,8 +706,8 @@ void launch_max_diagonal(hipStream_t s, const double* d_Hpp, int nP, const doubl
         nb = 1024;
     if (nb < 1)
         nb = 1;
-    hipLaunchKernelGGL(k_max_diag, dim3(nb), dim3(BS), 0, s, d_Hpp, nP, d_Hll, nL, rs.d_partials);
-    hipLaunchKernelGGL(k_max_partials, dim3(1), dim3(BS), 0, s, rs.d_partials, nb, d_out);
+    CUGO_LAUNCH(k_max_diag, dim3(nb), dim3(BS), 0, s, d_Hpp, nP, d_Hll, nL, rs.d_partials);
+    CUGO_LAUNCH(k_max_partials, dim3(1), dim3(BS), 0, s, rs.d_partials, nb, d_out);
 }
 
 void launch_schur(hipStream_t s, const cugo_edges& e, const cugo_hsc_struct& hs, double lambda,
@@ -706,13 +717,13 @@ void launch_schur(hipStream_t s, const cugo_edges& e, const cugo_hsc_struct& hs,
 {
     const EV ev = make_ev(e);
     if (ev.E > 0)
-        hipLaunchKernelGGL(k_schur_edges, dim3(div_up(ev.E, BS)), dim3(BS), 0, s, ev, lambda, d_Hll,
+        CUGO_LAUNCH(k_schur_edges, dim3(div_up(ev.E, BS)), dim3(BS), 0, s, ev, lambda, d_Hll,
                            d_Hpl, d_invHll, d_T);
     if (hs.n_blocks > 0)
-        hipLaunchKernelGGL(k_hsc_offdiag, dim3(div_up(hs.n_blocks, BS / 64)), dim3(BS), 0, s,
+        CUGO_LAUNCH(k_hsc_offdiag, dim3(div_up(hs.n_blocks, BS / 64)), dim3(BS), 0, s,
                            hs.n_blocks, hs.d_off_ptr, hs.d_off_ei, hs.d_off_ej, d_Hpl, d_T, d_Hsc);
     if (ev.P > 0)
-        hipLaunchKernelGGL(k_hsc_diag, dim3(ev.P), dim3(BS), (27 * BS + 32) * sizeof(double), s, ev,
+        CUGO_LAUNCH(k_hsc_diag, dim3(ev.P), dim3(BS), (27 * BS + 32) * sizeof(double), s, ev,
                            hs.d_rowptr, damp_hsc_diag ? lambda : 0.0, d_Hpp, d_bp, d_bl, d_Hpl, d_T,
                            d_Hsc, d_bsc);
 }
@@ -726,12 +737,12 @@ void launch_backsubst_update(hipStream_t s, const cugo_edges& e, double lambda, 
     const EV ev = make_ev(e);
     const int nbl = div_up(ev.L, BS), nbp = div_up(ev.P, BS);
     if (nbl > 0)
-        hipLaunchKernelGGL(k_backsubst_landmarks, dim3(nbl), dim3(BS), 0, s, ev, lambda, d_invHll,
+        CUGO_LAUNCH(k_backsubst_landmarks, dim3(nbl), dim3(BS), 0, s, ev, lambda, d_invHll,
                            d_bl, d_Hpl, d_xp, d_xl, d_lms_in, d_lms_out, rs.d_partials);
     if (nbp > 0)
-        hipLaunchKernelGGL(k_update_poses, dim3(nbp), dim3(BS), 0, s, ev.P, lambda_pose, d_xp, d_bp,
+        CUGO_LAUNCH(k_update_poses, dim3(nbp), dim3(BS), 0, s, ev.P, lambda_pose, d_xp, d_bp,
                            d_poses_in, d_poses_out, rs.d_partials + nbl);
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BS), 0, s, rs.d_partials, nbl + nbp, d_scale);
+    CUGO_LAUNCH(k_sum_partials, dim3(1), dim3(BS), 0, s, rs.d_partials, nbl + nbp, d_scale);
 }
 
 } // namespace cugo_k

@@ -731,10 +731,10 @@ void launch_chol_assemble(hipStream_t s, const CholPlanDev& p, double* d_fronts,
     (void)hipMemsetAsync(d_fronts, 0, front_doubles * sizeof(double), s);
     const long n = 36L * p.n_hsc_blocks;
     if (n > 0)
-        hipLaunchKernelGGL(k_assemble_blocks, dim3((unsigned)((n + CBS - 1) / CBS)), dim3(CBS), 0, s,
+        CUGO_LAUNCH(k_assemble_blocks, dim3((unsigned)((n + CBS - 1) / CBS)), dim3(CBS), 0, s,
                            p, d_fronts, d_Hsc, lambda);
     if (p.n > 0)
-        hipLaunchKernelGGL(k_assemble_rhs, dim3((6 * p.n + CBS - 1) / CBS), dim3(CBS), 0, s, p,
+        CUGO_LAUNCH(k_assemble_rhs, dim3((6 * p.n + CBS - 1) / CBS), dim3(CBS), 0, s, p,
                            d_fronts, d_bsc);
 }
 
@@ -744,7 +744,7 @@ void launch_chol_subtree_stage(hipStream_t s, const CholPlanDev& p, double* d_fr
     if (ntasks <= 0)
         return;
     ensure_lds(reinterpret_cast<const void*>(k_subtree_factor), lds_bytes);
-    hipLaunchKernelGGL(k_subtree_factor, dim3(ntasks), dim3(BIG), lds_bytes, s, p, d_fronts, task0,
+    CUGO_LAUNCH(k_subtree_factor, dim3(ntasks), dim3(BIG), lds_bytes, s, p, d_fronts, task0,
                        d_fail);
 }
 
@@ -755,19 +755,19 @@ void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fron
     if (ntasks <= 0)
         return;
     if (neap > 0) // children -> pivot columns, one workgroup per 2 block columns
-        hipLaunchKernelGGL(k_up_extend_add, dim3(neap), dim3(CBS), 0, s, p, d_fronts,
+        CUGO_LAUNCH(k_up_extend_add, dim3(neap), dim3(CBS), 0, s, p, d_fronts,
                            d_wl + 3L * eap0);
     ensure_lds(reinterpret_cast<const void*>(k_up_potrf), lds_bytes);
-    hipLaunchKernelGGL(k_up_potrf, dim3(ntasks), dim3(BIG), lds_bytes, s, p, d_fronts, task0, d_fail);
+    CUGO_LAUNCH(k_up_potrf, dim3(ntasks), dim3(BIG), lds_bytes, s, p, d_fronts, task0, d_fail);
     if (ntr + nea > 0)
     {
         ensure_lds(reinterpret_cast<const void*>(k_up_trsm), lds_bytes);
-        hipLaunchKernelGGL(k_up_trsm, dim3(ntr + nea), dim3(BIG), lds_bytes, s, p, d_fronts,
+        CUGO_LAUNCH(k_up_trsm, dim3(ntr + nea), dim3(BIG), lds_bytes, s, p, d_fronts,
                            d_wl + 3L * tr0, ntr, d_wl + 3L * ea0);
     }
     if (nsy > 0)
     {
-        hipLaunchKernelGGL(k_up_syrk, dim3(nsy), dim3(CBS), TEAM_LDS * sizeof(double), s, p, d_fronts,
+        CUGO_LAUNCH(k_up_syrk, dim3(nsy), dim3(CBS), TEAM_LDS * sizeof(double), s, p, d_fronts,
                            d_wl + 3L * sy0);
     }
 }
@@ -778,7 +778,7 @@ void launch_chol_backward_stage(hipStream_t s, const CholPlanDev& p, double* d_f
     if (ntasks <= 0)
         return;
     ensure_lds(reinterpret_cast<const void*>(k_backward_stage), lds_bytes);
-    hipLaunchKernelGGL(k_backward_stage, dim3(ntasks), dim3(BIG), lds_bytes, s, p, d_fronts, task0,
+    CUGO_LAUNCH(k_backward_stage, dim3(ntasks), dim3(BIG), lds_bytes, s, p, d_fronts, task0,
                        d_xnew, d_x);
 }
 

@@ -9,6 +9,40 @@
 namespace cugo_k
 {
 
+// Optional per-kernel timing hook: when installed, every kernel launch of the library is
+// bracketed by begin(name)/end(name) (the engine records HIP events on the launch stream).
+struct LaunchHook
+{
+    virtual void begin(const char* kernel, hipStream_t s) = 0;
+    virtual void end(const char* kernel, hipStream_t s) = 0;
+    virtual ~LaunchHook() {}
+};
+void set_launch_hook(LaunchHook* h); // nullptr = off (default)
+LaunchHook* launch_hook();
+struct LaunchScope
+{
+    const char* name;
+    hipStream_t s;
+    LaunchHook* h;
+    LaunchScope(const char* n, hipStream_t st) : name(n), s(st), h(launch_hook())
+    {
+        if (h)
+            h->begin(name, s);
+    }
+    ~LaunchScope()
+    {
+        if (h)
+            h->end(name, s);
+    }
+};
+// launch + per-kernel timing scope
+#define CUGO_LAUNCH(kernel, grid, block, lds, stream, ...)                          \
+    do                                                                              \
+    {                                                                               \
+        ::cugo_k::LaunchScope _scope(#kernel, stream);                              \
+        hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);          \
+    } while (0)
+
 // scratch for deterministic two-stage reductions: partial sums per workgroup
 struct ReduceScratch
 {

@@ -124,7 +124,8 @@ public:
     void setShard(int rank, int world, ExchangeFn fn, void* user);
     const std::vector<LmTrace>& lmTrace() const { return trace_; }
     int nActiveEdges() const;
-    /** B, M, nnz(L), flops, supernodes, stages, front bytes, off-diagonal products */
+    /** B, M, nnz(L), flops, supernodes, stages, front bytes, off-diagonal products, then per
+     *  factorisation: potrf / trsm / syrk flops, extend-add bytes, backward bytes */
     std::vector<double> structureStats() const;
     /** HIP-event timing of kernel groups on the solver's stream (diagnostic; adds overhead) */
     void setKernelTiming(bool on);

@@ -241,9 +241,11 @@ int cugo_graph_kernel_times(cugo_graph* g, char* names_buf, int buf_len, double*
                             int32_t* launches, int cap);
 /* device-to-device copy on the context stream (used by exchange callbacks) */
 int cugo_memcpy_d2d(cugo_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
-/* solver statistics of the last buildStructure: B (Hsc blocks), M (block products),
- * nnz(L), Cholesky flops, stages */
-int cugo_graph_structure_stats(cugo_graph* g, double* out8);
+/* solver statistics of the last buildStructure, in this order: B (Hsc blocks), M (block
+ * products), nnz(L), Cholesky flops, supernodes, stages, front bytes, off-diagonal products,
+ * then the algorithmic work of the batched Cholesky kernels per factorisation: potrf flops,
+ * trsm flops, syrk flops, extend-add bytes, backward bytes.  Returns the count written. */
+int cugo_graph_structure_stats(cugo_graph* g, double* out, int cap);
 
 /* seeded ORB-SLAM-style synthetic graph built directly into a graph.
  * Returns arrays through the getters above; also usable to feed the CPU oracle. */

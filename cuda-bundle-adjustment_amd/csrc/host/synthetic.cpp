@@ -294,8 +294,14 @@ extern "C" int cugo_synth_generate(const cugo_synth_params* prm, double* poses, 
             n = -n;
         for (int a = 0; a < 4; a++)
             o[a] = r[a] / n;
+        // T' = [dR | dt] * T: the translation is rotated too, i.e. the camera turns about its own
+        // centre (rotating only R would swing the camera about the world origin — metres of
+        // error on a kilometre-long trajectory)
+        Mat3 dR;
+        quat_to_R(dq, dR);
         for (int a = 0; a < 3; a++)
-            o[4 + a] = g[4 + a] + prm->pose_trans_noise * rng.normal();
+            o[4 + a] = dR.m[a][0] * g[4] + dR.m[a][1] * g[5] + dR.m[a][2] * g[6] +
+                       prm->pose_trans_noise * rng.normal();
     }
     for (int l = 0; l < L; l++)
     {

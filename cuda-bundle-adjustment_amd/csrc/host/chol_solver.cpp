@@ -3,6 +3,8 @@
 // (src/cholesky.hpp:170-309): initialize(pattern) once, solve(A, b, x)->bool per LM trial.
 #include "chol_solver.h"
 
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 using namespace cugo_host;
@@ -56,6 +58,14 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
                              int32_t* d_fail)
 {
     hipStream_t s = ctx->stream;
+    static const bool dbg = std::getenv("CUGO_DEBUG_STAMPS") != nullptr;
+    static long long* d_stamps = nullptr;
+    if (dbg && !d_stamps)
+    {
+        CUGO_HIP(hipMalloc(reinterpret_cast<void**>(&d_stamps), 64 * sizeof(long long)));
+        CUGO_HIP(hipMemset(d_stamps, 0, 64 * sizeof(long long)));
+        cugo_k::set_debug_stamps(d_stamps);
+    }
     CUGO_HIP(hipMemsetAsync(d_fail, 0, sizeof(int32_t), s));
     cugo_k::launch_chol_assemble(s, dev, d_fronts.data(), (size_t)plan.front_doubles, d_Hsc, lambda,
                                  d_bsc);
@@ -79,4 +89,20 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
                                            d_xnew.data(), d_x);
     }
     CUGO_HIP(hipGetLastError());
+    if (dbg)
+    {
+        long long h[64];
+        CUGO_HIP(hipStreamSynchronize(s));
+        CUGO_HIP(hipMemcpy(h, d_stamps, sizeof h, hipMemcpyDeviceToHost));
+        static int calls = 0;
+        if (++calls == 5)
+            for (int k = 0; k < 2; k++)
+            {
+                std::printf("stamps kernel %d (nc=%lld):", k, h[k * 8 + 6]);
+                for (int i = 1; i < 8; i++)
+                    if (i != 6 && h[k * 8 + i])
+                        std::printf(" [%d] +%lld", i, h[k * 8 + i] - h[k * 8]);
+                std::printf("  (cycles since kernel start; last launch of the kernel)\n");
+            }
+    }
 }

@@ -76,6 +76,16 @@ __global__ __launch_bounds__(CBS) void k_assemble_rhs(CholPlanDev p, double* __r
     fronts[p.off[f] + lc * ld + (ld - 1)] = bsc[6L * p.perm[jb] + comp];
 }
 
+// Diagnostic phase stamps (CUGO_DEBUG_STAMPS=1): workgroup 0 of a kernel stores s_memtime at a
+// few points into a side buffer that no other code reads.  Null pointer (default) = no-op.
+__device__ long long* g_stamps = nullptr;
+__device__ __forceinline__ void stamp(int kernel, int slot)
+{
+    if (g_stamps && blockIdx.x == 0 && threadIdx.x == 0)
+        g_stamps[kernel * 8 + slot] = clock64();
+}
+
+
 // ---------------------------------------------------------------- device building blocks
 // Every building block is written for the latency regime these fronts live in (a few hundred
 // rows, one or a handful of workgroups): no integer division in inner loops, independent
@@ -153,6 +163,15 @@ __device__ void dev_extend_add(const CholPlanDev& p, double* __restrict__ fronts
     }
 }
 
+// value of a double held by lane `src` (wave-uniform, in an SGPR): two v_readlane_b32
+__device__ __forceinline__ double readlane_f64(double v, int src)
+{
+    const int s = __builtin_amdgcn_readfirstlane(src);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), s);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), s);
+    return __hiloint2double(hi, lo);
+}
+
 // 1/sqrt(d) and sqrt(d) without the IEEE division / sqrt sequences (each ~150-250 cycles of
 // dependent fp64 work on the critical path): v_rsq_f64 seed + two Newton steps, then one
 // correction of the root.  Result within ~1 ulp.
@@ -221,155 +240,315 @@ __device__ __forceinline__ bool chol6_lds(double* __restrict__ Ls, int lds, int 
     return bad;
 }
 
-// lower triangle of F11 -> LDS (upper part zero); 32 lanes walk a column
+__device__ __forceinline__ int pad16(int nc) { return (nc + 15) & ~15; }
+
+// lower triangle of F11 -> LDS (upper part zero), padded to a multiple of 16 with an identity
+// block (the MFMA trsm works on 16-column blocks); leading dimension pad16(nc)+1.
 __device__ void dev_load_l11(const double* __restrict__ F, long ld, int nc, double* __restrict__ Ls)
 {
-    const int lds = nc + 1;
+    const int ncp = pad16(nc), lds = ncp + 1;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, nty = blockDim.x >> 5;
-    for (int c = ty; c < nc; c += nty)
-        for (int r = tx; r < nc; r += 32)
-            Ls[c * lds + r] = (r >= c) ? F[(long)c * ld + r] : 0.0;
+    // all global loads of a thread are issued before the first LDS store (3 rows x up to 4
+    // columns in flight): a dependent-load chain costs ~900 cycles per link otherwise
+    for (int c0 = ty; c0 < ncp; c0 += 4 * nty)
+    {
+        double v[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int q = 0; q < 3; q++)
+            {
+                const int c = c0 + u * nty, r = tx + 32 * q;
+                v[u][q] = (r == c) ? 1.0 : 0.0;
+                if (c < nc && r < nc)
+                    v[u][q] = (r >= c) ? F[(long)c * ld + r] : 0.0;
+            }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int q = 0; q < 3; q++)
+            {
+                const int c = c0 + u * nty, r = tx + 32 * q;
+                if (c < ncp && r < ncp)
+                    Ls[c * lds + r] = v[u][q];
+            }
+    }
 }
 
 // dinv[j] = 1 / L11[j][j] from an LDS copy of L11 (one division per thread, in parallel)
 __device__ void dev_recip_diag(const double* __restrict__ Ls, int nc, double* __restrict__ dinv)
 {
     for (int j = threadIdx.x; j < nc; j += blockDim.x)
-        dinv[j] = 1.0 / Ls[j * (nc + 1) + j];
+        dinv[j] = 1.0 / Ls[j * (pad16(nc) + 1) + j];
 }
 
-// L11 = chol(F11) in LDS (Ls: nc x nc, leading dimension nc+1), blocked by 6 columns.
-// On return Ls holds L11 (lower) and F11 in global memory is overwritten with it.
+// Factor the 6-column panel starting at (j0,j0) of the LDS matrix Ls by ONE wave, in registers:
+// lane t owns rows j0+t and j0+64+t of the panel (nc <= 96 < 128), the 6x6 diagonal block and
+// the rows below are processed together, column by column, with the pivot row broadcast by
+// lane reads (no LDS traffic, no barrier inside).  Also writes dinv[j0..j0+5].
+__device__ __forceinline__ bool panel_factor_wave(double* __restrict__ Ls, int lds, int nc, int j0,
+                                                  double* __restrict__ dinv)
+{
+    const int lane = threadIdx.x & 63;
+    const int r0 = j0 + lane, r1 = j0 + 64 + lane;
+    double x0[6], x1[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++)
+    {
+        x0[c] = r0 < nc ? Ls[(j0 + c) * lds + r0] : 0.0;
+        x1[c] = r1 < nc ? Ls[(j0 + c) * lds + r1] : 0.0;
+    }
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < 6; c++)
+    {
+        double d = readlane_f64(x0[c], c); // pivot (already updated by columns < c)
+        if (!(d > PIVOT_TOL))
+        {
+            bad = true;
+            d = 1.0; // keep finite numbers flowing; the LM step is rejected anyway
+        }
+        // chain: sqrt (~104 cycles) and 1/d (~80) run side by side, then one multiply
+        const double sq = sqrt(d);
+        const double inv = sq * (1.0 / d);
+        if (lane == 0)
+            dinv[j0 + c] = inv;
+        // scale column c (rows below the pivot); the pivot row gets sqrt(d)
+        x0[c] = lane == c ? sq : (lane > c ? x0[c] * inv : x0[c]);
+        x1[c] = x1[c] * inv;
+#pragma unroll
+        for (int c2 = 0; c2 < 6; c2++)
+            if (c2 > c)
+            {
+                const double l = readlane_f64(x0[c], c2); // L[j0+c2][j0+c]
+                if (lane >= c2)
+                    x0[c2] -= x0[c] * l;
+                x1[c2] -= x1[c] * l;
+            }
+    }
+#pragma unroll
+    for (int c = 0; c < 6; c++)
+    {
+        if (r0 < nc && lane >= c)
+            Ls[(j0 + c) * lds + r0] = x0[c];
+        if (r1 < nc)
+            Ls[(j0 + c) * lds + r1] = x1[c];
+    }
+    return bad;
+}
+
+// columns [c_lo, c_hi) of the LDS matrix -= (panel at j0)(panel at j0)^T, lower part only;
+// executed by the threads with tid0 <= threadIdx.x (32 lanes walk the rows of a column).
+// The 6-term dot product is split in two chains: a dependent fp64 FMA costs ~40 cycles.
+__device__ __forceinline__ void panel_update_cols(double* __restrict__ Ls, int lds, int nc, int j0,
+                                                  int c_lo, int c_hi, int tid0)
+{
+    const int t = (int)threadIdx.x - tid0;
+    if (t < 0)
+        return;
+    const int tx = t & 31, ty = t >> 5, nty = ((int)blockDim.x - tid0) >> 5;
+    for (int c = c_lo + ty; c < c_hi; c += nty)
+    {
+        double pc[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+            pc[k] = Ls[(j0 + k) * lds + c];
+        for (int r = c + tx; r < nc; r += 32)
+        {
+            const double s0 = Ls[(j0 + 0) * lds + r] * pc[0] + Ls[(j0 + 1) * lds + r] * pc[1] +
+                              Ls[(j0 + 2) * lds + r] * pc[2];
+            const double s1 = Ls[(j0 + 3) * lds + r] * pc[3] + Ls[(j0 + 4) * lds + r] * pc[4] +
+                              Ls[(j0 + 5) * lds + r] * pc[5];
+            Ls[c * lds + r] -= s0 + s1;
+        }
+    }
+}
+
+// the 6 columns right after panel j0 (the next panel), one matrix element per thread:
+// column = tid >> 7, row = j0 + 6 + (tid & 127)   (needs blockDim >= 768, nc <= 128)
+__device__ __forceinline__ void panel_update_next(double* __restrict__ Ls, int lds, int nc, int j0)
+{
+    const int cc = threadIdx.x >> 7, rr = threadIdx.x & 127;
+    const int c = j0 + 6 + cc, r = j0 + 6 + rr;
+    if (cc < 6 && c < nc && r < nc && r >= c)
+    {
+        const double s0 = Ls[(j0 + 0) * lds + r] * Ls[(j0 + 0) * lds + c] +
+                          Ls[(j0 + 1) * lds + r] * Ls[(j0 + 1) * lds + c] +
+                          Ls[(j0 + 2) * lds + r] * Ls[(j0 + 2) * lds + c];
+        const double s1 = Ls[(j0 + 3) * lds + r] * Ls[(j0 + 3) * lds + c] +
+                          Ls[(j0 + 4) * lds + r] * Ls[(j0 + 4) * lds + c] +
+                          Ls[(j0 + 5) * lds + r] * Ls[(j0 + 5) * lds + c];
+        Ls[c * lds + r] -= s0 + s1;
+    }
+}
+
+// L11 = chol(F11) in LDS (Ls: nc x nc, leading dimension nc+1), 6-column panels with
+// LOOK-AHEAD: once panel p is factored, all threads first update only the 6 columns of panel
+// p+1; then wave 0 factors panel p+1 in registers while the other waves apply panel p to the
+// remaining columns.  Two barriers per panel, and the sequential part (panel factorisation)
+// overlaps the parallel part (trailing update).
+// On return Ls holds L11 (lower), dinv the reciprocal diagonal, F11 is overwritten.
 __device__ void dev_potrf(double* __restrict__ F, long ld, int nc, double* __restrict__ Ls,
                           double* __restrict__ dinv, int32_t* __restrict__ fail)
 {
-    const int lds = nc + 1;
+    const int lds = pad16(nc) + 1;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, nty = blockDim.x >> 5;
     dev_load_l11(F, ld, nc, Ls);
     __syncthreads();
+    stamp(0, 2);
+    if (threadIdx.x < 64)
+        if (panel_factor_wave(Ls, lds, nc, 0, dinv))
+            *fail = 1;
+    __syncthreads();
+    stamp(0, 3);
     for (int j0 = 0; j0 < nc; j0 += 6)
     {
-        if (threadIdx.x == 0)
+        const int jn = j0 + 6;
+        if (jn >= nc)
+            break;
+        if (blockDim.x >= 768)
+            panel_update_next(Ls, lds, nc, j0); // next panel's columns, one element per thread
+        else
+            panel_update_cols(Ls, lds, nc, j0, jn, min(jn + 6, nc), 0);
+        __syncthreads();
+        if (threadIdx.x < 64)
         {
-            if (chol6_lds(Ls, lds, j0, dinv))
+            if (panel_factor_wave(Ls, lds, nc, jn, dinv))
                 *fail = 1;
         }
-        __syncthreads();
-        const int m = nc - (j0 + 6); // rows below the diagonal block inside F11
-        if ((int)threadIdx.x < m)
-        { // panel rows: x L_D^T = a
-            const int row = j0 + 6 + threadIdx.x;
-            double x[6], a[6], dl[6][6], di[6];
-#pragma unroll
-            for (int c = 0; c < 6; c++)
-            {
-                a[c] = Ls[(j0 + c) * lds + row];
-                di[c] = dinv[j0 + c];
-#pragma unroll
-                for (int k = 0; k < 6; k++)
-                    dl[k][c] = (k < c) ? Ls[(j0 + k) * lds + j0 + c] : 0.0;
-            }
-#pragma unroll
-            for (int c = 0; c < 6; c++)
-            {
-                double s = a[c];
-#pragma unroll
-                for (int k = 0; k < 6; k++)
-                    if (k < c)
-                        s -= x[k] * dl[k][c];
-                x[c] = s * di[c];
-            }
-#pragma unroll
-            for (int c = 0; c < 6; c++)
-                Ls[(j0 + c) * lds + row] = x[c];
-        }
-        __syncthreads();
-        for (int c = j0 + 6 + ty; c < nc; c += nty)
-        { // trailing update inside F11 (lower part): 32 lanes walk the rows of column c
-            double pc[6];
-#pragma unroll
-            for (int k = 0; k < 6; k++)
-                pc[k] = Ls[(j0 + k) * lds + c];
-            for (int r = c + tx; r < nc; r += 32)
-            {
-                double s = 0;
-#pragma unroll
-                for (int k = 0; k < 6; k++)
-                    s += Ls[(j0 + k) * lds + r] * pc[k];
-                Ls[c * lds + r] -= s;
-            }
-        }
+        else
+            panel_update_cols(Ls, lds, nc, j0, jn + 6, nc, 64); // the rest, meanwhile
         __syncthreads();
     }
+    stamp(0, 4);
     for (int c = ty; c < nc; c += nty)
         for (int r = c + tx; r < nc; r += 32)
             F[(long)c * ld + r] = Ls[c * lds + r];
 }
 
-// rows [row0, row0+nrows) (absolute scalar rows, nrows <= TR) of F21: X L11^T = B.
-// Ls holds L11; Bt is a TR x (nc+1) LDS tile.  LPR adjacent lanes share one row, so a row
-// never leaves its wave: LDS operations of one wave execute in order and a wave-level fence
-// is all the synchronisation the column loop needs.  LPR = blockDim / 64 (4 or 16).
+// V_J = inverse of the J-th 16x16 diagonal block of L11 (lower triangular), one 16-lane group
+// per block, lane c builds column c by forward substitution with the block of L broadcast from
+// LDS (fully unrolled: the v's stay in registers).  Vs[J][n*17 + k] = V_J[n][k].
+__device__ void dev_inv_diag16(const double* __restrict__ Ls, int ncp, double* __restrict__ Vs)
+{
+    const int lds = ncp + 1;
+    const int grp = threadIdx.x >> 4, c = threadIdx.x & 15;
+    if (grp >= (ncp >> 4))
+        return;
+    const int J = 16 * grp;
+    // right-looking forward substitution: once v[k] is known every later row is updated at
+    // once (independent FMAs), so the dependent chain is 16 x (mul + fma), not 120 FMAs
+    double v[16], sacc[16], di[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+    {
+        di[i] = 1.0 / Ls[(J + i) * lds + J + i]; // independent divisions, off the chain
+        sacc[i] = (i == c) ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+    {
+        v[k] = sacc[k] * di[k];
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            if (i > k)
+                sacc[i] -= Ls[(J + k) * lds + J + i] * v[k];
+    }
+    double* V = Vs + grp * (16 * 17);
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+        V[i * 17 + c] = (i >= c) ? v[i] : 0.0;
+}
+
+// rows [row0, row0+nrows) (absolute scalar rows, nrows <= 64) of F21: X L11^T = B on the f64
+// matrix cores, 16-column blocks:  X_J = B_J V_J^T,  B_J' -= X_J L[J',J]^T  (J' > J).
+// Ls: padded L11 (ld ncp+1), Vs: inverted diagonal blocks, Bt: 64 x (ncp+1) tile in LDS.
+// Wave w works on row group w&3 (16 rows) and on the column blocks J' = J+1+(w>>2), +4, ...
+// X passes through LDS because the MFMA result layout (row = (l>>4)+4q, col = l&15) is not the
+// A-operand layout (row = l&15, k = l>>4).
 __device__ void dev_trsm_tile(double* __restrict__ F, long ld, int nc, long row0, int nrows,
-                              const double* __restrict__ Ls, const double* __restrict__ dinv,
+                              const double* __restrict__ Ls, const double* __restrict__ Vs,
                               double* __restrict__ Bt)
 {
-    const int lds = nc + 1;
+    const int ncp = pad16(nc), lds = ncp + 1, nblk = ncp >> 4;
     {
         const int tr = threadIdx.x & 63, tc = threadIdx.x >> 6, ntc = blockDim.x >> 6;
-        if (tr < nrows)
-            for (int c = tc; c < nc; c += ntc)
-                Bt[tr * lds + c] = F[(long)c * ld + row0 + tr];
-    }
-    __syncthreads();
-    const int lpr = blockDim.x >> 6;                    // lanes per row
-    const int shift = lpr == 16 ? 4 : 2;
-    const int r = threadIdx.x >> shift, g = threadIdx.x & (lpr - 1);
-    if (r < nrows)
-    {
-        double* row = Bt + r * lds;
-        for (int j0 = 0; j0 < nc; j0 += 6)
-        {
-            // every lane of the row solves the 6x6 system redundantly (same inputs, same result)
-            double x[6], a[6], dl[6][6], di[6];
+        for (int c0 = tc; c0 < ncp; c0 += 6 * ntc)
+        { // up to 6 independent loads in flight per thread
+            double v[6];
 #pragma unroll
-            for (int c = 0; c < 6; c++)
+            for (int u = 0; u < 6; u++)
             {
-                a[c] = row[j0 + c];
-                di[c] = dinv[j0 + c];
-#pragma unroll
-                for (int k = 0; k < 6; k++)
-                    dl[k][c] = (k < c) ? Ls[(j0 + k) * lds + j0 + c] : 0.0;
+                const int c = c0 + u * ntc;
+                v[u] = (tr < nrows && c < nc) ? F[(long)c * ld + row0 + tr] : 0.0;
             }
 #pragma unroll
-            for (int c = 0; c < 6; c++)
+            for (int u = 0; u < 6; u++)
             {
-                double s = a[c];
-#pragma unroll
-                for (int k = 0; k < 6; k++)
-                    if (k < c)
-                        s -= x[k] * dl[k][c];
-                x[c] = s * di[c];
+                const int c = c0 + u * ntc;
+                if (c < ncp)
+                    Bt[tr * lds + c] = v[u];
             }
-            wave_lds_sync(); // all lanes of the row have read the old values
-            if (g == 0)
-            {
-#pragma unroll
-                for (int c = 0; c < 6; c++)
-                    row[j0 + c] = x[c];
-            }
-            for (int c = j0 + 6 + g; c < nc; c += lpr)
-            {
-                double s = 0;
-#pragma unroll
-                for (int k = 0; k < 6; k++)
-                    s += x[k] * Ls[(j0 + k) * lds + c];
-                row[c] -= s;
-            }
-            wave_lds_sync(); // updates visible to the row's other lanes
         }
     }
     __syncthreads();
+    stamp(1, 3);
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ln = lane & 15, lk = lane >> 4;
+    const int nw = blockDim.x >> 6;          // 4 or 16 waves
+    const int rg = w & 3, cs = w >> 2, ncs_ = nw >> 2; // row group, column subset, #subsets
+    double* Brow = Bt + (16 * rg) * lds;
+    for (int p = 0; p < nblk; p++)
+    {
+        const int J = 16 * p;
+        if (cs == 0)
+        { // X = B_J V_J^T
+            const double* V = Vs + p * (16 * 17);
+            double4_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+            double a[4], b[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++)
+            {
+                const int k = 4 * ks + lk;
+                a[ks] = Brow[ln * lds + J + k];
+                b[ks] = V[ln * 17 + k]; // V^T[k][n] = V[n][k]
+            }
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b[2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b[3], acc1, 0, 0, 0);
+            wave_lds_sync(); // every lane has read B_J before it is overwritten
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                Brow[(lk + 4 * q) * lds + J + ln] = acc0[q] + acc1[q];
+        }
+        __syncthreads();
+        for (int pb = p + 1 + cs; pb < nblk; pb += ncs_)
+        { // B_J' -= X L[J',J]^T
+            const int Jp = 16 * pb;
+            double4_t acc0, acc1 = {0, 0, 0, 0};
+            double a[4], b[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                acc0[q] = Brow[(lk + 4 * q) * lds + Jp + ln];
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++)
+            {
+                const int k = 4 * ks + lk;
+                a[ks] = -Brow[ln * lds + J + k];
+                b[ks] = Ls[(J + k) * lds + Jp + ln]; // L[J'+n][J+k]
+            }
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b[2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b[3], acc1, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                Brow[(lk + 4 * q) * lds + Jp + ln] = acc0[q] + acc1[q];
+        }
+        __syncthreads();
+    }
+    stamp(1, 4);
     {
         const int tr = threadIdx.x & 63, tc = threadIdx.x >> 6, ntc = blockDim.x >> 6;
         if (tr < nrows)
@@ -485,15 +664,6 @@ __device__ void dev_syrk_tiles(double* __restrict__ F, long ld, int ncs, int nt,
     }
 }
 
-// value of a double held by lane `src` (wave-uniform, in an SGPR): two v_readlane_b32
-__device__ __forceinline__ double readlane_f64(double v, int src)
-{
-    const int s = __builtin_amdgcn_readfirstlane(src);
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), s);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), s);
-    return __hiloint2double(hi, lo);
-}
-
 // backward substitution of one front: x_J = L11^-T (y_J - L21^T x_R)
 __device__ void dev_backward(const CholPlanDev& p, const double* __restrict__ fronts, int f,
                              double* __restrict__ lds, double* __restrict__ xnew,
@@ -503,9 +673,9 @@ __device__ void dev_backward(const CholPlanDev& p, const double* __restrict__ fr
     const long ld = 6L * nb + 1;
     const int ncs = 6 * ncb, nrs = 6 * (nb - ncb);
     const double* F = fronts + p.off[f];
-    const int ldsl = ncs + 1;
-    double* Ls = lds;                  // ncs*(ncs+1)
-    double* vs = lds + ncs * ldsl;     // ncs
+    const int ldsl = pad16(ncs) + 1;
+    double* Ls = lds;                  // padded L11
+    double* vs = lds + pad16(ncs) * ldsl; // ncs
     double* dinv = vs + ncs;           // ncs
     double* xr = dinv + ncs;           // nrs
     const int32_t* rows = p.rows + p.rows_ptr[f];
@@ -614,14 +784,18 @@ __global__ __launch_bounds__(BIG) void k_subtree_factor(CholPlanDev p, double* _
         const long ld = 6L * nb + 1;
         const int ncs = 6 * ncb, nrs = 6 * (nb - ncb), nt = nrs + 1;
         double* F = fronts + p.off[f];
+        const int ncp = pad16(ncs);
         double* Ls = lds;
-        double* dinv = lds + ncs * (ncs + 1);
-        double* Bt = dinv + ncs;
+        double* dinv = lds + ncp * (ncp + 1);
+        double* Vs = dinv + ncp;
+        double* Bt = Vs + (ncp >> 4) * (16 * 17);
         dev_extend_add(p, fronts, f, 0, nb);
         dev_potrf(F, ld, ncs, Ls, dinv, fail);
         __syncthreads();
+        dev_inv_diag16(Ls, ncp, Vs);
+        __syncthreads();
         for (int r0 = 0; r0 < nt; r0 += TR)
-            dev_trsm_tile(F, ld, ncs, ncs + r0, min(TR, nt - r0), Ls, dinv, Bt);
+            dev_trsm_tile(F, ld, ncs, ncs + r0, min(TR, nt - r0), Ls, Vs, Bt);
         __threadfence_block();
         __syncthreads();
         const int nti = (nt + 63) / 64, ntj = (nrs + 63) / 64;
@@ -646,9 +820,15 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
                                                   int task0, int32_t* __restrict__ fail)
 {
     extern __shared__ double lds[];
+    stamp(0, 0);
     const int f = p.task_fronts[p.task_ptr[task0 + blockIdx.x]];
     const int ncs = 6 * p.ncb[f];
-    dev_potrf(fronts + p.off[f], 6L * p.nb[f] + 1, ncs, lds, lds + ncs * (ncs + 1), fail);
+    const int ncp = pad16(ncs);
+    stamp(0, 1);
+    dev_potrf(fronts + p.off[f], 6L * p.nb[f] + 1, ncs, lds, lds + ncp * (ncp + 1), fail);
+    stamp(0, 7);
+    if (g_stamps && blockIdx.x == 0 && threadIdx.x == 0)
+        g_stamps[0 * 8 + 6] = ncs;
 }
 
 // trsm tiles (touch the pivot columns) and, in the same launch, the extend-add of the
@@ -669,14 +849,21 @@ __global__ __launch_bounds__(BIG) void k_up_trsm(CholPlanDev p, double* __restri
     const int ncs = 6 * p.ncb[f];
     const long ld = 6L * p.nb[f] + 1;
     double* F = fronts + p.off[f];
+    const int ncp = pad16(ncs);
     double* Ls = lds;
-    double* dinv = lds + ncs * (ncs + 1);
-    double* Bt = dinv + ncs;
+    double* Vs = lds + ncp * (ncp + 1);
+    double* Bt = Vs + (ncp >> 4) * (16 * 17);
+    stamp(1, 0);
     dev_load_l11(F, ld, ncs, Ls);
     __syncthreads();
-    dev_recip_diag(Ls, ncs, dinv);
+    stamp(1, 1);
+    dev_inv_diag16(Ls, ncp, Vs);
     __syncthreads();
-    dev_trsm_tile(F, ld, ncs, ncs + it[1], it[2] - it[1], Ls, dinv, Bt);
+    stamp(1, 2);
+    dev_trsm_tile(F, ld, ncs, ncs + it[1], it[2] - it[1], Ls, Vs, Bt);
+    stamp(1, 7);
+    if (g_stamps && blockIdx.x == 0 && threadIdx.x == 0)
+        g_stamps[1 * 8 + 6] = ncs;
 }
 
 // one workgroup (one team) per 64x64 tile; it[1] = linear tile index
@@ -715,13 +902,20 @@ namespace cugo_k
 
 size_t chol_lds_factor_bytes(int nc_max)
 {
-    const size_t trsm = (size_t)nc_max * (nc_max + 2) + (size_t)TR * (nc_max + 1);
+    const size_t ncp = (size_t)((nc_max + 15) & ~15);
+    const size_t trsm = ncp * (ncp + 2) + (ncp >> 4) * (16 * 17) + (size_t)TR * (ncp + 1);
     const size_t syrk = 4 * (size_t)TEAM_LDS; // four teams in the 1024-thread subtree kernel
     return (std::max(trsm, syrk) + 8) * sizeof(double);
 }
 size_t chol_lds_backward_bytes(int nc_max, long ld_max)
 {
-    return (size_t)(nc_max * (nc_max + 1) + 2 * nc_max + ld_max + 8) * sizeof(double);
+    const size_t ncp = (size_t)((nc_max + 15) & ~15);
+    return (ncp * (ncp + 1) + 2 * ncp + (size_t)ld_max + 8) * sizeof(double);
+}
+
+void set_debug_stamps(long long* d_buf)
+{
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &d_buf, sizeof(d_buf));
 }
 
 void launch_chol_assemble(hipStream_t s, const CholPlanDev& p, double* d_fronts,

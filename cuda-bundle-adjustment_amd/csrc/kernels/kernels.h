@@ -119,6 +119,7 @@ void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fron
 void launch_chol_backward_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,
                                 int ntasks, size_t lds_bytes, double* d_xnew, double* d_x);
 // LDS bytes of the factor kernels (L11 + one 64-row tile) and of the backward kernel
+void set_debug_stamps(long long* d_buf); // diagnostic s_memtime stamps (nullptr = off)
 size_t chol_lds_factor_bytes(int nc_max);
 size_t chol_lds_backward_bytes(int nc_max, long ld_max);
 

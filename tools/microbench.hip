@@ -1,0 +1,85 @@
+// micro-benchmarks that calibrate the latency model used for the Cholesky kernels
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+__global__ void k_empty(int* p) { if (p && threadIdx.x == 9999) p[0] = 1; }
+__global__ void k_lds(int* p) { extern __shared__ double lds[]; if (threadIdx.x == 0) lds[0] = 1; __syncthreads(); if (p && lds[0] == 2) p[0] = 1; }
+// dependent pointer chase by one lane
+__global__ void k_chase(const int* next, int n, int* out, long long* cyc)
+{
+    int i = 0;
+    long long t0 = clock64();
+    for (int k = 0; k < n; k++) i = next[i];
+    long long t1 = clock64();
+    out[0] = i; cyc[0] = t1 - t0;
+}
+// N barriers
+__global__ void k_barriers(int n, long long* cyc) { long long t0 = clock64(); for (int i = 0; i < n; i++) __syncthreads(); if (threadIdx.x == 0) cyc[0] = clock64() - t0; }
+// dependent LDS chain
+__global__ void k_ldschain(int n, long long* cyc, int* out) { __shared__ int a[1024]; for (int i = threadIdx.x; i < 1024; i += blockDim.x) a[i] = (i * 7 + 1) & 1023; __syncthreads(); int i = threadIdx.x; long long t0 = clock64(); for (int k = 0; k < n; k++) i = a[i]; long long t1 = clock64(); if (threadIdx.x == 0) { cyc[0] = t1 - t0; out[0] = i; } }
+// dependent fp64 fma chain
+__global__ void k_fmachain(int n, long long* cyc, double* out) { double x = threadIdx.x * 1e-3, y = 1.0000001; long long t0 = clock64(); for (int k = 0; k < n; k++) x = fma(x, y, 1e-9); long long t1 = clock64(); if (threadIdx.x == 0) cyc[0] = t1 - t0; out[threadIdx.x] = x; }
+__global__ void k_sqrtchain(int n, long long* cyc, double* out) { double x = 2.0 + threadIdx.x; long long t0 = clock64(); for (int k = 0; k < n; k++) x = sqrt(x) + 1.5; long long t1 = clock64(); if (threadIdx.x == 0) cyc[0] = t1 - t0; out[threadIdx.x] = x; }
+__global__ void k_divchain(int n, long long* cyc, double* out) { double x = 2.0 + threadIdx.x; long long t0 = clock64(); for (int k = 0; k < n; k++) x = 3.0 / x + 1.5; long long t1 = clock64(); if (threadIdx.x == 0) cyc[0] = t1 - t0; out[threadIdx.x] = x; }
+
+int main()
+{
+    hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    int* d; CK(hipMalloc(&d, 1 << 20));
+    long long* dc; CK(hipMalloc(&dc, 64)); double* dd; CK(hipMalloc(&dd, 8192));
+    float ms;
+    for (int rep = 0; rep < 2; rep++) {
+        CK(hipEventRecord(a, s));
+        for (int i = 0; i < 1000; i++) hipLaunchKernelGGL(k_empty, dim3(1), dim3(256), 0, s, d);
+        CK(hipEventRecord(b, s)); CK(hipEventSynchronize(b)); CK(hipEventElapsedTime(&ms, a, b));
+        printf("1000 empty kernels (1x256): %.2f us each\n", ms);
+    }
+    CK(hipFuncSetAttribute((const void*)k_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 140000));
+    CK(hipEventRecord(a, s));
+    for (int i = 0; i < 1000; i++) hipLaunchKernelGGL(k_lds, dim3(8), dim3(1024), 130000, s, d);
+    CK(hipEventRecord(b, s)); CK(hipEventSynchronize(b)); CK(hipEventElapsedTime(&ms, a, b));
+    printf("1000 kernels 8x1024 thr, 130 KB LDS: %.2f us each\n", ms);
+    CK(hipEventRecord(a, s));
+    for (int i = 0; i < 1000; i++) hipLaunchKernelGGL(k_lds, dim3(200), dim3(1024), 130000, s, d);
+    CK(hipEventRecord(b, s)); CK(hipEventSynchronize(b)); CK(hipEventElapsedTime(&ms, a, b));
+    printf("1000 kernels 200x1024 thr, 130 KB LDS: %.2f us each\n", ms);
+    // pointer chase over a 256 MB buffer (stride ~ 1 MB + 64 B => every hop a new page / line)
+    const size_t N = 64 << 20; int* big; CK(hipMalloc(&big, N * 4));
+    std::vector<int> h(N, 0);
+    size_t idx = 0; const int hops = 2000; const size_t stride = (1 << 18) + 16;
+    for (int k = 0; k < hops; k++) { size_t nx = (idx + stride) % N; h[idx] = (int)nx; idx = nx; }
+    CK(hipMemcpy(big, h.data(), N * 4, hipMemcpyHostToDevice));
+    long long cyc;
+    for (int rep = 0; rep < 2; rep++) {
+        hipLaunchKernelGGL(k_chase, dim3(1), dim3(1), 0, s, big, hops, d, dc); CK(hipStreamSynchronize(s));
+        CK(hipMemcpy(&cyc, dc, 8, hipMemcpyDeviceToHost)); printf("global pointer chase (1 MB stride, rep %d): %.0f cycles/hop (clock64 = 100 MHz ticks? see fma)\n", rep, (double)cyc / hops);
+    }
+    // small-stride chase (L2 hits)
+    for (size_t i = 0; i < 4096; i++) h[i] = (int)((i * 67 + 1) % 4096);
+    CK(hipMemcpy(big, h.data(), 4096 * 4, hipMemcpyHostToDevice));
+    for (int rep = 0; rep < 2; rep++) {
+        hipLaunchKernelGGL(k_chase, dim3(1), dim3(1), 0, s, big, 4000, d, dc); CK(hipStreamSynchronize(s));
+        CK(hipMemcpy(&cyc, dc, 8, hipMemcpyDeviceToHost)); printf("global pointer chase (16 KB footprint, rep %d): %.0f ticks/hop\n", rep, (double)cyc / 4000);
+    }
+    for (int thr : {64, 256, 1024}) {
+        hipLaunchKernelGGL(k_barriers, dim3(1), dim3(thr), 0, s, 1000, dc); CK(hipStreamSynchronize(s));
+        CK(hipMemcpy(&cyc, dc, 8, hipMemcpyDeviceToHost)); printf("__syncthreads with %d threads: %.1f ticks each\n", thr, (double)cyc / 1000);
+    }
+    hipLaunchKernelGGL(k_ldschain, dim3(1), dim3(64), 0, s, 1000, dc, d); CK(hipStreamSynchronize(s));
+    CK(hipMemcpy(&cyc, dc, 8, hipMemcpyDeviceToHost)); printf("dependent LDS read: %.1f ticks\n", (double)cyc / 1000);
+    hipLaunchKernelGGL(k_fmachain, dim3(1), dim3(64), 0, s, 10000, dc, dd); CK(hipStreamSynchronize(s));
+    CK(hipMemcpy(&cyc, dc, 8, hipMemcpyDeviceToHost)); printf("dependent fp64 fma: %.2f ticks\n", (double)cyc / 10000);
+    hipLaunchKernelGGL(k_sqrtchain, dim3(1), dim3(64), 0, s, 2000, dc, dd); CK(hipStreamSynchronize(s));
+    CK(hipMemcpy(&cyc, dc, 8, hipMemcpyDeviceToHost)); printf("dependent fp64 sqrt+add: %.1f ticks\n", (double)cyc / 2000);
+    hipLaunchKernelGGL(k_divchain, dim3(1), dim3(64), 0, s, 2000, dc, dd); CK(hipStreamSynchronize(s));
+    CK(hipMemcpy(&cyc, dc, 8, hipMemcpyDeviceToHost)); printf("dependent fp64 div+add: %.1f ticks\n", (double)cyc / 2000);
+    // wall time of the fma kernel to convert ticks -> ns
+    CK(hipEventRecord(a, s));
+    hipLaunchKernelGGL(k_fmachain, dim3(1), dim3(64), 0, s, 2000000, dc, dd);
+    CK(hipEventRecord(b, s)); CK(hipEventSynchronize(b)); CK(hipEventElapsedTime(&ms, a, b));
+    CK(hipMemcpy(&cyc, dc, 8, hipMemcpyDeviceToHost)); printf("2M fma chain: %.3f ms wall, %lld ticks => %.3f ticks/ns ; %.2f ns per dependent fma\n", ms, cyc, cyc / (ms * 1e6), ms * 1e6 / 2e6);
+    return 0;
+}

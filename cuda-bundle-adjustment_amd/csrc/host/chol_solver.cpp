@@ -96,7 +96,7 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
         CUGO_HIP(hipMemcpy(h, d_stamps, sizeof h, hipMemcpyDeviceToHost));
         static int calls = 0;
         if (++calls == 5)
-            for (int k = 0; k < 2; k++)
+            for (int k = 0; k < 3; k++)
             {
                 std::printf("stamps kernel %d (nc=%lld):", k, h[k * 8 + 6]);
                 for (int i = 1; i < 8; i++)

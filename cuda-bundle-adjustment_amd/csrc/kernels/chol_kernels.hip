@@ -282,58 +282,91 @@ __device__ void dev_recip_diag(const double* __restrict__ Ls, int nc, double* __
         dinv[j] = 1.0 / Ls[j * (pad16(nc) + 1) + j];
 }
 
-// Factor the 6-column panel starting at (j0,j0) of the LDS matrix Ls by ONE wave, in registers:
-// lane t owns rows j0+t and j0+64+t of the panel (nc <= 96 < 128), the 6x6 diagonal block and
-// the rows below are processed together, column by column, with the pivot row broadcast by
-// lane reads (no LDS traffic, no barrier inside).  Also writes dinv[j0..j0+5].
+// Factor the 6-column panel starting at (j0,j0) of the LDS matrix Ls by ONE wave, in registers.
+// Every lane holds the 6x6 diagonal block (broadcast LDS reads) and factors it REDUNDANTLY —
+// uniform values, no cross-lane traffic on the critical path — while applying each finished
+// column to its own rows below the block (lane t: rows j0+6+t and j0+70+t; nc <= 96).
+// Right-looking inside the panel, so every value is touched by one FMA per column: the
+// dependent chain is 6 x (sqrt || 1/d, mul, mul, fma) ~ 6 x 220 cycles.  Writes dinv[j0..j0+5].
 __device__ __forceinline__ bool panel_factor_wave(double* __restrict__ Ls, int lds, int nc, int j0,
                                                   double* __restrict__ dinv)
 {
     const int lane = threadIdx.x & 63;
-    const int r0 = j0 + lane, r1 = j0 + 64 + lane;
-    double x0[6], x1[6];
+    const int r0 = j0 + 6 + lane, r1 = j0 + 70 + lane;
+    if (j0 == 0)
+        stamp(2, 0);
+    double D[6][6], a0[6], a1[6];
 #pragma unroll
     for (int c = 0; c < 6; c++)
     {
-        x0[c] = r0 < nc ? Ls[(j0 + c) * lds + r0] : 0.0;
-        x1[c] = r1 < nc ? Ls[(j0 + c) * lds + r1] : 0.0;
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+            D[r][c] = (r >= c) ? Ls[(j0 + c) * lds + j0 + r] : 0.0;
+        a0[c] = r0 < nc ? Ls[(j0 + c) * lds + r0] : 0.0;
+        a1[c] = r1 < nc ? Ls[(j0 + c) * lds + r1] : 0.0;
     }
     bool bad = false;
-#pragma unroll
-    for (int c = 0; c < 6; c++)
+    double iv[6];
+    if (j0 == 0)
     {
-        double d = readlane_f64(x0[c], c); // pivot (already updated by columns < c)
+        // make the loads complete before the stamp: consume one value
+        asm volatile("" ::"v"(D[5][5]), "v"(a1[5]));
+        stamp(2, 1);
+    }
+#pragma unroll
+    for (int j = 0; j < 6; j++)
+    {
+        double d = D[j][j];
         if (!(d > PIVOT_TOL))
         {
             bad = true;
             d = 1.0; // keep finite numbers flowing; the LM step is rejected anyway
         }
-        // chain: sqrt (~104 cycles) and 1/d (~80) run side by side, then one multiply
         const double sq = sqrt(d);
-        const double inv = sq * (1.0 / d);
-        if (lane == 0)
-            dinv[j0 + c] = inv;
-        // scale column c (rows below the pivot); the pivot row gets sqrt(d)
-        x0[c] = lane == c ? sq : (lane > c ? x0[c] * inv : x0[c]);
-        x1[c] = x1[c] * inv;
+        const double inv = sq * (1.0 / d); // sqrt and reciprocal run side by side
+        iv[j] = inv;
+        D[j][j] = sq;
 #pragma unroll
-        for (int c2 = 0; c2 < 6; c2++)
-            if (c2 > c)
+        for (int i = 0; i < 6; i++)
+            if (i > j)
+                D[i][j] *= inv;
+        a0[j] *= inv;
+        a1[j] *= inv;
+#pragma unroll
+        for (int c = 0; c < 6; c++)
+            if (c > j)
             {
-                const double l = readlane_f64(x0[c], c2); // L[j0+c2][j0+c]
-                if (lane >= c2)
-                    x0[c2] -= x0[c] * l;
-                x1[c2] -= x1[c] * l;
+#pragma unroll
+                for (int i = 0; i < 6; i++)
+                    if (i >= c)
+                        D[i][c] -= D[i][j] * D[c][j];
+                a0[c] -= a0[j] * D[c][j];
+                a1[c] -= a1[j] * D[c][j];
             }
+    }
+    if (j0 == 0)
+    {
+        asm volatile("" ::"v"(D[5][5]), "v"(a1[5]), "v"(a0[5]));
+        stamp(2, 2);
     }
 #pragma unroll
     for (int c = 0; c < 6; c++)
     {
-        if (r0 < nc && lane >= c)
-            Ls[(j0 + c) * lds + r0] = x0[c];
+        if (lane == 0)
+        {
+            dinv[j0 + c] = iv[c];
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+                if (r >= c)
+                    Ls[(j0 + c) * lds + j0 + r] = D[r][c];
+        }
+        if (r0 < nc)
+            Ls[(j0 + c) * lds + r0] = a0[c];
         if (r1 < nc)
-            Ls[(j0 + c) * lds + r1] = x1[c];
+            Ls[(j0 + c) * lds + r1] = a1[c];
     }
+    if (j0 == 0)
+        stamp(2, 3);
     return bad;
 }
 

@@ -224,10 +224,20 @@ def main():
     rated = {k: v for k, v in kernels.items() if "achieved" in v}
     dominant = max(rated, key=lambda k: rated[k]["total_ms"]) if rated else None
     roofline = None
+    pmc = {}
+    try:  # HBM traffic per launch from the committed PMC passes (separate rocprofv3 --pmc runs)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+    except Exception:
+        pmc = {}
+    for k, v in kernels.items():
+        if k in pmc and args.workload == "kitti00" and world == 1:
+            v["traffic"] = pmc[k]["hbm_bytes_per_launch_fetch_x2"]
     if dominant:
         d = rated[dominant]
         roofline = {"kernel": dominant, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
-                    "unit": d["unit"], "frac": d["frac"], "traffic": None,
+                    "unit": d["unit"], "frac": d["frac"], "traffic": d.get("traffic"),
+                    "traffic_source": "profiles/r01_pmc_traffic.json (HBM bytes per launch, FETCH_SIZE x2 + "
+                                      "WRITE_SIZE, separate PMC passes)" if d.get("traffic") else None,
                     "avg_launch_ms": d["avg_ms"], "launches": d["launches"],
                     "note": "fp64 MFMA peak == fp64 vector peak (78.6 TF) on MI355X; the multifrontal "
                             "Cholesky kernels are latency/critical-path bound (DESIGN.md section 5)"}

@@ -271,3 +271,54 @@ def graph_from_arrays(d, per_edge_information=True, per_edge_camera=True, rk=(RK
                     cam[sel] if per_edge_camera else None)
         g.set_robust_kernel(dim, rk[0], rk[1])
     return g
+
+
+# ---- reference graph-file format (ref: samples/sample_ba_from_file/main.cpp:89-160) ---------
+def save_ba_json(path, d, pose_ids=None, lm_ids=None):
+    """write a flat-array problem in the JSON layout of the reference's ba_kitti_*.json"""
+    import json
+    P, L = len(d["pose"]), len(d["lm"])
+    pid = np.arange(P) if pose_ids is None else np.asarray(pose_ids)
+    lid = np.arange(L) if lm_ids is None else np.asarray(lm_ids)
+    cam = np.asarray(d["e_cam"], np.float64).reshape(-1, 5)[0]
+    out = {"fx": cam[0], "fy": cam[1], "cx": cam[2], "cy": cam[3], "bf": cam[4],
+           "pose_vertices": [{"id": int(pid[i]), "fixed": int(d["pose_fixed"][i]),
+                              "q": [float(x) for x in d["pose"][i][:4]],
+                              "t": [float(x) for x in d["pose"][i][4:]]} for i in range(P)],
+           "landmark_vertices": [{"id": int(lid[i]), "fixed": int(d["lm_fixed"][i]),
+                                  "Xw": [float(x) for x in d["lm"][i]]} for i in range(L)],
+           "monocular_edges": [], "stereo_edges": []}
+    for e in range(len(d["e_pose"])):
+        st = bool(d["e_stereo"][e])
+        out["stereo_edges" if st else "monocular_edges"].append(
+            {"vertexP": int(pid[d["e_pose"][e]]), "vertexL": int(lid[d["e_lm"][e]]),
+             "measurement": [float(x) for x in d["e_meas"][e][:3 if st else 2]],
+             "information": float(d["e_omega"][e])})
+    with open(path, "w") as f:
+        json.dump(out, f)
+
+
+def load_ba_json(path):
+    """read ba_kitti_*.json (reference sample format) into the flat-array dict + id arrays"""
+    import json
+    j = json.load(open(path))
+    pv, lv = j["pose_vertices"], j["landmark_vertices"]
+    pose_ids = np.array([v["id"] for v in pv], np.int32)
+    lm_ids = np.array([v["id"] for v in lv], np.int32)
+    ppos = {int(i): k for k, i in enumerate(pose_ids)}
+    lpos = {int(i): k for k, i in enumerate(lm_ids)}
+    cam = np.array([j["fx"], j["fy"], j["cx"], j["cy"], j["bf"]], np.float64)
+    ep, el, st, meas, om = [], [], [], [], []
+    for key, stereo in (("monocular_edges", 0), ("stereo_edges", 1)):
+        for e in j.get(key, []):
+            ep.append(ppos[e["vertexP"]]); el.append(lpos[e["vertexL"]]); st.append(stereo)
+            m = list(e["measurement"]) + [0.0] * (3 - len(e["measurement"]))
+            meas.append(m); om.append(e["information"])
+    d = dict(pose=np.array([v["q"] + v["t"] for v in pv], np.float64).reshape(-1, 7),
+             pose_fixed=np.array([v["fixed"] for v in pv], np.uint8),
+             lm=np.array([v["Xw"] for v in lv], np.float64).reshape(-1, 3),
+             lm_fixed=np.array([v["fixed"] for v in lv], np.uint8),
+             e_pose=np.array(ep, np.int32), e_lm=np.array(el, np.int32), e_stereo=np.array(st, np.uint8),
+             e_meas=np.array(meas, np.float64).reshape(-1, 3), e_omega=np.array(om, np.float64),
+             e_cam=np.tile(cam, (len(ep), 1)))
+    return d, pose_ids, lm_ids

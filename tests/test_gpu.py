@@ -370,3 +370,35 @@ def test_sharded_two_ranks_on_one_gpu_matches_single(oracle_lib):
         assert_trajectories_match(results[r]["stats"], single["stats"], 1e-11)
         np.testing.assert_allclose(results[r]["pose"], single["pose"], rtol=0, atol=1e-10)
         np.testing.assert_allclose(results[r]["lm"], single["lm"], rtol=0, atol=1e-9)
+
+
+def test_cpp_sample_reads_reference_json_format(oracle_lib, tmp_path):
+    """the C++ sample (mirrored public API, reference sample protocol) on a file in the
+    reference's ba_kitti_*.json layout gives the chi2 sequence of the flat-array path and of
+    the oracle (warm-up optimize(1), then initialize()+optimize(10) on the updated estimates)"""
+    import os
+    import re
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "samples", "build", "sample_ba_from_file")
+    if not os.path.exists(exe):
+        pytest.fail("samples/build/sample_ba_from_file missing: run __graft_entry__.build()")
+    d, prob = synth_problem(oracle_lib, 60, 900, 3700, seed=17, lc=0)
+    pose_ids = np.arange(60) * 2 + 5
+    lm_ids = np.arange(900) + 1000
+    path = str(tmp_path / "graph.json")
+    cugo.save_ba_json(path, d, pose_ids, lm_ids)
+    d2, pid2, lid2 = cugo.load_ba_json(path)
+    assert np.array_equal(pid2, pose_ids) and np.array_equal(lid2, lm_ids)
+    out = subprocess.run([exe, path, "10"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    chi = [float(m.group(1)) for m in re.finditer(r"iter:\s*\d+, chi2: ([0-9.eE+-]+)", out.stdout)]
+    assert len(chi) == 10
+    prob.optimize(1)
+    ref = prob.optimize(10)
+    for a, b in zip(chi, ref):
+        assert abs(a - b["chi2"]) <= 0.06  # the sample prints with %.1f
+    g = cugo.graph_from_arrays(d2, pose_ids=pid2, lm_ids=lid2)
+    g.initialize(); g.optimize(1); g.initialize(); g.optimize(10)
+    assert_trajectories_match(g.stats(), ref, 1e-10)
+    g.close()

@@ -23,6 +23,7 @@ void cugo_chol::upload(hipStream_t s)
     d_wl.upload(P.wl, s);
     d_fronts.resize((size_t)P.front_doubles + 16);
     d_xnew.resize((size_t)6 * P.n + 16);
+    d_junk.resize(64 * 1024);
     CUGO_HIP(hipStreamSynchronize(s)); // host vectors may be reused after return
 
     cugo_k::CholPlanDev& D = dev;
@@ -37,6 +38,7 @@ void cugo_chol::upload(hipStream_t s)
     D.blk_front = d_blk_front.data(), D.blk_row = d_blk_row.data();
     D.blk_col = d_blk_col.data(), D.blk_trans = d_blk_trans.data();
     D.n = P.n, D.perm = d_perm.data(), D.col_front = d_col_front.data();
+    D.junk = d_junk.data();
     lds_factor = cugo_k::chol_lds_factor_bytes(P.nc_max);
     lds_backward = cugo_k::chol_lds_backward_bytes(P.nc_max, P.ld_max);
 }
@@ -96,7 +98,7 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
         CUGO_HIP(hipMemcpy(h, d_stamps, sizeof h, hipMemcpyDeviceToHost));
         static int calls = 0;
         if (++calls == 5)
-            for (int k = 0; k < 3; k++)
+            for (int k = 0; k < 6; k++)
             {
                 std::printf("stamps kernel %d (nc=%lld):", k, h[k * 8 + 6]);
                 for (int i = 1; i < 8; i++)

@@ -18,7 +18,7 @@ struct cugo_chol
         d_col_front, d_wl;
     cugo_host::DevBuf<int64_t> d_off;
     cugo_host::DevBuf<uint8_t> d_blk_trans;
-    cugo_host::DevBuf<double> d_fronts, d_xnew;
+    cugo_host::DevBuf<double> d_fronts, d_xnew, d_junk;
 
     void analyze(int n, const int32_t* rowptr, const int32_t* colind);
     void upload(hipStream_t s);

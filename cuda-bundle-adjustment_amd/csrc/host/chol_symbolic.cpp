@@ -701,17 +701,19 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
                         P.up_ea_bytes += 24.0 * (cr * (cr + 1) / 2 + cr); // read U, read+write parent
                     }
                 }
-                // extend-add of the boundary columns (the pivot columns are done by the potrf
-                // workgroup itself)
+                // extend-add work items: a workgroup has 16 waves and a unit is one 64-row chunk
+                // of one block column, so an item takes as many block columns as fill 16 waves
                 if (P.child_ptr[f + 1] > P.child_ptr[f])
                 {
-                    for (int c0 = 0; c0 < ncb; c0 += 2)
+                    const int chunks = (6 * nb + 1 + 63) / 64;
+                    const int cols = std::max(1, std::min(8, 16 / chunks));
+                    for (int c0 = 0; c0 < ncb; c0 += cols)
                     {
-                        ea.push_back(f), ea.push_back(c0), ea.push_back(std::min(ncb, c0 + 2));
+                        ea.push_back(f), ea.push_back(c0), ea.push_back(std::min(ncb, c0 + cols));
                     }
-                    for (int c0 = ncb; c0 < nb; c0 += 4)
+                    for (int c0 = ncb; c0 < nb; c0 += cols)
                     {
-                        eab.push_back(f), eab.push_back(c0), eab.push_back(std::min(nb, c0 + 4));
+                        eab.push_back(f), eab.push_back(c0), eab.push_back(std::min(nb, c0 + cols));
                     }
                 }
                 const int nbelow = 6 * (nb - ncb) + 1; // boundary rows + rhs row

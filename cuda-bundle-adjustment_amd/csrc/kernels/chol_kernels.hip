@@ -76,15 +76,26 @@ __global__ __launch_bounds__(CBS) void k_assemble_rhs(CholPlanDev p, double* __r
     fronts[p.off[f] + lc * ld + (ld - 1)] = bsc[6L * p.perm[jb] + comp];
 }
 
-// Diagnostic phase stamps (CUGO_DEBUG_STAMPS=1): workgroup 0 of a kernel stores s_memtime at a
-// few points into a side buffer that no other code reads.  Null pointer (default) = no-op.
+// Diagnostic phase stamps: only in a build with -DCUGO_STAMPS (make STAMPS=1) and run with
+// CUGO_DEBUG_STAMPS=1.  Workgroup 0 of a kernel stores s_memtime at a few points into a side
+// buffer that no other code reads.  In the normal build stamp() is an empty inline function
+// (a run-time null check would cost a dependent global load per call).
+#ifdef CUGO_STAMPS
 __device__ long long* g_stamps = nullptr;
 __device__ __forceinline__ void stamp(int kernel, int slot)
 {
     if (g_stamps && blockIdx.x == 0 && threadIdx.x == 0)
         g_stamps[kernel * 8 + slot] = clock64();
 }
-
+__device__ __forceinline__ void stamp_value(int kernel, int slot, long long v)
+{
+    if (g_stamps && blockIdx.x == 0 && threadIdx.x == 0)
+        g_stamps[kernel * 8 + slot] = v;
+}
+#else
+__device__ __forceinline__ void stamp(int, int) {}
+__device__ __forceinline__ void stamp_value(int, int, long long) {}
+#endif
 
 // ---------------------------------------------------------------- device building blocks
 // Every building block is written for the latency regime these fronts live in (a few hundred
@@ -101,65 +112,95 @@ __device__ __forceinline__ void wave_lds_sync()
 // children -> parent, restricted to parent block columns [cb0, cb1); children one after the
 // other (barrier in between) so every parent entry is summed in child order.  One wave per
 // child column; each lane gathers up to 4 independent parent entries before storing them.
-__device__ void dev_extend_add(const CholPlanDev& p, double* __restrict__ fronts, int f, int cb0,
+// One 64-row chunk of one child update block column (6 scalar columns) added into the parent:
+// lane <-> row, the 6 columns are 6 independent read-modify-writes in flight per lane.
+__device__ __forceinline__ void ea_chunk(const double* __restrict__ U, long ldc, int nru, int nbr,
+                                         const int32_t* __restrict__ rel, double* __restrict__ Fp,
+                                         long ldp, int jb, int ch, int lane, double* __restrict__ sink)
+{
+    const int i = 6 * jb + 64 * ch + lane;
+    const bool ok = i < nru;
+    const int ic = ok ? i : 6 * jb;
+    const int ib = ic / 6;
+    const long pjb = 6L * rel[jb];
+    const int rr = rel[min(ib, nbr - 1)];
+    const long pi = (ic == nru - 1) ? ldp - 1 : 6L * rr + (ic - 6 * ib); // last row = rhs row
+    double* dst[6];
+    double u[6], v[6];
+#pragma unroll
+    for (int jj = 0; jj < 6; jj++)
+    { // branch-free: masked lanes (past the end / above the diagonal) use their private sink slot
+        const int j = 6 * jb + jj;
+        const bool okj = ok && ic >= j;
+        const double* src = okj ? U + (long)j * ldc + ic : sink;
+        dst[jj] = okj ? Fp + (pjb + jj) * ldp + pi : sink;
+        u[jj] = *src;
+    }
+#pragma unroll
+    for (int jj = 0; jj < 6; jj++)
+        v[jj] = *dst[jj];
+#pragma unroll
+    for (int jj = 0; jj < 6; jj++)
+        *dst[jj] = v[jj] + u[jj];
+}
+
+// Extend-add of the children of front f into its block columns [cb0, cb1).  Children are applied
+// one after the other in list order (fixed summation order => bit-reproducible); within a child
+// the (block column, 64-row chunk) units are dealt round-robin to the waves.
+constexpr int EA_BATCH = 32;
+__device__ __forceinline__ void dev_extend_add(const CholPlanDev& p, double* __restrict__ fronts, int f, int cb0,
                                int cb1)
 {
+    __shared__ int s_child[EA_BATCH][3]; // child front, first / past-last matching update block column
     const long ldp = 6L * p.nb[f] + 1;
     double* Fp = fronts + p.off[f];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
-    for (int ci = p.child_ptr[f]; ci < p.child_ptr[f + 1]; ci++)
+    double* sink = p.junk + ((blockIdx.x & 63) << 10) + threadIdx.x;
+    const int c0 = p.child_ptr[f], c1 = p.child_ptr[f + 1];
+    for (int cbase = c0; cbase < c1; cbase += EA_BATCH)
     {
-        const int c = p.child[ci];
-        const int ncb = p.ncb[c], nbr = p.nb[c] - ncb;
-        const int32_t* rel = p.rel + p.rel_ptr[c];
-        // child update block columns whose parent column falls in [cb0, cb1) (rel is ascending):
-        // counted with wave ballots, one pass of independent loads
-        int jlo = 0, jhi = 0;
-        for (int base = 0; base < nbr; base += 64)
+        const int nchild = min(EA_BATCH, c1 - cbase);
+        // child update block columns whose parent column falls in [cb0, cb1) (rel is ascending),
+        // counted with wave ballots; one wave per child so the dependent metadata loads of
+        // different children overlap
+        for (int k = wv; k < nchild; k += nwv)
         {
-            const int i = base + lane;
-            const int rv = i < nbr ? rel[i] : 0x7fffffff;
-            jlo += __popcll(__ballot(rv < cb0));
-            jhi += __popcll(__ballot(rv < cb1));
-        }
-        if (jhi > jlo)
-        {
-            const long ldc = 6L * p.nb[c] + 1;
-            const double* U = fronts + p.off[c] + (6L * ncb) * ldc + 6L * ncb; // (0,0) of update
-            const int nru = 6 * nbr + 1;
-            for (int jb = jlo; jb < jhi; jb++)
+            const int c = p.child[cbase + k];
+            const int nbr = p.nb[c] - p.ncb[c];
+            const int32_t* rel = p.rel + p.rel_ptr[c];
+            int jlo = 0, jhi = 0;
+            for (int base = 0; base < nbr; base += 64)
             {
-                const long pjb = 6L * rel[jb];
-                for (int jj = wv; jj < 6; jj += nwv)
-                {
-                    const int j = 6 * jb + jj;
-                    const double* ucol = U + (long)j * ldc;
-                    double* pcol = Fp + (pjb + jj) * ldp;
-                    for (int i0 = j + lane; i0 < nru; i0 += 256)
-                    {
-                        long pi[4];
-                        double u[4], v[4];
-#pragma unroll
-                        for (int t = 0; t < 4; t++)
-                        {
-                            const int i = i0 + 64 * t;
-                            const bool ok = i < nru;
-                            const int ib = ok ? i / 6 : 0;
-                            pi[t] = !ok ? -1 : (i == nru - 1 ? ldp - 1 : 6L * rel[ib] + (i - 6 * ib));
-                            u[t] = ok ? ucol[i] : 0.0;
-                        }
-#pragma unroll
-                        for (int t = 0; t < 4; t++)
-                            v[t] = pi[t] >= 0 ? pcol[pi[t]] : 0.0;
-#pragma unroll
-                        for (int t = 0; t < 4; t++)
-                            if (pi[t] >= 0)
-                                pcol[pi[t]] = v[t] + u[t];
-                    }
-                }
+                const int i = base + lane;
+                const int rv = rel[min(i, nbr - 1)];
+                jlo += __popcll(__ballot(i < nbr && rv < cb0));
+                jhi += __popcll(__ballot(i < nbr && rv < cb1));
             }
+            if (lane == 0)
+                s_child[k][0] = c, s_child[k][1] = jlo, s_child[k][2] = jhi;
         }
         __syncthreads();
+        for (int k = 0; k < nchild; k++)
+        {
+            const int c = s_child[k][0], jlo = s_child[k][1], jhi = s_child[k][2];
+            if (jhi <= jlo)
+                continue; // uniform over the workgroup
+            const int ncb = p.ncb[c], nbr = p.nb[c] - ncb;
+            const long ldc = 6L * p.nb[c] + 1;
+            const double* U = fronts + p.off[c] + (6L * ncb) * ldc + 6L * ncb; // (0,0) of update
+            const int32_t* rel = p.rel + p.rel_ptr[c];
+            const int nru = 6 * nbr + 1;
+            int u = wv;
+            for (int jb = jlo; jb < jhi; jb++)
+            {
+                const int nch = (nru - 6 * jb + 63) >> 6;
+                for (; u < nch; u += nwv)
+                    ea_chunk(U, ldc, nru, nbr, rel, Fp, ldp, jb, u, lane, sink);
+                u -= nch;
+            }
+            __syncthreads(); // the next child may touch the same parent entries
+        }
+        __syncthreads(); // s_child is rewritten by the next batch
     }
 }
 
@@ -244,7 +285,7 @@ __device__ __forceinline__ int pad16(int nc) { return (nc + 15) & ~15; }
 
 // lower triangle of F11 -> LDS (upper part zero), padded to a multiple of 16 with an identity
 // block (the MFMA trsm works on 16-column blocks); leading dimension pad16(nc)+1.
-__device__ void dev_load_l11(const double* __restrict__ F, long ld, int nc, double* __restrict__ Ls)
+__device__ __forceinline__ void dev_load_l11(const double* __restrict__ F, long ld, int nc, double* __restrict__ Ls)
 {
     const int ncp = pad16(nc), lds = ncp + 1;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, nty = blockDim.x >> 5;
@@ -276,7 +317,7 @@ __device__ void dev_load_l11(const double* __restrict__ F, long ld, int nc, doub
 }
 
 // dinv[j] = 1 / L11[j][j] from an LDS copy of L11 (one division per thread, in parallel)
-__device__ void dev_recip_diag(const double* __restrict__ Ls, int nc, double* __restrict__ dinv)
+__device__ __forceinline__ void dev_recip_diag(const double* __restrict__ Ls, int nc, double* __restrict__ dinv)
 {
     for (int j = threadIdx.x; j < nc; j += blockDim.x)
         dinv[j] = 1.0 / Ls[j * (pad16(nc) + 1) + j];
@@ -421,7 +462,7 @@ __device__ __forceinline__ void panel_update_next(double* __restrict__ Ls, int l
 // remaining columns.  Two barriers per panel, and the sequential part (panel factorisation)
 // overlaps the parallel part (trailing update).
 // On return Ls holds L11 (lower), dinv the reciprocal diagonal, F11 is overwritten.
-__device__ void dev_potrf(double* __restrict__ F, long ld, int nc, double* __restrict__ Ls,
+__device__ __forceinline__ void dev_potrf(double* __restrict__ F, long ld, int nc, double* __restrict__ Ls,
                           double* __restrict__ dinv, int32_t* __restrict__ fail)
 {
     const int lds = pad16(nc) + 1;
@@ -462,7 +503,7 @@ __device__ void dev_potrf(double* __restrict__ F, long ld, int nc, double* __res
 // V_J = inverse of the J-th 16x16 diagonal block of L11 (lower triangular), one 16-lane group
 // per block, lane c builds column c by forward substitution with the block of L broadcast from
 // LDS (fully unrolled: the v's stay in registers).  Vs[J][n*17 + k] = V_J[n][k].
-__device__ void dev_inv_diag16(const double* __restrict__ Ls, int ncp, double* __restrict__ Vs)
+__device__ __forceinline__ void dev_inv_diag16(const double* __restrict__ Ls, int ncp, double* __restrict__ Vs)
 {
     const int lds = ncp + 1;
     const int grp = threadIdx.x >> 4, c = threadIdx.x & 15;
@@ -499,7 +540,7 @@ __device__ void dev_inv_diag16(const double* __restrict__ Ls, int ncp, double* _
 // Wave w works on row group w&3 (16 rows) and on the column blocks J' = J+1+(w>>2), +4, ...
 // X passes through LDS because the MFMA result layout (row = (l>>4)+4q, col = l&15) is not the
 // A-operand layout (row = l&15, k = l>>4).
-__device__ void dev_trsm_tile(double* __restrict__ F, long ld, int nc, long row0, int nrows,
+__device__ __forceinline__ void dev_trsm_tile(double* __restrict__ F, long ld, int nc, long row0, int nrows,
                               const double* __restrict__ Ls, const double* __restrict__ Vs,
                               double* __restrict__ Bt)
 {
@@ -603,9 +644,11 @@ constexpr int PST = 80; // LDS panel stride (doubles) per k
 constexpr int KC = 24;  // K chunk
 constexpr int TEAM_LDS = 2 * KC * PST; // doubles per team
 
-__device__ void dev_syrk_tiles(double* __restrict__ F, long ld, int ncs, int nt, int nrs,
-                               int first_tile, int ntiles_total, int ntj, double* __restrict__ lds)
+__device__ __forceinline__ void dev_syrk_tiles(double* __restrict__ F, long ld, int ncs, int nt, int nrs,
+                               int first_tile, int ntiles_total, int ntj, double* __restrict__ lds,
+                               double* __restrict__ junk)
 {
+    double* sink = junk + ((blockIdx.x & 63) << 10) + threadIdx.x; // private slot of this lane
     // tile index -> (ti, tj): column-major over the lower triangle of tiles, nti = ceil(nt/64)
     const int nti = (nt + 63) >> 6;
     const int team = threadIdx.x >> 8, nteams = blockDim.x >> 8;
@@ -638,29 +681,42 @@ __device__ void dev_syrk_tiles(double* __restrict__ F, long ld, int ncs, int nt,
             acc[t] = double4_t{0, 0, 0, 0};
         // prefetch the U entries this lane will update (independent loads, issued first)
         double uold[4][4];
-        if (active)
-        {
 #pragma unroll
-            for (int t = 0; t < 4; t++)
+        for (int t = 0; t < 4; t++)
 #pragma unroll
-                for (int q = 0; q < 4; q++)
-                {
-                    const int i = 64 * ti + 16 * t + ln, j = 64 * tj + 16 * w + lk + 4 * q;
-                    uold[t][q] = (i < nt && j < nrs && i >= j) ? U[(long)j * ld + i] : 0.0;
-                }
-        }
+            for (int q = 0; q < 4; q++)
+            { // masked lanes read their private sink slot: no branch, 16 loads in flight
+                const int i = 64 * ti + 16 * t + ln, j = 64 * tj + 16 * w + lk + 4 * q;
+                const bool ok = active && i < nt && j < nrs && i >= j;
+                const double* src = ok ? U + ((long)j * ld + i) : sink;
+                uold[t][q] = *src;
+            }
+        stamp(4, 2);
         for (int kc = 0; kc < ncs; kc += KC)
         {
             const int kn = min(KC, ncs - kc);
             if (active)
-            {
-                const int r = tt & 63;
+            { // all 12 global loads of a thread are issued before the first LDS store
+                const int r = tt & 63, kq = tt >> 6;
                 const int gi = 64 * ti + r, gj = 64 * tj + r;
-                for (int k = tt >> 6; k < kn; k += 4)
+                double vi[KC / 4], vj[KC / 4];
+#pragma unroll
+                for (int u = 0; u < KC / 4; u++)
                 {
-                    Pi[k * PST + r] = gi < nt ? L21[(long)(kc + k) * ld + gi] : 0.0;
-                    if (!diag)
-                        Pj[k * PST + r] = gj < nt ? L21[(long)(kc + k) * ld + gj] : 0.0;
+                    const int k = kq + 4 * u;
+                    vi[u] = (k < kn && gi < nt) ? L21[(long)(kc + k) * ld + gi] : 0.0;
+                    vj[u] = (!diag && k < kn && gj < nt) ? L21[(long)(kc + k) * ld + gj] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < KC / 4; u++)
+                {
+                    const int k = kq + 4 * u;
+                    if (k < kn)
+                    {
+                        Pi[k * PST + r] = vi[u];
+                        if (!diag)
+                            Pj[k * PST + r] = vj[u];
+                    }
                 }
             }
             __syncthreads();
@@ -682,23 +738,22 @@ __device__ void dev_syrk_tiles(double* __restrict__ F, long ld, int ncs, int nt,
             }
             __syncthreads();
         }
-        if (active)
-        {
+        stamp(4, 3);
 #pragma unroll
-            for (int t = 0; t < 4; t++)
+        for (int t = 0; t < 4; t++)
 #pragma unroll
-                for (int q = 0; q < 4; q++)
-                {
-                    const int i = 64 * ti + 16 * t + ln, j = 64 * tj + 16 * w + lk + 4 * q;
-                    if (i < nt && j < nrs && i >= j)
-                        U[(long)j * ld + i] = uold[t][q] - acc[t][q];
-                }
-        }
+            for (int q = 0; q < 4; q++)
+            { // branch-free: masked lanes store into their sink slot, 16 stores back to back
+                const int i = 64 * ti + 16 * t + ln, j = 64 * tj + 16 * w + lk + 4 * q;
+                const bool ok = active && i < nt && j < nrs && i >= j;
+                double* dst = ok ? U + ((long)j * ld + i) : sink;
+                *dst = uold[t][q] - acc[t][q];
+            }
     }
 }
 
 // backward substitution of one front: x_J = L11^-T (y_J - L21^T x_R)
-__device__ void dev_backward(const CholPlanDev& p, const double* __restrict__ fronts, int f,
+__device__ __forceinline__ void dev_backward(const CholPlanDev& p, const double* __restrict__ fronts, int f,
                              double* __restrict__ lds, double* __restrict__ xnew,
                              double* __restrict__ xout)
 {
@@ -712,6 +767,7 @@ __device__ void dev_backward(const CholPlanDev& p, const double* __restrict__ fr
     double* dinv = vs + ncs;           // ncs
     double* xr = dinv + ncs;           // nrs
     const int32_t* rows = p.rows + p.rows_ptr[f];
+    stamp(3, 1);
     dev_load_l11(F, ld, ncs, Ls);
     for (int i = threadIdx.x; i < nrs; i += blockDim.x)
     {
@@ -719,6 +775,7 @@ __device__ void dev_backward(const CholPlanDev& p, const double* __restrict__ fr
         xr[i] = xnew[6L * rows[ib] + (i - 6 * ib)];
     }
     __syncthreads();
+    stamp(3, 2);
     dev_recip_diag(Ls, ncs, dinv);
     { // v_j = y_j - sum_i L21[i,j] x_R[i]: 16 lanes per column, lanes stride the rows
         const int g = threadIdx.x >> 4, l16 = threadIdx.x & 15, ng = blockDim.x >> 4;
@@ -748,6 +805,7 @@ __device__ void dev_backward(const CholPlanDev& p, const double* __restrict__ fr
         }
     }
     __syncthreads();
+    stamp(3, 3);
     // L11^T x = v by ONE wave, wave-synchronously: lane t keeps v[t] and v[t+64] in registers,
     // x_j is broadcast with a lane read, the row of L for the next step is prefetched from LDS
     // (stride ncs+1 doubles: conflict-free).  No workgroup barrier inside the 6*ncb steps.
@@ -790,6 +848,7 @@ __device__ void dev_backward(const CholPlanDev& p, const double* __restrict__ fr
             vs[lane + 64] = v1;
     }
     __syncthreads();
+    stamp(3, 4);
     const int c0 = p.col0[f];
     for (int j = threadIdx.x; j < ncs; j += blockDim.x)
     {
@@ -835,18 +894,20 @@ __global__ __launch_bounds__(BIG) void k_subtree_factor(CholPlanDev p, double* _
         int ntiles = 0;
         for (int tj = 0; tj < ntj; tj++)
             ntiles += nti - tj;
-        dev_syrk_tiles(F, ld, ncs, nt, nrs, 0, ntiles, ntj, lds);
+        dev_syrk_tiles(F, ld, ncs, nt, nrs, 0, ntiles, ntj, lds, p.junk);
         __threadfence_block();
         __syncthreads();
     }
 }
 
 // ---------------------------------------------------------------- upper stages ---------
-__global__ __launch_bounds__(CBS) void k_up_extend_add(CholPlanDev p, double* __restrict__ fronts,
+__global__ __launch_bounds__(BIG) void k_up_extend_add(CholPlanDev p, double* __restrict__ fronts,
                                                        const int32_t* __restrict__ wl)
 {
+    stamp(5, 0);
     const int32_t* it = wl + 3 * blockIdx.x;
     dev_extend_add(p, fronts, it[0], it[1], it[2]);
+    stamp(5, 7);
 }
 
 __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restrict__ fronts,
@@ -860,8 +921,7 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
     stamp(0, 1);
     dev_potrf(fronts + p.off[f], 6L * p.nb[f] + 1, ncs, lds, lds + ncp * (ncp + 1), fail);
     stamp(0, 7);
-    if (g_stamps && blockIdx.x == 0 && threadIdx.x == 0)
-        g_stamps[0 * 8 + 6] = ncs;
+    stamp_value(0, 6, ncs);
 }
 
 // trsm tiles (touch the pivot columns) and, in the same launch, the extend-add of the
@@ -895,8 +955,7 @@ __global__ __launch_bounds__(BIG) void k_up_trsm(CholPlanDev p, double* __restri
     stamp(1, 2);
     dev_trsm_tile(F, ld, ncs, ncs + it[1], it[2] - it[1], Ls, Vs, Bt);
     stamp(1, 7);
-    if (g_stamps && blockIdx.x == 0 && threadIdx.x == 0)
-        g_stamps[1 * 8 + 6] = ncs;
+    stamp_value(1, 6, ncs);
 }
 
 // one workgroup (one team) per 64x64 tile; it[1] = linear tile index
@@ -904,11 +963,14 @@ __global__ __launch_bounds__(CBS) void k_up_syrk(CholPlanDev p, double* __restri
                                                  const int32_t* __restrict__ wl)
 {
     extern __shared__ double lds[];
+    stamp(4, 0);
     const int32_t* it = wl + 3 * blockIdx.x;
     const int f = it[0];
     const int ncs = 6 * p.ncb[f], nrs = 6 * (p.nb[f] - p.ncb[f]);
+    stamp(4, 1);
     dev_syrk_tiles(fronts + p.off[f], 6L * p.nb[f] + 1, ncs, nrs + 1, nrs, it[1], it[1] + 1,
-                   (nrs + 63) / 64, lds);
+                   (nrs + 63) / 64, lds, p.junk);
+    stamp(4, 7);
 }
 
 __global__ __launch_bounds__(BIG) void k_backward_stage(CholPlanDev p,
@@ -917,9 +979,11 @@ __global__ __launch_bounds__(BIG) void k_backward_stage(CholPlanDev p,
                                                         double* __restrict__ xout)
 {
     extern __shared__ double lds[];
+    stamp(3, 0);
     const int task = task0 + blockIdx.x;
     for (int fi = p.task_ptr[task + 1] - 1; fi >= p.task_ptr[task]; fi--)
         dev_backward(p, fronts, p.task_fronts[fi], lds, xnew, xout);
+    stamp(3, 7);
 }
 
 void ensure_lds(const void* fn, size_t bytes)
@@ -948,7 +1012,11 @@ size_t chol_lds_backward_bytes(int nc_max, long ld_max)
 
 void set_debug_stamps(long long* d_buf)
 {
+#ifdef CUGO_STAMPS
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &d_buf, sizeof(d_buf));
+#else
+    (void)d_buf;
+#endif
 }
 
 void launch_chol_assemble(hipStream_t s, const CholPlanDev& p, double* d_fronts,
@@ -981,8 +1049,8 @@ void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fron
 {
     if (ntasks <= 0)
         return;
-    if (neap > 0) // children -> pivot columns, one workgroup per 2 block columns
-        CUGO_LAUNCH(k_up_extend_add, dim3(neap), dim3(CBS), 0, s, p, d_fronts,
+    if (neap > 0) // children -> pivot columns
+        CUGO_LAUNCH(k_up_extend_add, dim3(neap), dim3(BIG), 0, s, p, d_fronts,
                            d_wl + 3L * eap0);
     ensure_lds(reinterpret_cast<const void*>(k_up_potrf), lds_bytes);
     CUGO_LAUNCH(k_up_potrf, dim3(ntasks), dim3(BIG), lds_bytes, s, p, d_fronts, task0, d_fail);

@@ -106,6 +106,9 @@ struct CholPlanDev
     int n;                     // block rows of the matrix
     const int32_t* perm;       // new -> old
     const int32_t* col_front;  // new col -> front
+    // sink for masked-off lanes: lets conditional stores/loads be emitted branch-free (a branch
+    // per store makes the compiler wait vmcnt(0) before each one, serialising the stores)
+    double* junk;              // 64 x 1024 doubles
 };
 
 void launch_chol_assemble(hipStream_t s, const CholPlanDev& p, double* d_fronts, size_t front_doubles,

@@ -89,6 +89,11 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
         const int t0 = plan.stage_task_ptr[st], t1 = plan.stage_task_ptr[st + 1];
         cugo_k::launch_chol_backward_stage(s, dev, d_fronts.data(), t0, t1 - t0, lds_backward,
                                            d_xnew.data(), d_x);
+        if (dbg && st == plan.n_stages - 1)
+        { // keep the top stage's backward stamps (kernel 3) in slots 48.. before stage 0 overwrites them
+            CUGO_HIP(hipStreamSynchronize(s));
+            CUGO_HIP(hipMemcpy(d_stamps + 48, d_stamps + 24, 8 * sizeof(long long), hipMemcpyDeviceToDevice));
+        }
     }
     CUGO_HIP(hipGetLastError());
     if (dbg)
@@ -98,7 +103,7 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
         CUGO_HIP(hipMemcpy(h, d_stamps, sizeof h, hipMemcpyDeviceToHost));
         static int calls = 0;
         if (++calls == 5)
-            for (int k = 0; k < 6; k++)
+            for (int k = 0; k < 7; k++)
             {
                 std::printf("stamps kernel %d (nc=%lld):", k, h[k * 8 + 6]);
                 for (int i = 1; i < 8; i++)

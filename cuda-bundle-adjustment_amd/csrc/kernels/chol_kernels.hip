@@ -632,39 +632,40 @@ __device__ __forceinline__ void dev_trsm_tile(double* __restrict__ F, long ld, i
     __syncthreads();
 }
 
-// U(ti,tj) -= L21(ti rows) L21(tj rows)^T, 64x64 tiles on the f64 matrix cores, executed by
-// TEAMS of 4 waves (a 256-thread workgroup is one team, a 1024-thread one four teams working
-// on four tiles at once).  The team stages its two 64-row panels through LDS in K chunks of
-// 24 (k-major, stride 80 doubles: the two 16-lane halves of a ds_read_b64 then hit different
-// banks); all loads of a chunk are issued together.  tiles[] enumerates (ti,tj) with ti>=tj.
+// U(ti,tj) -= L21(ti rows) L21(tj rows)^T, 64x64 tiles on the f64 matrix cores.  The whole
+// 1024-thread workgroup (16 waves) works on ONE tile: wave w owns the 16x16 sub-tile
+// (columns 16*(w&3).., rows 16*(w>>2)..), i.e. one MFMA accumulator chain per wave.  A single
+// wave issues roughly one instruction per 8 cycles and runs its MFMAs back to back at 64 cycles
+// each, while four waves per SIMD interleave freely — so the tile is spread over as many waves
+// as there are sub-tiles.  The two 64-row panels go through LDS for the whole pivot width
+// KC (k-major, stride 80 doubles: the two 16-lane halves of a ds_read_b64 then hit different
+// banks): one global round trip and one barrier per tile.
 // MFMA operand map (v_mfma_f64_16x16x4_f64): lane l supplies A[m = l&15][k = l>>4] and
 // B[k = l>>4][n = l&15]; result reg q holds D[m = (l>>4) + 4q][n = l&15].  With m = U column
 // and n = U row the 16 lanes l&15 hit consecutive rows of one column: 128-B segments.
-constexpr int PST = 80; // LDS panel stride (doubles) per k
-constexpr int KC = 24;  // K chunk
-constexpr int TEAM_LDS = 2 * KC * PST; // doubles per team
+constexpr int PST = 80;  // LDS panel stride (doubles) per k
+constexpr int KC_SYRK = 96; // K extent staged per barrier pair (= the widest pivot block)
+constexpr int syrk_lds() { return 2 * KC_SYRK * PST; } // doubles
 
 __device__ __forceinline__ void dev_syrk_tiles(double* __restrict__ F, long ld, int ncs, int nt, int nrs,
                                int first_tile, int ntiles_total, int ntj, double* __restrict__ lds,
                                double* __restrict__ junk)
 {
+    constexpr int KC = KC_SYRK;
     double* sink = junk + ((blockIdx.x & 63) << 10) + threadIdx.x; // private slot of this lane
     // tile index -> (ti, tj): column-major over the lower triangle of tiles, nti = ceil(nt/64)
     const int nti = (nt + 63) >> 6;
-    const int team = threadIdx.x >> 8, nteams = blockDim.x >> 8;
-    const int tt = threadIdx.x & 255;
+    const int tt = threadIdx.x;
     const int lane = tt & 63, w = tt >> 6;
+    const int wc = w & 3, wr = w >> 2;
     const int ln = lane & 15, lk = lane >> 4;
     const double* L21 = F + ncs; // element (row i, col k) = L21[k*ld + i]
-    double* Pi = lds + team * TEAM_LDS;
+    double* Pi = lds;
     double* Pj = Pi + KC * PST;
     double* U = F + (long)ncs * ld + ncs;
-    for (int base = first_tile; base < ntiles_total; base += nteams)
+    for (int tile = first_tile; tile < ntiles_total; tile++)
     {
-        const int tile = base + team;
-        const bool active = tile < ntiles_total;
         int ti = 0, tj = 0;
-        if (active)
         { // unrank: columns tj = 0.. have (nti - tj) tiles each
             int rem = tile;
             while (tj < ntj && rem >= nti - tj)
@@ -675,42 +676,38 @@ __device__ __forceinline__ void dev_syrk_tiles(double* __restrict__ F, long ld, 
             ti = tj + rem;
         }
         const bool diag = ti == tj;
-        double4_t acc[4];
-#pragma unroll
-        for (int t = 0; t < 4; t++)
-            acc[t] = double4_t{0, 0, 0, 0};
-        // prefetch the U entries this lane will update (independent loads, issued first)
-        double uold[4][4];
-#pragma unroll
-        for (int t = 0; t < 4; t++)
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-            { // masked lanes read their private sink slot: no branch, 16 loads in flight
-                const int i = 64 * ti + 16 * t + ln, j = 64 * tj + 16 * w + lk + 4 * q;
-                const bool ok = active && i < nt && j < nrs && i >= j;
-                const double* src = ok ? U + ((long)j * ld + i) : sink;
-                uold[t][q] = *src;
-            }
+        double4_t acc = {0, 0, 0, 0};
+        double uold[4];
         stamp(4, 2);
         for (int kc = 0; kc < ncs; kc += KC)
         {
             const int kn = min(KC, ncs - kc);
-            if (active)
-            { // all 12 global loads of a thread are issued before the first LDS store
+            { // all global loads of a thread are issued before the first LDS store
                 const int r = tt & 63, kq = tt >> 6;
                 const int gi = 64 * ti + r, gj = 64 * tj + r;
-                double vi[KC / 4], vj[KC / 4];
+                double vi[KC / 16], vj[KC / 16];
 #pragma unroll
-                for (int u = 0; u < KC / 4; u++)
+                for (int u = 0; u < KC / 16; u++)
                 {
-                    const int k = kq + 4 * u;
+                    const int k = kq + 16 * u;
                     vi[u] = (k < kn && gi < nt) ? L21[(long)(kc + k) * ld + gi] : 0.0;
                     vj[u] = (!diag && k < kn && gj < nt) ? L21[(long)(kc + k) * ld + gj] : 0.0;
                 }
+                if (kc == 0)
+                { // the U entries this lane updates travel with the first chunk
 #pragma unroll
-                for (int u = 0; u < KC / 4; u++)
+                    for (int q = 0; q < 4; q++)
+                    { // masked lanes read their private sink slot: no branch
+                        const int i = 64 * ti + 16 * wr + ln, j = 64 * tj + 16 * wc + lk + 4 * q;
+                        const bool ok = i < nt && j < nrs && i >= j;
+                        const double* src = ok ? U + ((long)j * ld + i) : sink;
+                        uold[q] = *src;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < KC / 16; u++)
                 {
-                    const int k = kq + 4 * u;
+                    const int k = kq + 16 * u;
                     if (k < kn)
                     {
                         Pi[k * PST + r] = vi[u];
@@ -720,35 +717,28 @@ __device__ __forceinline__ void dev_syrk_tiles(double* __restrict__ F, long ld, 
                 }
             }
             __syncthreads();
-            if (active)
             {
                 const double* Pa = diag ? Pi : Pj;
                 for (int k0 = 0; k0 < kn; k0 += 4)
                 {
-                    const int k = k0 + lk;
-                    const bool kok = k < kn;
-                    const double a = kok ? Pa[k * PST + 16 * w + ln] : 0.0;
-#pragma unroll
-                    for (int t = 0; t < 4; t++)
-                    {
-                        const double b = kok ? Pi[k * PST + 16 * t + ln] : 0.0;
-                        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
-                    }
+                    const int k = min(k0 + lk, kn - 1); // clamped: no branch around the LDS reads
+                    const bool kok = k0 + lk < kn;
+                    const double a = Pa[k * PST + 16 * wc + ln];
+                    const double b = Pi[k * PST + 16 * wr + ln];
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(kok ? a : 0.0, b, acc, 0, 0, 0);
                 }
             }
             __syncthreads();
         }
         stamp(4, 3);
 #pragma unroll
-        for (int t = 0; t < 4; t++)
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-            { // branch-free: masked lanes store into their sink slot, 16 stores back to back
-                const int i = 64 * ti + 16 * t + ln, j = 64 * tj + 16 * w + lk + 4 * q;
-                const bool ok = active && i < nt && j < nrs && i >= j;
-                double* dst = ok ? U + ((long)j * ld + i) : sink;
-                *dst = uold[t][q] - acc[t][q];
-            }
+        for (int q = 0; q < 4; q++)
+        { // branch-free: masked lanes store into their sink slot
+            const int i = 64 * ti + 16 * wr + ln, j = 64 * tj + 16 * wc + lk + 4 * q;
+            const bool ok = i < nt && j < nrs && i >= j;
+            double* dst = ok ? U + ((long)j * ld + i) : sink;
+            *dst = uold[q] - acc[q];
+        }
     }
 }
 
@@ -768,6 +758,7 @@ __device__ __forceinline__ void dev_backward(const CholPlanDev& p, const double*
     double* xr = dinv + ncs;           // nrs
     const int32_t* rows = p.rows + p.rows_ptr[f];
     stamp(3, 1);
+    stamp_value(3, 6, 1000L * ncs + nrs);
     dev_load_l11(F, ld, ncs, Ls);
     for (int i = threadIdx.x; i < nrs; i += blockDim.x)
     {
@@ -958,8 +949,8 @@ __global__ __launch_bounds__(BIG) void k_up_trsm(CholPlanDev p, double* __restri
     stamp_value(1, 6, ncs);
 }
 
-// one workgroup (one team) per 64x64 tile; it[1] = linear tile index
-__global__ __launch_bounds__(CBS) void k_up_syrk(CholPlanDev p, double* __restrict__ fronts,
+// one workgroup per 64x64 tile; it[1] = linear tile index
+__global__ __launch_bounds__(BIG) void k_up_syrk(CholPlanDev p, double* __restrict__ fronts,
                                                  const int32_t* __restrict__ wl)
 {
     extern __shared__ double lds[];
@@ -971,6 +962,7 @@ __global__ __launch_bounds__(CBS) void k_up_syrk(CholPlanDev p, double* __restri
     dev_syrk_tiles(fronts + p.off[f], 6L * p.nb[f] + 1, ncs, nrs + 1, nrs, it[1], it[1] + 1,
                    (nrs + 63) / 64, lds, p.junk);
     stamp(4, 7);
+    stamp_value(4, 6, 1000L * ncs + nrs);
 }
 
 __global__ __launch_bounds__(BIG) void k_backward_stage(CholPlanDev p,
@@ -1001,7 +993,7 @@ size_t chol_lds_factor_bytes(int nc_max)
 {
     const size_t ncp = (size_t)((nc_max + 15) & ~15);
     const size_t trsm = ncp * (ncp + 2) + (ncp >> 4) * (16 * 17) + (size_t)TR * (ncp + 1);
-    const size_t syrk = 4 * (size_t)TEAM_LDS; // four teams in the 1024-thread subtree kernel
+    const size_t syrk = (size_t)syrk_lds();
     return (std::max(trsm, syrk) + 8) * sizeof(double);
 }
 size_t chol_lds_backward_bytes(int nc_max, long ld_max)
@@ -1062,7 +1054,8 @@ void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fron
     }
     if (nsy > 0)
     {
-        CUGO_LAUNCH(k_up_syrk, dim3(nsy), dim3(CBS), TEAM_LDS * sizeof(double), s, p, d_fronts,
+        ensure_lds(reinterpret_cast<const void*>(k_up_syrk), syrk_lds() * sizeof(double));
+        CUGO_LAUNCH(k_up_syrk, dim3(nsy), dim3(BIG), syrk_lds() * sizeof(double), s, p, d_fronts,
                            d_wl + 3L * sy0);
     }
 }

@@ -24,6 +24,13 @@ __global__ void k_fmachain(int n, long long* cyc, double* out) { double x = thre
 __global__ void k_sqrtchain(int n, long long* cyc, double* out) { double x = 2.0 + threadIdx.x; long long t0 = clock64(); for (int k = 0; k < n; k++) x = sqrt(x) + 1.5; long long t1 = clock64(); if (threadIdx.x == 0) cyc[0] = t1 - t0; out[threadIdx.x] = x; }
 __global__ void k_divchain(int n, long long* cyc, double* out) { double x = 2.0 + threadIdx.x; long long t0 = clock64(); for (int k = 0; k < n; k++) x = 3.0 / x + 1.5; long long t1 = clock64(); if (threadIdx.x == 0) cyc[0] = t1 - t0; out[threadIdx.x] = x; }
 
+typedef double d4 __attribute__((ext_vector_type(4)));
+__global__ void k_mfma_dep(int n, long long* cyc, double* out) { d4 acc = {0, 0, 0, 0}; double a = threadIdx.x * 1e-3, b = 1.0 + threadIdx.x * 1e-6; long long t0 = clock64(); for (int k = 0; k < n; k++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0); long long t1 = clock64(); if (threadIdx.x == 0) cyc[0] = t1 - t0; out[threadIdx.x] = acc[0] + acc[1] + acc[2] + acc[3]; }
+__global__ void k_mfma_ind4(int n, long long* cyc, double* out) { d4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0; double a = threadIdx.x * 1e-3, b = 1.0 + threadIdx.x * 1e-6; long long t0 = clock64(); for (int k = 0; k < n; k++) { a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, a0, 0, 0, 0); a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, a1, 0, 0, 0); a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, a2, 0, 0, 0); a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, a3, 0, 0, 0); } long long t1 = clock64(); if (threadIdx.x == 0) cyc[0] = t1 - t0; out[threadIdx.x] = a0[0] + a1[1] + a2[2] + a3[3]; }
+__global__ void k_fma_ind8(int n, long long* cyc, double* out) { double x[8]; for (int i = 0; i < 8; i++) x[i] = threadIdx.x * 1e-3 + i; double y = 1.0000001; long long t0 = clock64(); for (int k = 0; k < n; k++) { for (int i = 0; i < 8; i++) x[i] = fma(x[i], y, 1e-9); } long long t1 = clock64(); if (threadIdx.x == 0) cyc[0] = t1 - t0; double s = 0; for (int i = 0; i < 8; i++) s += x[i]; out[threadIdx.x] = s; }
+__global__ void k_f32_dep(int n, long long* cyc, double* out) { float x = threadIdx.x * 1e-3f, y = 1.0000001f; long long t0 = clock64(); for (int k = 0; k < n; k++) x = fmaf(x, y, 1e-9f); long long t1 = clock64(); if (threadIdx.x == 0) cyc[0] = t1 - t0; out[threadIdx.x] = x; }
+__global__ void k_wallclock(long long* cyc) { long long t0 = clock64(); long long w0 = wall_clock64(); long long w1 = w0; while (w1 - w0 < 100000) w1 = wall_clock64(); long long t1 = clock64(); if (threadIdx.x == 0) { cyc[0] = t1 - t0; cyc[1] = w1 - w0; } }
+
 int main()
 {
     hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
@@ -76,6 +83,18 @@ int main()
     CK(hipMemcpy(&cyc, dc, 8, hipMemcpyDeviceToHost)); printf("dependent fp64 sqrt+add: %.1f ticks\n", (double)cyc / 2000);
     hipLaunchKernelGGL(k_divchain, dim3(1), dim3(64), 0, s, 2000, dc, dd); CK(hipStreamSynchronize(s));
     CK(hipMemcpy(&cyc, dc, 8, hipMemcpyDeviceToHost)); printf("dependent fp64 div+add: %.1f ticks\n", (double)cyc / 2000);
+    for (int thr : {64, 256, 1024}) {
+        hipLaunchKernelGGL(k_mfma_dep, dim3(1), dim3(thr), 0, s, 2000, dc, dd); CK(hipStreamSynchronize(s));
+        CK(hipMemcpy(&cyc, dc, 8, hipMemcpyDeviceToHost)); printf("dependent mfma_f64_16x16x4 (%d thr): %.1f ticks each\n", thr, (double)cyc / 2000);
+        hipLaunchKernelGGL(k_mfma_ind4, dim3(1), dim3(thr), 0, s, 2000, dc, dd); CK(hipStreamSynchronize(s));
+        CK(hipMemcpy(&cyc, dc, 8, hipMemcpyDeviceToHost)); printf("4 independent mfma_f64_16x16x4 (%d thr): %.1f ticks per mfma\n", thr, (double)cyc / 8000);
+        hipLaunchKernelGGL(k_fma_ind8, dim3(1), dim3(thr), 0, s, 2000, dc, dd); CK(hipStreamSynchronize(s));
+        CK(hipMemcpy(&cyc, dc, 8, hipMemcpyDeviceToHost)); printf("8 independent fp64 fma chains (%d thr): %.2f ticks per fma\n", thr, (double)cyc / 16000);
+    }
+    hipLaunchKernelGGL(k_f32_dep, dim3(1), dim3(64), 0, s, 10000, dc, dd); CK(hipStreamSynchronize(s));
+    CK(hipMemcpy(&cyc, dc, 8, hipMemcpyDeviceToHost)); printf("dependent fp32 fma: %.2f ticks\n", (double)cyc / 10000);
+    { long long c2[2]; hipLaunchKernelGGL(k_wallclock, dim3(1), dim3(64), 0, s, dc); CK(hipStreamSynchronize(s));
+      CK(hipMemcpy(c2, dc, 16, hipMemcpyDeviceToHost)); printf("clock64 ticks per wall_clock64 tick (100 MHz): %.3f => clock64 at %.1f MHz\n", (double)c2[0] / c2[1], 100.0 * c2[0] / c2[1]); }
     // wall time of the fma kernel to convert ticks -> ns
     CK(hipEventRecord(a, s));
     hipLaunchKernelGGL(k_fmachain, dim3(1), dim3(64), 0, s, 2000000, dc, dd);

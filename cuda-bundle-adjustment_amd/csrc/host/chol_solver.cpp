@@ -13,6 +13,7 @@ void cugo_chol::upload(hipStream_t s)
 {
     const CholPlan& P = plan;
     d_ncb.upload(P.ncb, s), d_nb.upload(P.nb, s), d_off.upload(P.off, s), d_col0.upload(P.col0, s);
+    d_woff.upload(P.woff, s);
     d_rows_ptr.upload(P.rows_ptr, s), d_rows.upload(P.rows, s);
     d_child_ptr.upload(P.child_ptr, s), d_child.upload(P.child, s);
     d_rel_ptr.upload(P.rel_ptr, s), d_rel.upload(P.rel, s);
@@ -24,6 +25,7 @@ void cugo_chol::upload(hipStream_t s)
     d_fronts.resize((size_t)P.front_doubles + 16);
     d_xnew.resize((size_t)6 * P.n + 16);
     d_junk.resize(64 * 1024);
+    d_winv.resize((size_t)P.winv_doubles + 16);
     CUGO_HIP(hipStreamSynchronize(s)); // host vectors may be reused after return
 
     cugo_k::CholPlanDev& D = dev;
@@ -39,6 +41,7 @@ void cugo_chol::upload(hipStream_t s)
     D.blk_col = d_blk_col.data(), D.blk_trans = d_blk_trans.data();
     D.n = P.n, D.perm = d_perm.data(), D.col_front = d_col_front.data();
     D.junk = d_junk.data();
+    D.woff = d_woff.data(), D.winv = d_winv.data(), D.nc_max = P.nc_max;
     lds_factor = cugo_k::chol_lds_factor_bytes(P.nc_max);
     lds_backward = cugo_k::chol_lds_backward_bytes(P.nc_max, P.ld_max);
 }

@@ -487,7 +487,8 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
     // ---- 5. fronts: boundary rows, parents, relative indices ---------------------------
     P.rows_ptr.assign(ns + 1, 0);
     P.ncb.resize(ns), P.nb.resize(ns), P.col0.resize(ns), P.off.resize(ns), P.sparent.assign(ns, -1);
-    int64_t off = 0;
+    P.woff.resize(ns);
+    int64_t off = 0, woff = 0;
     for (int s = 0; s < ns; s++)
     {
         const int lastc = sfirst[s + 1] - 1;
@@ -500,6 +501,9 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
         P.off[s] = off;
         const int64_t ld = 6LL * P.nb[s] + 1;
         off += ld * 6LL * P.nb[s];
+        const int64_t ncp = (6LL * P.ncb[s] + 15) & ~15LL;
+        P.woff[s] = woff;
+        woff += ncp * ncp;
         P.ld_max = std::max<long>(P.ld_max, (long)ld);
         if (nr > 0)
             P.sparent[s] = P.col_front[P.rows[P.rows_ptr[s]]];
@@ -509,6 +513,7 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
                    nc * nc * nrs; // LL^T of the pivot block + TRSM + SYRK of the update
     }
     P.front_doubles = off;
+    P.winv_doubles = woff;
     // children (ascending order => fixed, deterministic extend-add order)
     P.child_ptr.assign(ns + 1, 0);
     for (int s = 0; s < ns; s++)

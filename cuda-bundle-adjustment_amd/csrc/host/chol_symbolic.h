@@ -31,6 +31,8 @@ struct CholPlan
     std::vector<int32_t> ncb, nb, col0;
     std::vector<int64_t> off;
     int64_t front_doubles = 0;
+    std::vector<int64_t> woff; // per front: offset of W = L11^-1 (pad16(6*ncb)^2 doubles)
+    int64_t winv_doubles = 0;
     std::vector<int32_t> col_front;      // new column -> supernode
 
     int n_stages = 0;

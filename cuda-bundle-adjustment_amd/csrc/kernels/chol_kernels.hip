@@ -204,83 +204,6 @@ __device__ __forceinline__ void dev_extend_add(const CholPlanDev& p, double* __r
     }
 }
 
-// value of a double held by lane `src` (wave-uniform, in an SGPR): two v_readlane_b32
-__device__ __forceinline__ double readlane_f64(double v, int src)
-{
-    const int s = __builtin_amdgcn_readfirstlane(src);
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), s);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), s);
-    return __hiloint2double(hi, lo);
-}
-
-// 1/sqrt(d) and sqrt(d) without the IEEE division / sqrt sequences (each ~150-250 cycles of
-// dependent fp64 work on the critical path): v_rsq_f64 seed + two Newton steps, then one
-// correction of the root.  Result within ~1 ulp.
-__device__ __forceinline__ void rsqrt_sqrt(double d, double& rs, double& s)
-{
-    double r = __builtin_amdgcn_rsq(d);
-    r = r * fma(-0.5 * d * r, r, 1.5);
-    r = r * fma(-0.5 * d * r, r, 1.5);
-    double q = d * r;
-    q = fma(0.5 * r, fma(-q, q, d), q);
-    rs = r;
-    s = q;
-}
-
-// in-register Cholesky of the 6x6 diagonal block at (j0,j0) of an LDS matrix (one thread);
-// also stores the reciprocals of the new diagonal entries in dinv[j0..j0+5]
-__device__ __forceinline__ bool chol6_lds(double* __restrict__ Ls, int lds, int j0,
-                                          double* __restrict__ dinv)
-{
-    double a[6][6];
-#pragma unroll
-    for (int c = 0; c < 6; c++)
-#pragma unroll
-        for (int r = 0; r < 6; r++)
-            a[r][c] = (r >= c) ? Ls[(j0 + c) * lds + j0 + r] : 0.0;
-    bool bad = false;
-    double iv[6];
-#pragma unroll
-    for (int j = 0; j < 6; j++)
-    {
-        double d = a[j][j];
-#pragma unroll
-        for (int k = 0; k < 6; k++)
-            if (k < j)
-                d -= a[j][k] * a[j][k];
-        if (!(d > PIVOT_TOL))
-        {
-            bad = true;
-            d = 1.0; // keep finite numbers flowing; the LM step is rejected anyway
-        }
-        double inv, sq;
-        rsqrt_sqrt(d, inv, sq);
-        a[j][j] = sq;
-        iv[j] = inv;
-#pragma unroll
-        for (int i = 0; i < 6; i++)
-            if (i > j)
-            {
-                double s = a[i][j];
-#pragma unroll
-                for (int k = 0; k < 6; k++)
-                    if (k < j)
-                        s -= a[i][k] * a[j][k];
-                a[i][j] = s * inv;
-            }
-    }
-#pragma unroll
-    for (int c = 0; c < 6; c++)
-    {
-        dinv[j0 + c] = iv[c];
-#pragma unroll
-        for (int r = 0; r < 6; r++)
-            if (r >= c)
-                Ls[(j0 + c) * lds + j0 + r] = a[r][c];
-    }
-    return bad;
-}
-
 __device__ __forceinline__ int pad16(int nc) { return (nc + 15) & ~15; }
 
 // lower triangle of F11 -> LDS (upper part zero), padded to a multiple of 16 with an identity
@@ -314,13 +237,6 @@ __device__ __forceinline__ void dev_load_l11(const double* __restrict__ F, long 
                     Ls[c * lds + r] = v[u][q];
             }
     }
-}
-
-// dinv[j] = 1 / L11[j][j] from an LDS copy of L11 (one division per thread, in parallel)
-__device__ __forceinline__ void dev_recip_diag(const double* __restrict__ Ls, int nc, double* __restrict__ dinv)
-{
-    for (int j = threadIdx.x; j < nc; j += blockDim.x)
-        dinv[j] = 1.0 / Ls[j * (pad16(nc) + 1) + j];
 }
 
 // Factor the 6-column panel starting at (j0,j0) of the LDS matrix Ls by ONE wave, in registers.
@@ -461,12 +377,12 @@ __device__ __forceinline__ void panel_update_next(double* __restrict__ Ls, int l
 // p+1; then wave 0 factors panel p+1 in registers while the other waves apply panel p to the
 // remaining columns.  Two barriers per panel, and the sequential part (panel factorisation)
 // overlaps the parallel part (trailing update).
-// On return Ls holds L11 (lower), dinv the reciprocal diagonal, F11 is overwritten.
-__device__ __forceinline__ void dev_potrf(double* __restrict__ F, long ld, int nc, double* __restrict__ Ls,
+// On return Ls holds L11 (lower) and dinv the reciprocal diagonal.  L11 is NOT written back to
+// F: every later consumer (trsm, backward substitution) works with W = L11^-1 (dev_winv).
+__device__ __forceinline__ void dev_potrf(const double* __restrict__ F, long ld, int nc, double* __restrict__ Ls,
                           double* __restrict__ dinv, int32_t* __restrict__ fail)
 {
     const int lds = pad16(nc) + 1;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, nty = blockDim.x >> 5;
     dev_load_l11(F, ld, nc, Ls);
     __syncthreads();
     stamp(0, 2);
@@ -495,9 +411,6 @@ __device__ __forceinline__ void dev_potrf(double* __restrict__ F, long ld, int n
         __syncthreads();
     }
     stamp(0, 4);
-    for (int c = ty; c < nc; c += nty)
-        for (int r = c + tx; r < nc; r += 32)
-            F[(long)c * ld + r] = Ls[c * lds + r];
 }
 
 // V_J = inverse of the J-th 16x16 diagonal block of L11 (lower triangular), one 16-lane group
@@ -534,101 +447,158 @@ __device__ __forceinline__ void dev_inv_diag16(const double* __restrict__ Ls, in
         V[i * 17 + c] = (i >= c) ? v[i] : 0.0;
 }
 
-// rows [row0, row0+nrows) (absolute scalar rows, nrows <= 64) of F21: X L11^T = B on the f64
-// matrix cores, 16-column blocks:  X_J = B_J V_J^T,  B_J' -= X_J L[J',J]^T  (J' > J).
-// Ls: padded L11 (ld ncp+1), Vs: inverted diagonal blocks, Bt: 64 x (ncp+1) tile in LDS.
-// Wave w works on row group w&3 (16 rows) and on the column blocks J' = J+1+(w>>2), +4, ...
-// X passes through LDS because the MFMA result layout (row = (l>>4)+4q, col = l&15) is not the
-// A-operand layout (row = l&15, k = l>>4).
-__device__ __forceinline__ void dev_trsm_tile(double* __restrict__ F, long ld, int nc, long row0, int nrows,
-                              const double* __restrict__ Ls, const double* __restrict__ Vs,
-                              double* __restrict__ Bt)
+// W = L11^-1 (lower triangular, ncp x ncp with the identity padding) on the f64 matrix cores,
+// written to global memory column-major: Wg[col*ncp + row].  Wave J builds block column J top
+// down:  W_JJ = V_J,  W_IJ = -V_I * sum_{K=J..I-1} L_IK W_KJ.  The MFMA result layout
+// (reg q: row (l>>4)+4q, col l&15) IS the B-operand layout of the next product, so the whole
+// chain stays in registers: no LDS round trip between the dependent products.
+// Everything after the factorisation works with W: trsm becomes a plain GEMM (no serial
+// block substitution per tile) and the backward substitution a matrix-vector product (no
+// 96-step serial solve).
+__device__ __forceinline__ void dev_winv(const double* __restrict__ Ls, int ncp, const double* __restrict__ Vs,
+                                         double* __restrict__ Wg)
 {
-    const int ncp = pad16(nc), lds = ncp + 1, nblk = ncp >> 4;
+    const int lds = ncp + 1, nblk = ncp >> 4;
+    const int J = threadIdx.x >> 6, lane = threadIdx.x & 63, ln = lane & 15, lk = lane >> 4;
+    if (J >= nblk)
+        return;
+    double4_t Wr[6];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        Wr[0][q] = Vs[J * 272 + (lk + 4 * q) * 17 + ln];
+#pragma unroll
+    for (int d = 1; d < 6; d++)
     {
-        const int tr = threadIdx.x & 63, tc = threadIdx.x >> 6, ntc = blockDim.x >> 6;
-        for (int c0 = tc; c0 < ncp; c0 += 6 * ntc)
-        { // up to 6 independent loads in flight per thread
-            double v[6];
+        const int I = J + d;
+        Wr[d] = double4_t{0, 0, 0, 0};
+        if (I < nblk) // wave-uniform
+        {
+            double4_t T = {0, 0, 0, 0};
 #pragma unroll
-            for (int u = 0; u < 6; u++)
+            for (int e = 0; e < d; e++)
             {
-                const int c = c0 + u * ntc;
-                v[u] = (tr < nrows && c < nc) ? F[(long)c * ld + row0 + tr] : 0.0;
-            }
+                double a[4];
 #pragma unroll
-            for (int u = 0; u < 6; u++)
-            {
-                const int c = c0 + u * ntc;
-                if (c < ncp)
-                    Bt[tr * lds + c] = v[u];
+                for (int kk = 0; kk < 4; kk++)
+                    a[kk] = Ls[(16 * (J + e) + lk + 4 * kk) * lds + 16 * I + ln]; // L_IK[m][k]
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++)
+                    T = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], Wr[e][kk], T, 0, 0, 0);
             }
+            double4_t acc = {0, 0, 0, 0};
+            double a[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++)
+                a[kk] = Vs[I * 272 + ln * 17 + lk + 4 * kk]; // V_I[m][k]
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], T[kk], acc, 0, 0, 0);
+            Wr[d] = -acc;
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 6; d++)
+        if (J + d < nblk)
+        {
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                Wg[(long)(16 * J + ln) * ncp + 16 * (J + d) + lk + 4 * q] = Wr[d][q];
+        }
+}
+
+// rows [row0, row0+nrows) (absolute scalar rows, nrows <= 64) of F21:  X = B W^T  (X L11^T = B)
+// as a GEMM on the f64 matrix cores.  The B tile is staged in LDS k-major (Bt[k*PST + r]); wave
+// w owns row group w&3 and one or two 16-column blocks cb of X (dealt so that every wave has at
+// most 6 K-blocks of work: X block cb needs K-blocks 0..cb because W is lower triangular).
+// A-operand = W[16cb+m][k] straight from global (coalesced, L2-resident, shared by all tiles
+// of the front), all loads issued before the barrier.  D[m][n] = X[row n][col m]: the 16 lanes
+// l&15 store consecutive rows of one column.
+constexpr int PSTB = 80;
+__device__ __forceinline__ void dev_trsm_w(double* __restrict__ F, long ld, int nc, long row0, int nrows,
+                                           const double* __restrict__ Wg, double* __restrict__ Bt)
+{
+    const int ncp = pad16(nc), nblk = ncp >> 4;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, ln = lane & 15, lk = lane >> 4;
+    const int rg = w & 3, g = w >> 2;
+    // deal the column blocks (cost cb+1) to the 4 wave groups: largest first, to the least loaded
+    int cbA = -1, cbB = -1;
+    {
+        int load[4] = {0, 0, 0, 0};
+        for (int cb = nblk - 1; cb >= 0; cb--)
+        {
+            int best = 0;
+#pragma unroll
+            for (int t = 1; t < 4; t++)
+                if (load[t] < load[best])
+                    best = t;
+            load[best] += cb + 1;
+            if (best == g)
+            {
+                if (cbA < 0)
+                    cbA = cb;
+                else
+                    cbB = cb;
+            }
+        }
+    }
+    const int nA = cbA + 1, nU = nA + cbB + 1; // K-blocks of the first block / in total (<= 6)
+    double a[6][4];
+#pragma unroll
+    for (int u = 0; u < 6; u++)
+    {
+        const int cb = u < nA ? cbA : cbB, kb = u < nA ? u : u - nA;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++)
+            a[u][kk] = (u < nU) ? Wg[(long)(16 * kb + lk + 4 * kk) * ncp + 16 * cb + ln] : 0.0;
+    }
+    { // stage the B tile: r = t&63, 6 columns per thread, loads first
+        const int r = threadIdx.x & 63, kq = threadIdx.x >> 6;
+        double v[6];
+#pragma unroll
+        for (int u = 0; u < 6; u++)
+        {
+            const int k = kq + 16 * u;
+            v[u] = (k < nc && r < nrows) ? F[(long)k * ld + row0 + r] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 6; u++)
+        {
+            const int k = kq + 16 * u;
+            if (k < ncp)
+                Bt[k * PSTB + r] = v[u];
         }
     }
     __syncthreads();
     stamp(1, 3);
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int ln = lane & 15, lk = lane >> 4;
-    const int nw = blockDim.x >> 6;          // 4 or 16 waves
-    const int rg = w & 3, cs = w >> 2, ncs_ = nw >> 2; // row group, column subset, #subsets
-    double* Brow = Bt + (16 * rg) * lds;
-    for (int p = 0; p < nblk; p++)
+    double4_t acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < 6; u++)
     {
-        const int J = 16 * p;
-        if (cs == 0)
-        { // X = B_J V_J^T
-            const double* V = Vs + p * (16 * 17);
-            double4_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-            double a[4], b[4];
+        if (u < nU)
+        {
+            const int kb = u < nA ? u : u - nA;
 #pragma unroll
-            for (int ks = 0; ks < 4; ks++)
+            for (int kk = 0; kk < 4; kk++)
             {
-                const int k = 4 * ks + lk;
-                a[ks] = Brow[ln * lds + J + k];
-                b[ks] = V[ln * 17 + k]; // V^T[k][n] = V[n][k]
+                const double b = Bt[(16 * kb + lk + 4 * kk) * PSTB + 16 * rg + ln];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][kk], b, acc, 0, 0, 0);
             }
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b[2], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b[3], acc1, 0, 0, 0);
-            wave_lds_sync(); // every lane has read B_J before it is overwritten
+            if (u == nA - 1 || u == nU - 1)
+            { // block finished: X[row0 + 16rg + ln][16cb + lk + 4q]
+                const int cb = u < nA ? cbA : cbB;
+                const int r = 16 * rg + ln;
 #pragma unroll
-            for (int q = 0; q < 4; q++)
-                Brow[(lk + 4 * q) * lds + J + ln] = acc0[q] + acc1[q];
-        }
-        __syncthreads();
-        for (int pb = p + 1 + cs; pb < nblk; pb += ncs_)
-        { // B_J' -= X L[J',J]^T
-            const int Jp = 16 * pb;
-            double4_t acc0, acc1 = {0, 0, 0, 0};
-            double a[4], b[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                acc0[q] = Brow[(lk + 4 * q) * lds + Jp + ln];
-#pragma unroll
-            for (int ks = 0; ks < 4; ks++)
-            {
-                const int k = 4 * ks + lk;
-                a[ks] = -Brow[ln * lds + J + k];
-                b[ks] = Ls[(J + k) * lds + Jp + ln]; // L[J'+n][J+k]
+                for (int q = 0; q < 4; q++)
+                {
+                    const int c = 16 * cb + lk + 4 * q;
+                    if (c < nc && r < nrows)
+                        F[(long)c * ld + row0 + r] = acc[q];
+                }
+                acc = double4_t{0, 0, 0, 0};
             }
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b[2], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b[3], acc1, 0, 0, 0);
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                Brow[(lk + 4 * q) * lds + Jp + ln] = acc0[q] + acc1[q];
         }
-        __syncthreads();
     }
     stamp(1, 4);
-    {
-        const int tr = threadIdx.x & 63, tc = threadIdx.x >> 6, ntc = blockDim.x >> 6;
-        if (tr < nrows)
-            for (int c = tc; c < nc; c += ntc)
-                F[(long)c * ld + row0 + tr] = Bt[tr * lds + c];
-    }
     __syncthreads();
 }
 
@@ -742,112 +712,84 @@ __device__ __forceinline__ void dev_syrk_tiles(double* __restrict__ F, long ld, 
     }
 }
 
-// backward substitution of one front: x_J = L11^-T (y_J - L21^T x_R)
+// backward substitution of one front: x_J = W^T (y_J - L21^T x_R), W = L11^-1 from dev_winv.
+// Both halves are matrix-vector products: 16 lanes per pivot column, all loads of a lane in
+// flight together, a 16-lane butterfly at the end.  No serial triangular solve.
 __device__ __forceinline__ void dev_backward(const CholPlanDev& p, const double* __restrict__ fronts, int f,
                              double* __restrict__ lds, double* __restrict__ xnew,
                              double* __restrict__ xout)
 {
     const int ncb = p.ncb[f], nb = p.nb[f];
     const long ld = 6L * nb + 1;
-    const int ncs = 6 * ncb, nrs = 6 * (nb - ncb);
+    const int ncs = 6 * ncb, nrs = 6 * (nb - ncb), ncp = pad16(ncs);
     const double* F = fronts + p.off[f];
-    const int ldsl = pad16(ncs) + 1;
-    double* Ls = lds;                  // padded L11
-    double* vs = lds + pad16(ncs) * ldsl; // ncs
-    double* dinv = vs + ncs;           // ncs
-    double* xr = dinv + ncs;           // nrs
+    const double* Wg = p.winv + p.woff[f];
+    const int c0 = p.col0[f];
+    double* vs = lds;      // ncp
+    double* xr = lds + ncp; // nrs
     const int32_t* rows = p.rows + p.rows_ptr[f];
     stamp(3, 1);
     stamp_value(3, 6, 1000L * ncs + nrs);
-    dev_load_l11(F, ld, ncs, Ls);
     for (int i = threadIdx.x; i < nrs; i += blockDim.x)
     {
         const int ib = i / 6;
         xr[i] = xnew[6L * rows[ib] + (i - 6 * ib)];
     }
+    for (int j = ncs + threadIdx.x; j < ncp; j += blockDim.x)
+        vs[j] = 0.0;
     __syncthreads();
     stamp(3, 2);
-    dev_recip_diag(Ls, ncs, dinv);
-    { // v_j = y_j - sum_i L21[i,j] x_R[i]: 16 lanes per column, lanes stride the rows
-        const int g = threadIdx.x >> 4, l16 = threadIdx.x & 15, ng = blockDim.x >> 4;
-        for (int j = g; j < ncs; j += ng)
-        {
-            const double* col = F + (long)j * ld + ncs;
-            double s = 0;
-            for (int i = l16; i < nrs; i += 64)
-            { // four independent loads in flight per lane
-                const double a0 = col[i];
-                const double a1 = i + 16 < nrs ? col[i + 16] : 0.0;
-                const double a2 = i + 32 < nrs ? col[i + 32] : 0.0;
-                const double a3 = i + 48 < nrs ? col[i + 48] : 0.0;
-                s += a0 * xr[i];
-                if (i + 16 < nrs)
-                    s += a1 * xr[i + 16];
-                if (i + 32 < nrs)
-                    s += a2 * xr[i + 32];
-                if (i + 48 < nrs)
-                    s += a3 * xr[i + 48];
-            }
+    const int g = threadIdx.x >> 4, l16 = threadIdx.x & 15, ng = blockDim.x >> 4;
+    // v_j = y_j - sum_i L21[i,j] x_R[i]
+    for (int j = g; j < ncs; j += ng)
+    {
+        const double* col = F + (long)j * ld + ncs;
+        const double y = F[(long)j * ld + (ld - 1)];
+        double s = 0;
+        for (int i = l16; i < nrs; i += 128)
+        { // eight independent loads in flight per lane
+            double a[8];
 #pragma unroll
-            for (int off = 8; off > 0; off >>= 1)
-                s += __shfl_down(s, off, 16);
-            if (l16 == 0)
-                vs[j] = F[(long)j * ld + (ld - 1)] - s;
+            for (int u = 0; u < 8; u++)
+                a[u] = col[min(i + 16 * u, nrs - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                s += (i + 16 * u < nrs) ? a[u] * xr[i + 16 * u] : 0.0;
         }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1)
+            s += __shfl_xor(s, off, 16);
+        if (l16 == 0)
+            vs[j] = y - s;
     }
     __syncthreads();
     stamp(3, 3);
-    // L11^T x = v by ONE wave, wave-synchronously: lane t keeps v[t] and v[t+64] in registers,
-    // x_j is broadcast with a lane read, the row of L for the next step is prefetched from LDS
-    // (stride ncs+1 doubles: conflict-free).  No workgroup barrier inside the 6*ncb steps.
-    if (threadIdx.x < 64)
+    // x_j = sum_k W[k][j] v_k over k >= 16*floor(j/16) (W lower triangular, zeros above the
+    // diagonal inside the diagonal block); Wg is column-major, so the sum runs along a column
+    for (int j = g; j < ncs; j += ng)
     {
-        const int lane = threadIdx.x;
-        double v0 = lane < ncs ? vs[lane] : 0.0;
-        double v1 = lane + 64 < ncs ? vs[lane + 64] : 0.0;
-        int j = ncs - 1;
-        double l0 = lane < j ? Ls[lane * ldsl + j] : 0.0;
-        double l1 = lane + 64 < j ? Ls[(lane + 64) * ldsl + j] : 0.0;
-        double dj = dinv[j];
-        for (; j >= 0; j--)
-        {
-            // prefetch row j-1
-            const int jn = j - 1;
-            double n0 = 0.0, n1 = 0.0, dn = 0.0;
-            if (jn >= 0)
-            {
-                n0 = lane < jn ? Ls[lane * ldsl + jn] : 0.0;
-                n1 = lane + 64 < jn ? Ls[(lane + 64) * ldsl + jn] : 0.0;
-                dn = dinv[jn];
-            }
-            const double vj = j < 64 ? readlane_f64(v0, j) : readlane_f64(v1, j - 64);
-            const double xj = vj * dj;
-            v0 -= l0 * xj;
-            v1 -= l1 * xj;
-            if (lane == (j & 63))
-            {
-                if (j < 64)
-                    v0 = xj;
-                else
-                    v1 = xj;
-            }
-            l0 = n0, l1 = n1, dj = dn;
-        }
-        if (lane < ncs)
-            vs[lane] = v0;
-        if (lane + 64 < ncs)
-            vs[lane + 64] = v1;
-    }
-    __syncthreads();
-    stamp(3, 4);
-    const int c0 = p.col0[f];
-    for (int j = threadIdx.x; j < ncs; j += blockDim.x)
-    {
+        const int k0 = (j & ~15) + l16;
+        const double* wcol = Wg + (long)j * ncp;
         const int jb = j / 6, comp = j - 6 * jb;
-        const double v = vs[j];
-        xnew[6L * (c0 + jb) + comp] = v;
-        xout[6L * p.perm[c0 + jb] + comp] = v;
+        const int pj = p.perm[c0 + jb];
+        double wv[6];
+#pragma unroll
+        for (int u = 0; u < 6; u++)
+            wv[u] = wcol[min(k0 + 16 * u, ncp - 1)];
+        double s = 0;
+#pragma unroll
+        for (int u = 0; u < 6; u++)
+            s += (k0 + 16 * u < ncp) ? wv[u] * vs[k0 + 16 * u] : 0.0;
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1)
+            s += __shfl_xor(s, off, 16);
+        if (l16 == 0)
+        {
+            xnew[6L * (c0 + jb) + comp] = s;
+            xout[6L * pj + comp] = s;
+        }
     }
+    stamp(3, 4);
     __threadfence_block();
     __syncthreads();
 }
@@ -872,13 +814,17 @@ __global__ __launch_bounds__(BIG) void k_subtree_factor(CholPlanDev p, double* _
         double* dinv = lds + ncp * (ncp + 1);
         double* Vs = dinv + ncp;
         double* Bt = Vs + (ncp >> 4) * (16 * 17);
+        double* Wg = p.winv + p.woff[f];
         dev_extend_add(p, fronts, f, 0, nb);
         dev_potrf(F, ld, ncs, Ls, dinv, fail);
         __syncthreads();
         dev_inv_diag16(Ls, ncp, Vs);
         __syncthreads();
+        dev_winv(Ls, ncp, Vs, Wg);
+        __threadfence_block();
+        __syncthreads();
         for (int r0 = 0; r0 < nt; r0 += TR)
-            dev_trsm_tile(F, ld, ncs, ncs + r0, min(TR, nt - r0), Ls, Vs, Bt);
+            dev_trsm_w(F, ld, ncs, ncs + r0, min(TR, nt - r0), Wg, Bt);
         __threadfence_block();
         __syncthreads();
         const int nti = (nt + 63) / 64, ntj = (nrs + 63) / 64;
@@ -910,12 +856,20 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
     const int ncs = 6 * p.ncb[f];
     const int ncp = pad16(ncs);
     stamp(0, 1);
-    dev_potrf(fronts + p.off[f], 6L * p.nb[f] + 1, ncs, lds, lds + ncp * (ncp + 1), fail);
+    double* Ls = lds;
+    double* dinv = lds + ncp * (ncp + 1);
+    double* Vs = dinv + ncp;
+    dev_potrf(fronts + p.off[f], 6L * p.nb[f] + 1, ncs, Ls, dinv, fail);
+    __syncthreads();
+    dev_inv_diag16(Ls, ncp, Vs);
+    __syncthreads();
+    stamp(0, 5);
+    dev_winv(Ls, ncp, Vs, p.winv + p.woff[f]);
     stamp(0, 7);
     stamp_value(0, 6, ncs);
 }
 
-// trsm tiles (touch the pivot columns) and, in the same launch, the extend-add of the
+// trsm tiles (touch the pivot columns; LDS = one 64-row B tile) and, in the same launch, the extend-add of the
 // boundary columns (touch the update region): independent data, one kernel boundary less
 __global__ __launch_bounds__(BIG) void k_up_trsm(CholPlanDev p, double* __restrict__ fronts,
                                                  const int32_t* __restrict__ wl, int ntr,
@@ -933,18 +887,8 @@ __global__ __launch_bounds__(BIG) void k_up_trsm(CholPlanDev p, double* __restri
     const int ncs = 6 * p.ncb[f];
     const long ld = 6L * p.nb[f] + 1;
     double* F = fronts + p.off[f];
-    const int ncp = pad16(ncs);
-    double* Ls = lds;
-    double* Vs = lds + ncp * (ncp + 1);
-    double* Bt = Vs + (ncp >> 4) * (16 * 17);
     stamp(1, 0);
-    dev_load_l11(F, ld, ncs, Ls);
-    __syncthreads();
-    stamp(1, 1);
-    dev_inv_diag16(Ls, ncp, Vs);
-    __syncthreads();
-    stamp(1, 2);
-    dev_trsm_tile(F, ld, ncs, ncs + it[1], it[2] - it[1], Ls, Vs, Bt);
+    dev_trsm_w(F, ld, ncs, ncs + it[1], it[2] - it[1], p.winv + p.woff[f], lds);
     stamp(1, 7);
     stamp_value(1, 6, ncs);
 }
@@ -990,16 +934,21 @@ namespace cugo_k
 {
 
 size_t chol_lds_factor_bytes(int nc_max)
-{
+{ // subtree / potrf kernels: L11 + dinv + inverted diagonal blocks + one trsm B tile, or the syrk panels
     const size_t ncp = (size_t)((nc_max + 15) & ~15);
-    const size_t trsm = ncp * (ncp + 2) + (ncp >> 4) * (16 * 17) + (size_t)TR * (ncp + 1);
+    const size_t trsm = ncp * (ncp + 2) + (ncp >> 4) * (16 * 17) + ncp * (size_t)PSTB;
     const size_t syrk = (size_t)syrk_lds();
     return (std::max(trsm, syrk) + 8) * sizeof(double);
+}
+size_t chol_lds_trsm_bytes(int nc_max)
+{
+    const size_t ncp = (size_t)((nc_max + 15) & ~15);
+    return (ncp * (size_t)PSTB + 8) * sizeof(double);
 }
 size_t chol_lds_backward_bytes(int nc_max, long ld_max)
 {
     const size_t ncp = (size_t)((nc_max + 15) & ~15);
-    return (ncp * (ncp + 1) + 2 * ncp + (size_t)ld_max + 8) * sizeof(double);
+    return (ncp + (size_t)ld_max + 8) * sizeof(double);
 }
 
 void set_debug_stamps(long long* d_buf)
@@ -1048,8 +997,9 @@ void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fron
     CUGO_LAUNCH(k_up_potrf, dim3(ntasks), dim3(BIG), lds_bytes, s, p, d_fronts, task0, d_fail);
     if (ntr + nea > 0)
     {
-        ensure_lds(reinterpret_cast<const void*>(k_up_trsm), lds_bytes);
-        CUGO_LAUNCH(k_up_trsm, dim3(ntr + nea), dim3(BIG), lds_bytes, s, p, d_fronts,
+        const size_t lds_trsm = chol_lds_trsm_bytes(p.nc_max);
+        ensure_lds(reinterpret_cast<const void*>(k_up_trsm), lds_trsm);
+        CUGO_LAUNCH(k_up_trsm, dim3(ntr + nea), dim3(BIG), lds_trsm, s, p, d_fronts,
                            d_wl + 3L * tr0, ntr, d_wl + 3L * ea0);
     }
     if (nsy > 0)

@@ -85,6 +85,9 @@ struct CholPlanDev
     const int32_t* ncb;        // pivot block columns
     const int32_t* nb;         // total block rows (pivot + boundary); scalar ld = 6*nb + 1
     const int64_t* off;        // offset (doubles) of the front matrix in `fronts`
+    const int64_t* woff;       // offset (doubles) of W = L11^-1 (pad16(6*ncb)^2, column-major) in winv
+    double* winv;
+    int nc_max;                // widest pivot block (scalars)
     const int32_t* col0;       // first pivot column (new ordering, block units)
     const int32_t* rows_ptr;   // [n_fronts+1] into rows: boundary block rows (new ordering)
     const int32_t* rows;
@@ -125,5 +128,6 @@ void launch_chol_backward_stage(hipStream_t s, const CholPlanDev& p, double* d_f
 void set_debug_stamps(long long* d_buf); // diagnostic s_memtime stamps (nullptr = off)
 size_t chol_lds_factor_bytes(int nc_max);
 size_t chol_lds_backward_bytes(int nc_max, long ld_max);
+size_t chol_lds_trsm_bytes(int nc_max);
 
 } // namespace cugo_k

@@ -50,7 +50,8 @@ void cugo_chol::analyze(int n, const int32_t* rowptr, const int32_t* colind)
 {
     chol_analyze(n, rowptr, colind, CholOptions::from_env(), plan);
     trans32.assign(plan.blk_trans.begin(), plan.blk_trans.end());
-    if (cugo_k::chol_lds_factor_bytes(plan.nc_max) > 160 * 1024 ||
+    if (plan.nc_max > cugo_k::chol_max_pivot_cols() ||
+        cugo_k::chol_lds_factor_bytes(plan.nc_max) > 160 * 1024 ||
         cugo_k::chol_lds_backward_bytes(plan.nc_max, plan.ld_max) > 160 * 1024)
         throw std::runtime_error("cugo: a front exceeds the LDS budget (nc=" +
                                  std::to_string(plan.nc_max) + ", ld=" + std::to_string(plan.ld_max) + ")");

@@ -30,6 +30,8 @@ namespace
 constexpr int CBS = 256;
 constexpr double PIVOT_TOL = 1e-14;
 constexpr int TR = 64; // trsm / syrk tile edge
+constexpr int NC_MAX = 96; // widest pivot block (scalars): L11 lives in LDS
+constexpr int LLD = NC_MAX + 1; // leading dimension of the LDS copy of L11
 
 using cugo_k::CholPlanDev;
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -207,36 +209,34 @@ __device__ __forceinline__ void dev_extend_add(const CholPlanDev& p, double* __r
 __device__ __forceinline__ int pad16(int nc) { return (nc + 15) & ~15; }
 
 // lower triangle of F11 -> LDS (upper part zero), padded to a multiple of 16 with an identity
-// block (the MFMA trsm works on 16-column blocks); leading dimension pad16(nc)+1.
+// block (W = L11^-1 is built from 16-column blocks).  The LDS copy always has leading dimension
+// LLD = 97 (odd: column walks are conflict-free) whatever nc is, so that every LDS address in
+// the factorisation is `base + compile-time offset` — one instruction per access.
 __device__ __forceinline__ void dev_load_l11(const double* __restrict__ F, long ld, int nc, double* __restrict__ Ls)
 {
-    const int ncp = pad16(nc), lds = ncp + 1;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, nty = blockDim.x >> 5;
-    // all global loads of a thread are issued before the first LDS store (3 rows x up to 4
-    // columns in flight): a dependent-load chain costs ~900 cycles per link otherwise
-    for (int c0 = ty; c0 < ncp; c0 += 4 * nty)
-    {
-        double v[4][3];
+    // 1024 threads cover the full NC_MAX x NC_MAX LDS matrix, 9 elements each: all global loads
+    // (clamped addresses, no branch) are issued before the first LDS store; everything outside
+    // the nc x nc lower triangle becomes identity / zero
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const unsigned uld = (unsigned)ld;
+    double v[3][3];
 #pragma unroll
-        for (int u = 0; u < 4; u++)
+    for (int u = 0; u < 3; u++)
 #pragma unroll
-            for (int q = 0; q < 3; q++)
-            {
-                const int c = c0 + u * nty, r = tx + 32 * q;
-                v[u][q] = (r == c) ? 1.0 : 0.0;
-                if (c < nc && r < nc)
-                    v[u][q] = (r >= c) ? F[(long)c * ld + r] : 0.0;
-            }
+        for (int q = 0; q < 3; q++)
+        {
+            const int c = ty + 32 * u, r = tx + 32 * q;
+            v[u][q] = F[(unsigned)min(c, nc - 1) * uld + (unsigned)min(r, nc - 1)];
+        }
 #pragma unroll
-        for (int u = 0; u < 4; u++)
+    for (int u = 0; u < 3; u++)
 #pragma unroll
-            for (int q = 0; q < 3; q++)
-            {
-                const int c = c0 + u * nty, r = tx + 32 * q;
-                if (c < ncp && r < ncp)
-                    Ls[c * lds + r] = v[u][q];
-            }
-    }
+        for (int q = 0; q < 3; q++)
+        {
+            const int c = ty + 32 * u, r = tx + 32 * q;
+            const double x = (c < nc && r < nc) ? (r >= c ? v[u][q] : 0.0) : (r == c ? 1.0 : 0.0);
+            Ls[c * LLD + r] = x;
+        }
 }
 
 // Factor the 6-column panel starting at (j0,j0) of the LDS matrix Ls by ONE wave, in registers.
@@ -245,11 +245,17 @@ __device__ __forceinline__ void dev_load_l11(const double* __restrict__ F, long 
 // column to its own rows below the block (lane t: rows j0+6+t and j0+70+t; nc <= 96).
 // Right-looking inside the panel, so every value is touched by one FMA per column: the
 // dependent chain is 6 x (sqrt || 1/d, mul, mul, fma) ~ 6 x 220 cycles.  Writes dinv[j0..j0+5].
-__device__ __forceinline__ bool panel_factor_wave(double* __restrict__ Ls, int lds, int nc, int j0,
+__device__ __forceinline__ bool panel_factor_wave(double* __restrict__ Ls, int nc, int j0,
                                                   double* __restrict__ dinv)
 {
     const int lane = threadIdx.x & 63;
     const int r0 = j0 + 6 + lane, r1 = j0 + 70 + lane;
+    // rows past the end are clamped to the last padded row for the loads (valid LDS, results
+    // unused) and masked as a group for the stores: no branch per access
+    const bool ok0 = r0 < nc, ok1 = r1 < nc;
+    double* P = Ls + j0 * LLD + j0;           // (j0, j0); column c at P + c*LLD (immediate offsets)
+    const double* A0 = Ls + j0 * LLD + min(r0, NC_MAX - 1);
+    const double* A1 = Ls + j0 * LLD + min(r1, NC_MAX - 1);
     if (j0 == 0)
         stamp(2, 0);
     double D[6][6], a0[6], a1[6];
@@ -258,9 +264,9 @@ __device__ __forceinline__ bool panel_factor_wave(double* __restrict__ Ls, int l
     {
 #pragma unroll
         for (int r = 0; r < 6; r++)
-            D[r][c] = (r >= c) ? Ls[(j0 + c) * lds + j0 + r] : 0.0;
-        a0[c] = r0 < nc ? Ls[(j0 + c) * lds + r0] : 0.0;
-        a1[c] = r1 < nc ? Ls[(j0 + c) * lds + r1] : 0.0;
+            D[r][c] = (r >= c) ? P[c * LLD + r] : 0.0;
+        a0[c] = A0[c * LLD];
+        a1[c] = A1[c * LLD];
     }
     bool bad = false;
     double iv[6];
@@ -306,21 +312,31 @@ __device__ __forceinline__ bool panel_factor_wave(double* __restrict__ Ls, int l
         asm volatile("" ::"v"(D[5][5]), "v"(a1[5]), "v"(a0[5]));
         stamp(2, 2);
     }
-#pragma unroll
-    for (int c = 0; c < 6; c++)
+    if (ok0)
     {
-        if (lane == 0)
+        double* W0 = Ls + j0 * LLD + r0;
+#pragma unroll
+        for (int c = 0; c < 6; c++)
+            W0[c * LLD] = a0[c];
+    }
+    if (ok1)
+    {
+        double* W1 = Ls + j0 * LLD + r1;
+#pragma unroll
+        for (int c = 0; c < 6; c++)
+            W1[c * LLD] = a1[c];
+    }
+    if (lane == 0)
+    {
+#pragma unroll
+        for (int c = 0; c < 6; c++)
         {
             dinv[j0 + c] = iv[c];
 #pragma unroll
             for (int r = 0; r < 6; r++)
                 if (r >= c)
-                    Ls[(j0 + c) * lds + j0 + r] = D[r][c];
+                    P[c * LLD + r] = D[r][c];
         }
-        if (r0 < nc)
-            Ls[(j0 + c) * lds + r0] = a0[c];
-        if (r1 < nc)
-            Ls[(j0 + c) * lds + r1] = a1[c];
     }
     if (j0 == 0)
         stamp(2, 3);
@@ -330,7 +346,7 @@ __device__ __forceinline__ bool panel_factor_wave(double* __restrict__ Ls, int l
 // columns [c_lo, c_hi) of the LDS matrix -= (panel at j0)(panel at j0)^T, lower part only;
 // executed by the threads with tid0 <= threadIdx.x (32 lanes walk the rows of a column).
 // The 6-term dot product is split in two chains: a dependent fp64 FMA costs ~40 cycles.
-__device__ __forceinline__ void panel_update_cols(double* __restrict__ Ls, int lds, int nc, int j0,
+__device__ __forceinline__ void panel_update_cols(double* __restrict__ Ls, int nc, int j0,
                                                   int c_lo, int c_hi, int tid0)
 {
     const int t = (int)threadIdx.x - tid0;
@@ -342,33 +358,33 @@ __device__ __forceinline__ void panel_update_cols(double* __restrict__ Ls, int l
         double pc[6];
 #pragma unroll
         for (int k = 0; k < 6; k++)
-            pc[k] = Ls[(j0 + k) * lds + c];
+            pc[k] = Ls[(j0 + k) * LLD + c];
         for (int r = c + tx; r < nc; r += 32)
         {
-            const double s0 = Ls[(j0 + 0) * lds + r] * pc[0] + Ls[(j0 + 1) * lds + r] * pc[1] +
-                              Ls[(j0 + 2) * lds + r] * pc[2];
-            const double s1 = Ls[(j0 + 3) * lds + r] * pc[3] + Ls[(j0 + 4) * lds + r] * pc[4] +
-                              Ls[(j0 + 5) * lds + r] * pc[5];
-            Ls[c * lds + r] -= s0 + s1;
+            const double s0 = Ls[(j0 + 0) * LLD + r] * pc[0] + Ls[(j0 + 1) * LLD + r] * pc[1] +
+                              Ls[(j0 + 2) * LLD + r] * pc[2];
+            const double s1 = Ls[(j0 + 3) * LLD + r] * pc[3] + Ls[(j0 + 4) * LLD + r] * pc[4] +
+                              Ls[(j0 + 5) * LLD + r] * pc[5];
+            Ls[c * LLD + r] -= s0 + s1;
         }
     }
 }
 
 // the 6 columns right after panel j0 (the next panel), one matrix element per thread:
 // column = tid >> 7, row = j0 + 6 + (tid & 127)   (needs blockDim >= 768, nc <= 128)
-__device__ __forceinline__ void panel_update_next(double* __restrict__ Ls, int lds, int nc, int j0)
+__device__ __forceinline__ void panel_update_next(double* __restrict__ Ls, int nc, int j0)
 {
     const int cc = threadIdx.x >> 7, rr = threadIdx.x & 127;
     const int c = j0 + 6 + cc, r = j0 + 6 + rr;
     if (cc < 6 && c < nc && r < nc && r >= c)
     {
-        const double s0 = Ls[(j0 + 0) * lds + r] * Ls[(j0 + 0) * lds + c] +
-                          Ls[(j0 + 1) * lds + r] * Ls[(j0 + 1) * lds + c] +
-                          Ls[(j0 + 2) * lds + r] * Ls[(j0 + 2) * lds + c];
-        const double s1 = Ls[(j0 + 3) * lds + r] * Ls[(j0 + 3) * lds + c] +
-                          Ls[(j0 + 4) * lds + r] * Ls[(j0 + 4) * lds + c] +
-                          Ls[(j0 + 5) * lds + r] * Ls[(j0 + 5) * lds + c];
-        Ls[c * lds + r] -= s0 + s1;
+        const double s0 = Ls[(j0 + 0) * LLD + r] * Ls[(j0 + 0) * LLD + c] +
+                          Ls[(j0 + 1) * LLD + r] * Ls[(j0 + 1) * LLD + c] +
+                          Ls[(j0 + 2) * LLD + r] * Ls[(j0 + 2) * LLD + c];
+        const double s1 = Ls[(j0 + 3) * LLD + r] * Ls[(j0 + 3) * LLD + c] +
+                          Ls[(j0 + 4) * LLD + r] * Ls[(j0 + 4) * LLD + c] +
+                          Ls[(j0 + 5) * LLD + r] * Ls[(j0 + 5) * LLD + c];
+        Ls[c * LLD + r] -= s0 + s1;
     }
 }
 
@@ -382,12 +398,11 @@ __device__ __forceinline__ void panel_update_next(double* __restrict__ Ls, int l
 __device__ __forceinline__ void dev_potrf(const double* __restrict__ F, long ld, int nc, double* __restrict__ Ls,
                           double* __restrict__ dinv, int32_t* __restrict__ fail)
 {
-    const int lds = pad16(nc) + 1;
     dev_load_l11(F, ld, nc, Ls);
     __syncthreads();
     stamp(0, 2);
     if (threadIdx.x < 64)
-        if (panel_factor_wave(Ls, lds, nc, 0, dinv))
+        if (panel_factor_wave(Ls, nc, 0, dinv))
             *fail = 1;
     __syncthreads();
     stamp(0, 3);
@@ -397,17 +412,17 @@ __device__ __forceinline__ void dev_potrf(const double* __restrict__ F, long ld,
         if (jn >= nc)
             break;
         if (blockDim.x >= 768)
-            panel_update_next(Ls, lds, nc, j0); // next panel's columns, one element per thread
+            panel_update_next(Ls, nc, j0); // next panel's columns, one element per thread
         else
-            panel_update_cols(Ls, lds, nc, j0, jn, min(jn + 6, nc), 0);
+            panel_update_cols(Ls, nc, j0, jn, min(jn + 6, nc), 0);
         __syncthreads();
         if (threadIdx.x < 64)
         {
-            if (panel_factor_wave(Ls, lds, nc, jn, dinv))
+            if (panel_factor_wave(Ls, nc, jn, dinv))
                 *fail = 1;
         }
         else
-            panel_update_cols(Ls, lds, nc, j0, jn + 6, nc, 64); // the rest, meanwhile
+            panel_update_cols(Ls, nc, j0, jn + 6, nc, 64); // the rest, meanwhile
         __syncthreads();
     }
     stamp(0, 4);
@@ -418,7 +433,6 @@ __device__ __forceinline__ void dev_potrf(const double* __restrict__ F, long ld,
 // LDS (fully unrolled: the v's stay in registers).  Vs[J][n*17 + k] = V_J[n][k].
 __device__ __forceinline__ void dev_inv_diag16(const double* __restrict__ Ls, int ncp, double* __restrict__ Vs)
 {
-    const int lds = ncp + 1;
     const int grp = threadIdx.x >> 4, c = threadIdx.x & 15;
     if (grp >= (ncp >> 4))
         return;
@@ -429,7 +443,7 @@ __device__ __forceinline__ void dev_inv_diag16(const double* __restrict__ Ls, in
 #pragma unroll
     for (int i = 0; i < 16; i++)
     {
-        di[i] = 1.0 / Ls[(J + i) * lds + J + i]; // independent divisions, off the chain
+        di[i] = 1.0 / Ls[(J + i) * LLD + J + i]; // independent divisions, off the chain
         sacc[i] = (i == c) ? 1.0 : 0.0;
     }
 #pragma unroll
@@ -439,7 +453,7 @@ __device__ __forceinline__ void dev_inv_diag16(const double* __restrict__ Ls, in
 #pragma unroll
         for (int i = 0; i < 16; i++)
             if (i > k)
-                sacc[i] -= Ls[(J + k) * lds + J + i] * v[k];
+                sacc[i] -= Ls[(J + k) * LLD + J + i] * v[k];
     }
     double* V = Vs + grp * (16 * 17);
 #pragma unroll
@@ -458,7 +472,7 @@ __device__ __forceinline__ void dev_inv_diag16(const double* __restrict__ Ls, in
 __device__ __forceinline__ void dev_winv(const double* __restrict__ Ls, int ncp, const double* __restrict__ Vs,
                                          double* __restrict__ Wg)
 {
-    const int lds = ncp + 1, nblk = ncp >> 4;
+    const int nblk = ncp >> 4;
     const int J = threadIdx.x >> 6, lane = threadIdx.x & 63, ln = lane & 15, lk = lane >> 4;
     if (J >= nblk)
         return;
@@ -480,7 +494,7 @@ __device__ __forceinline__ void dev_winv(const double* __restrict__ Ls, int ncp,
                 double a[4];
 #pragma unroll
                 for (int kk = 0; kk < 4; kk++)
-                    a[kk] = Ls[(16 * (J + e) + lk + 4 * kk) * lds + 16 * I + ln]; // L_IK[m][k]
+                    a[kk] = Ls[(16 * (J + e) + lk + 4 * kk) * LLD + 16 * I + ln]; // L_IK[m][k]
 #pragma unroll
                 for (int kk = 0; kk < 4; kk++)
                     T = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], Wr[e][kk], T, 0, 0, 0);
@@ -811,9 +825,9 @@ __global__ __launch_bounds__(BIG) void k_subtree_factor(CholPlanDev p, double* _
         double* F = fronts + p.off[f];
         const int ncp = pad16(ncs);
         double* Ls = lds;
-        double* dinv = lds + ncp * (ncp + 1);
-        double* Vs = dinv + ncp;
-        double* Bt = Vs + (ncp >> 4) * (16 * 17);
+        double* dinv = lds + NC_MAX * LLD;
+        double* Vs = dinv + NC_MAX;
+        double* Bt = Vs + (NC_MAX >> 4) * (16 * 17);
         double* Wg = p.winv + p.woff[f];
         dev_extend_add(p, fronts, f, 0, nb);
         dev_potrf(F, ld, ncs, Ls, dinv, fail);
@@ -857,8 +871,8 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
     const int ncp = pad16(ncs);
     stamp(0, 1);
     double* Ls = lds;
-    double* dinv = lds + ncp * (ncp + 1);
-    double* Vs = dinv + ncp;
+    double* dinv = lds + NC_MAX * LLD;
+    double* Vs = dinv + NC_MAX;
     dev_potrf(fronts + p.off[f], 6L * p.nb[f] + 1, ncs, Ls, dinv, fail);
     __syncthreads();
     dev_inv_diag16(Ls, ncp, Vs);
@@ -935,11 +949,12 @@ namespace cugo_k
 
 size_t chol_lds_factor_bytes(int nc_max)
 { // subtree / potrf kernels: L11 + dinv + inverted diagonal blocks + one trsm B tile, or the syrk panels
-    const size_t ncp = (size_t)((nc_max + 15) & ~15);
-    const size_t trsm = ncp * (ncp + 2) + (ncp >> 4) * (16 * 17) + ncp * (size_t)PSTB;
+    (void)nc_max; // fixed layout (LLD): see dev_load_l11
+    const size_t trsm = (size_t)NC_MAX * LLD + NC_MAX + (NC_MAX >> 4) * (16 * 17) + (size_t)NC_MAX * PSTB;
     const size_t syrk = (size_t)syrk_lds();
     return (std::max(trsm, syrk) + 8) * sizeof(double);
 }
+int chol_max_pivot_cols() { return NC_MAX; }
 size_t chol_lds_trsm_bytes(int nc_max)
 {
     const size_t ncp = (size_t)((nc_max + 15) & ~15);

@@ -129,5 +129,6 @@ void set_debug_stamps(long long* d_buf); // diagnostic s_memtime stamps (nullptr
 size_t chol_lds_factor_bytes(int nc_max);
 size_t chol_lds_backward_bytes(int nc_max, long ld_max);
 size_t chol_lds_trsm_bytes(int nc_max);
+int chol_max_pivot_cols(); // widest pivot block the kernels support (scalars)
 
 } // namespace cugo_k

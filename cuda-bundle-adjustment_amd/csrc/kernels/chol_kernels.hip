@@ -344,15 +344,15 @@ __device__ __forceinline__ bool panel_factor_wave(double* __restrict__ Ls, int n
 }
 
 // columns [c_lo, c_hi) of the LDS matrix -= (panel at j0)(panel at j0)^T, lower part only;
-// executed by the threads with tid0 <= threadIdx.x (32 lanes walk the rows of a column).
+// executed by a subset of `nthreads` threads, t = index within the subset (t < 0: not a member);
+// 32 lanes walk the rows of a column.
 // The 6-term dot product is split in two chains: a dependent fp64 FMA costs ~40 cycles.
 __device__ __forceinline__ void panel_update_cols(double* __restrict__ Ls, int nc, int j0,
-                                                  int c_lo, int c_hi, int tid0)
+                                                  int c_lo, int c_hi, int t, int nthreads)
 {
-    const int t = (int)threadIdx.x - tid0;
     if (t < 0)
         return;
-    const int tx = t & 31, ty = t >> 5, nty = ((int)blockDim.x - tid0) >> 5;
+    const int tx = t & 31, ty = t >> 5, nty = nthreads >> 5;
     for (int c = c_lo + ty; c < c_hi; c += nty)
     {
         double pc[6];
@@ -366,6 +366,51 @@ __device__ __forceinline__ void panel_update_cols(double* __restrict__ Ls, int n
             const double s1 = Ls[(j0 + 3) * LLD + r] * pc[3] + Ls[(j0 + 4) * LLD + r] * pc[4] +
                               Ls[(j0 + 5) * LLD + r] * pc[5];
             Ls[c * LLD + r] -= s0 + s1;
+        }
+    }
+}
+
+// Trailing update on the matrix cores: columns [c0, NC) of the LDS matrix -= P P^T with P the
+// 6-column panel at j0, in 16x16 tiles dealt to `nw` waves (widx = index of this wave, < 0: not a
+// member).  K = 6 is two v_mfma_f64_16x16x4 steps (k = 4,5 in the second, upper lanes zero).
+// About 20 instructions per 256 elements instead of ~14 per element with vector FMAs: a wave
+// issues roughly one instruction per 8 cycles, so instruction count is what matters here.
+// Diagonal tiles also write their upper half (never read); rows/columns >= NC_MAX are masked.
+__device__ __forceinline__ void panel_update_mfma(double* __restrict__ Ls, int nc, int j0, int c0,
+                                                  int widx, int nw)
+{
+    if (widx < 0 || c0 >= nc)
+        return;
+    const int lane = threadIdx.x & 63, ln = lane & 15, lk = lane >> 4;
+    const int nt = (nc - c0 + 15) >> 4;
+    const int ntiles = nt * (nt + 1) / 2;
+    const double* P0 = Ls + (j0 + lk) * LLD;               // k = lk
+    const double* P1 = Ls + (j0 + 4 + (lk & 1)) * LLD;     // k = 4 + lk (lk < 2)
+    for (int t = widx; t < ntiles; t += nw)
+    {
+        int tj = 0, rem = t; // unrank: tile column tj has nt - tj tiles
+        while (rem >= nt - tj)
+        {
+            rem -= nt - tj;
+            tj++;
+        }
+        const int R = c0 + 16 * (tj + rem), C = c0 + 16 * tj;
+        const int ra = min(R + ln, NC_MAX - 1), cb = min(C + ln, NC_MAX - 1);
+        const double a0 = -P0[ra], b0 = P0[cb];
+        const double a1 = lk < 2 ? -P1[ra] : 0.0, b1 = lk < 2 ? P1[cb] : 0.0;
+        double4_t acc;
+        double* Cc = Ls + cb * LLD;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            acc[q] = Cc[min(R + lk + 4 * q, NC_MAX - 1)];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
+        if (C + ln < NC_MAX)
+        {
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (R + lk + 4 * q < NC_MAX)
+                    Cc[R + lk + 4 * q] = acc[q];
         }
     }
 }
@@ -399,6 +444,8 @@ __device__ __forceinline__ void dev_potrf(const double* __restrict__ F, long ld,
                           double* __restrict__ dinv, int32_t* __restrict__ fail)
 {
     dev_load_l11(F, ld, nc, Ls);
+    if (threadIdx.x < NC_MAX)
+        dinv[threadIdx.x] = 1.0; // identity padding; the panels overwrite the real columns
     __syncthreads();
     stamp(0, 2);
     if (threadIdx.x < 64)
@@ -414,7 +461,7 @@ __device__ __forceinline__ void dev_potrf(const double* __restrict__ F, long ld,
         if (blockDim.x >= 768)
             panel_update_next(Ls, nc, j0); // next panel's columns, one element per thread
         else
-            panel_update_cols(Ls, nc, j0, jn, min(jn + 6, nc), 0);
+            panel_update_cols(Ls, nc, j0, jn, min(jn + 6, nc), threadIdx.x, blockDim.x);
         __syncthreads();
         if (threadIdx.x < 64)
         {
@@ -422,43 +469,58 @@ __device__ __forceinline__ void dev_potrf(const double* __restrict__ F, long ld,
                 *fail = 1;
         }
         else
-            panel_update_cols(Ls, nc, j0, jn + 6, nc, 64); // the rest, meanwhile
+            panel_update_mfma(Ls, nc, j0, jn + 6, (int)(threadIdx.x >> 6) - 1, (int)(blockDim.x >> 6) - 1); // the rest, meanwhile
         __syncthreads();
     }
     stamp(0, 4);
 }
 
-// V_J = inverse of the J-th 16x16 diagonal block of L11 (lower triangular), one 16-lane group
-// per block, lane c builds column c by forward substitution with the block of L broadcast from
-// LDS (fully unrolled: the v's stay in registers).  Vs[J][n*17 + k] = V_J[n][k].
-__device__ __forceinline__ void dev_inv_diag16(const double* __restrict__ Ls, int ncp, double* __restrict__ Vs)
+// V = inverse of the 16x16 diagonal block `blk` of L11 (lower triangular) by 16 lanes: lane c
+// builds column c by forward substitution with the block of L broadcast from LDS (fully
+// unrolled: the v's stay in registers).  Vs[blk][n*17 + k] = V[n][k]; when Wg != nullptr the
+// block is also written to the global W (column-major, leading dimension ncp).
+__device__ __forceinline__ void inv_diag16_block(const double* __restrict__ Ls, const double* __restrict__ dinv,
+                                                 int blk, int c, double* __restrict__ Vs,
+                                                 double* __restrict__ Wg, int ncp)
 {
-    const int grp = threadIdx.x >> 4, c = threadIdx.x & 15;
-    if (grp >= (ncp >> 4))
-        return;
-    const int J = 16 * grp;
-    // right-looking forward substitution: once v[k] is known every later row is updated at
-    // once (independent FMAs), so the dependent chain is 16 x (mul + fma), not 120 FMAs
-    double v[16], sacc[16], di[16];
+    const double* Lb = Ls + (16 * blk) * LLD + 16 * blk;
+    const double* di = dinv + 16 * blk; // reciprocal diagonal from the panel factorisation
+    // right-looking forward substitution, in place: v[k] = e_c, then for k = 0..15
+    // v[k] *= 1/L[k][k] and every later row is updated at once (independent FMAs), so the
+    // dependent chain is 16 x (mul + fma), not 120 FMAs.  16 doubles of registers per lane.
+    double v[16];
 #pragma unroll
     for (int i = 0; i < 16; i++)
-    {
-        di[i] = 1.0 / Ls[(J + i) * LLD + J + i]; // independent divisions, off the chain
-        sacc[i] = (i == c) ? 1.0 : 0.0;
-    }
+        v[i] = (i == c) ? 1.0 : 0.0;
 #pragma unroll
     for (int k = 0; k < 16; k++)
     {
-        v[k] = sacc[k] * di[k];
+        v[k] *= di[k];
 #pragma unroll
         for (int i = 0; i < 16; i++)
             if (i > k)
-                sacc[i] -= Ls[(J + k) * LLD + J + i] * v[k];
+                v[i] -= Lb[k * LLD + i] * v[k];
     }
-    double* V = Vs + grp * (16 * 17);
+    double* V = Vs + blk * (16 * 17);
 #pragma unroll
     for (int i = 0; i < 16; i++)
         V[i * 17 + c] = (i >= c) ? v[i] : 0.0;
+    if (Wg)
+    {
+        double* wc = Wg + (long)(16 * blk + c) * ncp + 16 * blk;
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            wc[i] = (i >= c) ? v[i] : 0.0;
+    }
+}
+
+// all diagonal blocks at once, one 16-lane group per block
+__device__ __forceinline__ void dev_inv_diag16(const double* __restrict__ Ls, const double* __restrict__ dinv,
+                                               int ncp, double* __restrict__ Vs)
+{
+    const int grp = threadIdx.x >> 4, c = threadIdx.x & 15;
+    if (grp < (ncp >> 4))
+        inv_diag16_block(Ls, dinv, grp, c, Vs, nullptr, ncp);
 }
 
 // W = L11^-1 (lower triangular, ncp x ncp with the identity padding) on the f64 matrix cores,
@@ -832,7 +894,7 @@ __global__ __launch_bounds__(BIG) void k_subtree_factor(CholPlanDev p, double* _
         dev_extend_add(p, fronts, f, 0, nb);
         dev_potrf(F, ld, ncs, Ls, dinv, fail);
         __syncthreads();
-        dev_inv_diag16(Ls, ncp, Vs);
+        dev_inv_diag16(Ls, dinv, ncp, Vs);
         __syncthreads();
         dev_winv(Ls, ncp, Vs, Wg);
         __threadfence_block();
@@ -875,12 +937,14 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
     double* Vs = dinv + NC_MAX;
     dev_potrf(fronts + p.off[f], 6L * p.nb[f] + 1, ncs, Ls, dinv, fail);
     __syncthreads();
-    dev_inv_diag16(Ls, ncp, Vs);
-    __syncthreads();
     stamp(0, 5);
+    // one wave per diagonal block (16 lanes each): V_J = inverse of the 16x16 diagonal block
+    if ((threadIdx.x & 63) < 16 && (int)(threadIdx.x >> 6) < (ncp >> 4))
+        inv_diag16_block(Ls, dinv, threadIdx.x >> 6, threadIdx.x & 15, Vs, nullptr, ncp);
+    __syncthreads();
     dev_winv(Ls, ncp, Vs, p.winv + p.woff[f]);
-    stamp(0, 7);
     stamp_value(0, 6, ncs);
+    stamp(0, 7);
 }
 
 // trsm tiles (touch the pivot columns; LDS = one 64-row B tile) and, in the same launch, the extend-add of the
@@ -954,6 +1018,10 @@ size_t chol_lds_factor_bytes(int nc_max)
     const size_t syrk = (size_t)syrk_lds();
     return (std::max(trsm, syrk) + 8) * sizeof(double);
 }
+size_t chol_lds_potrf_bytes()
+{
+    return ((size_t)NC_MAX * LLD + NC_MAX + (NC_MAX >> 4) * (16 * 17) + 8) * sizeof(double);
+}
 int chol_max_pivot_cols() { return NC_MAX; }
 size_t chol_lds_trsm_bytes(int nc_max)
 {
@@ -1008,8 +1076,9 @@ void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fron
     if (neap > 0) // children -> pivot columns
         CUGO_LAUNCH(k_up_extend_add, dim3(neap), dim3(BIG), 0, s, p, d_fronts,
                            d_wl + 3L * eap0);
-    ensure_lds(reinterpret_cast<const void*>(k_up_potrf), lds_bytes);
-    CUGO_LAUNCH(k_up_potrf, dim3(ntasks), dim3(BIG), lds_bytes, s, p, d_fronts, task0, d_fail);
+    ensure_lds(reinterpret_cast<const void*>(k_up_potrf), chol_lds_potrf_bytes());
+    CUGO_LAUNCH(k_up_potrf, dim3(ntasks), dim3(BIG), chol_lds_potrf_bytes(), s, p, d_fronts, task0,
+                d_fail);
     if (ntr + nea > 0)
     {
         const size_t lds_trsm = chol_lds_trsm_bytes(p.nc_max);

@@ -1,3 +1,4 @@
+#include <cmath>
 // micro-benchmarks that calibrate the latency model used for the Cholesky kernels
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -30,6 +31,19 @@ __global__ void k_mfma_ind4(int n, long long* cyc, double* out) { d4 a0 = {0, 0,
 __global__ void k_fma_ind8(int n, long long* cyc, double* out) { double x[8]; for (int i = 0; i < 8; i++) x[i] = threadIdx.x * 1e-3 + i; double y = 1.0000001; long long t0 = clock64(); for (int k = 0; k < n; k++) { for (int i = 0; i < 8; i++) x[i] = fma(x[i], y, 1e-9); } long long t1 = clock64(); if (threadIdx.x == 0) cyc[0] = t1 - t0; double s = 0; for (int i = 0; i < 8; i++) s += x[i]; out[threadIdx.x] = s; }
 __global__ void k_f32_dep(int n, long long* cyc, double* out) { float x = threadIdx.x * 1e-3f, y = 1.0000001f; long long t0 = clock64(); for (int k = 0; k < n; k++) x = fmaf(x, y, 1e-9f); long long t1 = clock64(); if (threadIdx.x == 0) cyc[0] = t1 - t0; out[threadIdx.x] = x; }
 __global__ void k_wallclock(long long* cyc) { long long t0 = clock64(); long long w0 = wall_clock64(); long long w1 = w0; while (w1 - w0 < 100000) w1 = wall_clock64(); long long t1 = clock64(); if (threadIdx.x == 0) { cyc[0] = t1 - t0; cyc[1] = w1 - w0; } }
+
+__global__ void k_rsq_acc(const double* d, double* r0, double* r1, double* r2, int n)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = d[i];
+    double r = __builtin_amdgcn_rsq(x);
+    r0[i] = r;
+    { double t = x * r; double e = fma(-t, r, 1.0); r = fma(0.5 * r, e, r); }
+    r1[i] = r;
+    { double t = x * r; double e = fma(-t, r, 1.0); r = fma(0.5 * r, e, r); }
+    r2[i] = r;
+}
 
 int main()
 {
@@ -95,6 +109,18 @@ int main()
     CK(hipMemcpy(&cyc, dc, 8, hipMemcpyDeviceToHost)); printf("dependent fp32 fma: %.2f ticks\n", (double)cyc / 10000);
     { long long c2[2]; hipLaunchKernelGGL(k_wallclock, dim3(1), dim3(64), 0, s, dc); CK(hipStreamSynchronize(s));
       CK(hipMemcpy(c2, dc, 16, hipMemcpyDeviceToHost)); printf("clock64 ticks per wall_clock64 tick (100 MHz): %.3f => clock64 at %.1f MHz\n", (double)c2[0] / c2[1], 100.0 * c2[0] / c2[1]); }
+    { // accuracy of v_rsq_f64 and of one / two Newton steps on it
+        const int n = 1 << 20; std::vector<double> hd(n), h0(n), h1(n), h2(n);
+        unsigned long long st = 88172645463325252ULL;
+        for (int i = 0; i < n; i++) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; double u = (st >> 11) * (1.0 / 9007199254740992.0); hd[i] = exp(-7.0 + 21.0 * u); }
+        double *dx, *d0, *d1, *d2; CK(hipMalloc(&dx, n * 8)); CK(hipMalloc(&d0, n * 8)); CK(hipMalloc(&d1, n * 8)); CK(hipMalloc(&d2, n * 8));
+        CK(hipMemcpy(dx, hd.data(), n * 8, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_rsq_acc, dim3(n / 256), dim3(256), 0, s, dx, d0, d1, d2, n); CK(hipStreamSynchronize(s));
+        CK(hipMemcpy(h0.data(), d0, n * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(h1.data(), d1, n * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(h2.data(), d2, n * 8, hipMemcpyDeviceToHost));
+        double e0 = 0, e1 = 0, e2 = 0;
+        for (int i = 0; i < n; i++) { long double ref = 1.0L / sqrtl((long double)hd[i]); e0 = fmax(e0, (double)fabsl((h0[i] - ref) / ref)); e1 = fmax(e1, (double)fabsl((h1[i] - ref) / ref)); e2 = fmax(e2, (double)fabsl((h2[i] - ref) / ref)); }
+        printf("v_rsq_f64 max rel err %.3e ; +1 Newton %.3e ; +2 Newton %.3e (eps = 2.2e-16)\n", e0, e1, e2);
+    }
     // wall time of the fma kernel to convert ticks -> ns
     CK(hipEventRecord(a, s));
     hipLaunchKernelGGL(k_fmachain, dim3(1), dim3(64), 0, s, 2000000, dc, dd);

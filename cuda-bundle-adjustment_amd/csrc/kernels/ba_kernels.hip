@@ -513,10 +513,19 @@ __global__ __launch_bounds__(BS) void k_hsc_diag(EV ev, const int32_t* __restric
 // ---------------------------------------------------------------- Schur: off-diagonal --
 // one wave per Hsc block k: Hsc[k] = - sum_{(ei,ej)} T[ei] Hpl[ej]^T
 // (ref: computeHschureKernel .cu:1327-1345, which uses 36 atomics per product instead).
-// Each LANE takes whole products (lane, lane+64, ... of the block's contribution list): its
-// two 144-B operands are contiguous, so they are fetched with 16-B loads that are all in flight
-// at once, and the 6x6 result is accumulated in 36 registers.  The 64 per-lane partial blocks
-// are then summed with a fixed xor-butterfly (bit-reproducible) and stored by lanes 0..35.
+// The vector memory path handles roughly one cache line per ~4 cycles per CU, so what counts is
+// the number of lines a load instruction touches.  A chunk of 7 products is fetched by ONE pair
+// of 16-B loads: lanes 9j..9j+8 read the contiguous 144-B T block (resp. Hpl block) of product j
+// — ~2 lines per product instead of 64 lines per instruction with a lane-per-product gather.
+// The operands go through a per-wave LDS slot; then LANE = OUTPUT ELEMENT (r,c), 36 of 64 lanes,
+// accumulates its own element over the chunk: no cross-lane reduction, summation in list order
+// (bit-reproducible).  The next chunk's loads are in flight while the current one is consumed.
+constexpr int OD_CH = 14; // products per chunk: two 7-product groups per load round
+__device__ __forceinline__ void wave_sync_lds()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
 __global__ __launch_bounds__(BS) void k_hsc_offdiag(int nblocks,
                                                     const int32_t* __restrict__ off_ptr,
                                                     const int32_t* __restrict__ off_ei,
@@ -525,47 +534,66 @@ __global__ __launch_bounds__(BS) void k_hsc_offdiag(int nblocks,
                                                     const double* __restrict__ T,
                                                     double* __restrict__ Hsc)
 {
-    const int lane = threadIdx.x & 63;
-    const int k = blockIdx.x * (BS / 64) + (threadIdx.x >> 6);
+    __shared__ double2 stage[BS / 64][2][OD_CH * 9 + 1];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int k = blockIdx.x * (BS / 64) + w;
     if (k >= nblocks)
-        return;
+        return; // whole wave
+    const int lc = lane < 36 ? lane : 35; // idle lanes shadow lane 35
+    const int r = lc % 6, c = lc / 6;
+    const int pj = min(lane / 9, 6), part = lane - 9 * (lane / 9); // lane 63 shadows product 6
+    const bool writer = lane < 63;
     const int beg = off_ptr[k], end = off_ptr[k + 1];
-    double acc[36];
-#pragma unroll
-    for (int i = 0; i < 36; i++)
-        acc[i] = 0;
-    for (int idx = beg + lane; idx < end; idx += 64)
+    const double* sT = reinterpret_cast<const double*>(stage[w][0]);
+    const double* sH = reinterpret_cast<const double*>(stage[w][1]);
+    double acc = 0;
+    if (beg >= end)
     {
-        const int ei = off_ei[idx], ej = off_ej[idx];
-        const double2* pt = reinterpret_cast<const double2*>(T + 18 * (size_t)ei);
-        const double2* ph = reinterpret_cast<const double2*>(Hpl + 18 * (size_t)ej);
-        double t[18], h[18];
-#pragma unroll
-        for (int i = 0; i < 9; i++)
-        {
-            const double2 a = pt[i], b = ph[i];
-            t[2 * i] = a.x, t[2 * i + 1] = a.y;
-            h[2 * i] = b.x, h[2 * i + 1] = b.y;
-        }
-#pragma unroll
-        for (int c = 0; c < 6; c++)
-#pragma unroll
-            for (int r = 0; r < 6; r++)
-                acc[c * 6 + r] += t[r] * h[c] + t[6 + r] * h[6 + c] + t[12 + r] * h[12 + c];
+        if (lane < 36)
+            Hsc[36 * (size_t)k + lane] = 0.0;
+        return;
     }
-    double mine = 0;
-#pragma unroll
-    for (int v = 0; v < 36; v++)
+    // software pipeline: index pairs two chunks ahead, operands one chunk ahead
+    // (scalars, not arrays: the compiler parks small indexed arrays in scratch memory)
+    const double2* Tq = reinterpret_cast<const double2*>(T) + part;
+    const double2* Hq = reinterpret_cast<const double2*>(Hpl) + part;
+    int j0 = min(beg + pj, end - 1), j1 = min(beg + pj + 7, end - 1); // clamped: surplus lanes re-read the last product
+    int ei0 = off_ei[j0], ej0 = off_ej[j0], ei1 = off_ei[j1], ej1 = off_ej[j1];
+    double2 tv0 = Tq[9 * (size_t)ei0], hv0 = Hq[9 * (size_t)ej0];
+    double2 tv1 = Tq[9 * (size_t)ei1], hv1 = Hq[9 * (size_t)ej1];
+    j0 = min(beg + OD_CH + pj, end - 1), j1 = min(beg + OD_CH + pj + 7, end - 1);
+    ei0 = off_ei[j0], ej0 = off_ej[j0], ei1 = off_ei[j1], ej1 = off_ej[j1];
+    double2* w0 = &stage[w][0][9 * pj + part];
+    double2* w1 = &stage[w][1][9 * pj + part];
+    for (int idx = beg; idx < end; idx += OD_CH)
     {
-        double sum = acc[v];
+        if (writer)
+        {
+            w0[0] = tv0, w1[0] = hv0;
+            w0[63] = tv1, w1[63] = hv1;
+        }
+        if (idx + OD_CH < end)
+        {
+            tv0 = Tq[9 * (size_t)ei0], hv0 = Hq[9 * (size_t)ej0];
+            tv1 = Tq[9 * (size_t)ei1], hv1 = Hq[9 * (size_t)ej1];
+            j0 = min(idx + 2 * OD_CH + pj, end - 1), j1 = min(idx + 2 * OD_CH + pj + 7, end - 1);
+            ei0 = off_ei[j0], ej0 = off_ej[j0], ei1 = off_ei[j1], ej1 = off_ej[j1];
+        }
+        wave_sync_lds();
+        const int n = min(OD_CH, end - idx);
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1)
-            sum += __shfl_xor(sum, off, 64);
-        if (lane == v)
-            mine = sum;
+        for (int u = 0; u < OD_CH; u++)
+            if (u < n) // wave-uniform
+            {
+                double s = sT[18 * u + r] * sH[18 * u + c];
+                s = fma(sT[18 * u + 6 + r], sH[18 * u + 6 + c], s);
+                s = fma(sT[18 * u + 12 + r], sH[18 * u + 12 + c], s);
+                acc += s;
+            }
+        wave_sync_lds(); // the slot is rewritten by the next iteration
     }
     if (lane < 36)
-        Hsc[36 * (size_t)k + lane] = -mine;
+        Hsc[36 * (size_t)k + lane] = -acc;
 }
 
 // ---------------------------------------------------------------- back-substitution ----

@@ -298,7 +298,42 @@ void Engine::initialize(FlatGraph&& g)
     shard_range(lm_cnt, m.rank, m.world, l0, l1);
     m.shard_l0 = l0, m.shard_l1 = l1;
     const int e_begin = lm_cnt[l0], e_end = lm_cnt[l1];
-    const int E = e_end - e_begin;
+    // Slot layout of this shard's edges: landmark-major, padded with inactive slots so that no
+    // landmark with <= 256 edges straddles a 256-slot boundary (k_build_edges / the back-
+    // substitution sum a landmark's edges inside one workgroup).  A padding slot belongs to
+    // the landmark before it; slot_src[i] = index into `order`, or -1 for padding.
+    constexpr int kBlock = 256;
+    std::vector<int32_t> slot_src;
+    slot_src.reserve((size_t)(e_end - e_begin) + (e_end - e_begin) / 32 + kBlock);
+    m.h_lm_ptr.assign(m.Lall + 1, 0);
+    {
+        int last_l = -1; // last landmark that owns slots
+        for (int l = l0; l < l1; l++)
+        {
+            const int k = lm_cnt[l + 1] - lm_cnt[l];
+            int pos = (int)slot_src.size();
+            if (k > 0 && k <= kBlock && pos % kBlock + k > kBlock && last_l >= 0)
+            {
+                const int pad = kBlock - pos % kBlock;
+                slot_src.insert(slot_src.end(), pad, -1);
+                pos += pad;
+                for (int q = last_l + 1; q <= l; q++)
+                    m.h_lm_ptr[q] = pos; // the padding extends landmark last_l
+            }
+            m.h_lm_ptr[l] = pos;
+            for (int i = lm_cnt[l]; i < lm_cnt[l + 1]; i++)
+                slot_src.push_back(i);
+            if (k > 0)
+                last_l = l;
+        }
+        const int total = (int)slot_src.size();
+        for (int l = l1; l <= m.Lall; l++)
+            m.h_lm_ptr[l] = total;
+        // lm_ptr[l] for l < l0 stays 0; fix up the entries between padded landmarks
+        for (int l = l0 + 1; l <= l1; l++)
+            m.h_lm_ptr[l] = std::max(m.h_lm_ptr[l], m.h_lm_ptr[l - 1]);
+    }
+    const int E = (int)slot_src.size();
     m.E = E;
     m.h_e_pose.resize(E), m.h_e_lm.resize(E), m.h_flags.resize(E);
     std::vector<double> meas(3 * (size_t)E), omega;
@@ -313,7 +348,19 @@ void Engine::initialize(FlatGraph&& g)
         cam.resize(E);
     for (int i = 0; i < E; i++)
     {
-        const int e = order[e_begin + i];
+        if (slot_src[i] < 0)
+        { // padding: inactive edge of the previous slot's landmark
+            m.h_e_pose[i] = 0;
+            m.h_e_lm[i] = m.h_e_lm[i - 1];
+            m.h_flags[i] = CUGO_EDGE_INACTIVE;
+            meas[i] = meas[(size_t)E + i] = meas[2 * (size_t)E + i] = 0.0;
+            if (m.n_omega > 1)
+                omega[i] = 0.0;
+            if (m.n_cams > 1)
+                cam[i] = 0;
+            continue;
+        }
+        const int e = order[slot_src[i]];
         m.h_e_pose[i] = g.e_pose[e];
         m.h_e_lm[i] = g.e_lm[e];
         m.h_flags[i] = g.e_flags[e];
@@ -325,25 +372,19 @@ void Engine::initialize(FlatGraph&& g)
         if (m.n_cams > 1)
             cam[i] = g.e_cam[e];
     }
-    m.h_lm_ptr.assign(m.Lall + 1, 0);
-    for (int l = 0; l < m.Lall; l++)
-    {
-        const int a = std::min(std::max(lm_cnt[l], e_begin), e_end) - e_begin;
-        const int b = std::min(std::max(lm_cnt[l + 1], e_begin), e_end) - e_begin;
-        m.h_lm_ptr[l] = a;
-        m.h_lm_ptr[l + 1] = b;
-    }
     // ---- pose-major view (stable counting sort => ascending landmark inside a pose) ----
     m.h_pose_ptr.assign(m.Pall + 1, 0);
     for (int i = 0; i < E; i++)
-        m.h_pose_ptr[m.h_e_pose[i] + 1]++;
+        if (slot_src[i] >= 0)
+            m.h_pose_ptr[m.h_e_pose[i] + 1]++;
     for (int p = 0; p < m.Pall; p++)
         m.h_pose_ptr[p + 1] += m.h_pose_ptr[p];
-    m.h_pose_edge.resize(E);
+    m.h_pose_edge.assign(std::max(E, 1), 0);
     {
         std::vector<int32_t> pos(m.h_pose_ptr.begin(), m.h_pose_ptr.end() - 1);
         for (int i = 0; i < E; i++)
-            m.h_pose_edge[pos[m.h_e_pose[i]]++] = i;
+            if (slot_src[i] >= 0)
+                m.h_pose_edge[pos[m.h_e_pose[i]]++] = i;
     }
     // ---- upload --------------------------------------------------------------------------
     m.d_e_pose.upload(m.h_e_pose, s), m.d_e_lm.upload(m.h_e_lm, s), m.d_flags.upload(m.h_flags, s);

@@ -162,19 +162,57 @@ __global__ __launch_bounds__(BS) void k_errors(EV ev, const double* __restrict__
         partials[blockIdx.x] = chi;
 }
 
-// ---------------------------------------------------------------- build: edges ---------
-// Hpl[e] = w JP^T JL (6x3 col-major), one lane per edge; also chi2 partials
+// ---------------------------------------------------------------- build: edges + landmarks
+// One lane per edge: residual and Jacobians are evaluated ONCE and feed both
+//   Hpl[e] = w JP^T JL (6x3 col-major, global) and the chi2 partials, and
+//   the edge's landmark contribution w JL^T [JL | e] (9 values, LDS).
+// Edges are landmark-major, so the edges of a landmark are consecutive lanes: the lane that
+// holds a landmark's FIRST edge sums the contributions of its edges from LDS in edge order
+// (fixed order, no atomics) and writes Hll[l], bl[l].  The engine pads the edge array with
+// inactive edges so that no landmark straddles a 256-edge block; for arbitrary layouts
+// (kernel-level C ABI) the owner recomputes the few edges that lie beyond its block.
+// Thread i of the grid also zero-fills landmark i if it has no edge at all.
+struct LmContrib
+{
+    double h00, h01, h02, h11, h12, h22, b0, b1, b2;
+};
+__device__ __forceinline__ LmContrib lm_contrib(const double JL[3][3], const EdgeGeom& g, bool stereo)
+{
+    const int dim = stereo ? 3 : 2;
+    double s00 = 0, s01 = 0, s02 = 0, s11 = 0, s12 = 0, s22 = 0, t0 = 0, t1 = 0, t2 = 0;
+    for (int m = 0; m < dim; m++)
+    {
+        s00 += JL[m][0] * JL[m][0];
+        s01 += JL[m][0] * JL[m][1];
+        s02 += JL[m][0] * JL[m][2];
+        s11 += JL[m][1] * JL[m][1];
+        s12 += JL[m][1] * JL[m][2];
+        s22 += JL[m][2] * JL[m][2];
+        t0 += JL[m][0] * g.e[m];
+        t1 += JL[m][1] * g.e[m];
+        t2 += JL[m][2] * g.e[m];
+    }
+    return LmContrib{g.w * s00, g.w * s01, g.w * s02, g.w * s11, g.w * s12, g.w * s22,
+                     g.w * t0, g.w * t1, g.w * t2};
+}
+
 __global__ __launch_bounds__(BS) void k_build_edges(EV ev, const double* __restrict__ poses,
                                                     const double* __restrict__ lms, Robust2 rk,
                                                     double* __restrict__ Hpl,
+                                                    double* __restrict__ Hll,
+                                                    double* __restrict__ bl,
                                                     double* __restrict__ partials)
 {
     __shared__ double sm[BS / 64];
+    __shared__ double cs[9][BS];
     const int e = blockIdx.x * BS + threadIdx.x;
     double chi = 0;
+    LmContrib lc = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int l = -1;
     if (e < ev.E)
     {
         const uint8_t fl = ev.flags[e];
+        l = ev.lm[e];
         double H[18];
 #pragma unroll
         for (int i = 0; i < 18; i++)
@@ -187,11 +225,13 @@ __global__ __launch_bounds__(BS) void k_build_edges(EV ev, const double* __restr
             edge_residual(pose, lms + 3 * (size_t)in.il, in.mu, in.mv, in.mr, in.stereo, in.omega,
                           in.cam, in.stereo ? rk.s : rk.m, g);
             chi = g.chi;
+            double JL[3][3];
+            jac_landmark(g.Xc, pose, in.cam, in.stereo, JL);
+            lc = lm_contrib(JL, g, in.stereo);
             if (!(fl & (CUGO_EDGE_FIXED_L | CUGO_EDGE_FIXED_P)))
             {
-                double JP[3][6], JL[3][3];
+                double JP[3][6];
                 jac_pose(g.Xc, in.cam, in.stereo, JP);
-                jac_landmark(g.Xc, pose, in.cam, in.stereo, JL);
 #pragma unroll
                 for (int c = 0; c < 3; c++)
 #pragma unroll
@@ -209,58 +249,56 @@ __global__ __launch_bounds__(BS) void k_build_edges(EV ev, const double* __restr
         for (int i = 0; i < 9; i++)
             dst[i] = make_double2(H[2 * i], H[2 * i + 1]);
     }
-    chi = block_sum(chi, sm);
+    {
+        const int t = threadIdx.x;
+        cs[0][t] = lc.h00, cs[1][t] = lc.h01, cs[2][t] = lc.h02, cs[3][t] = lc.h11, cs[4][t] = lc.h12;
+        cs[5][t] = lc.h22, cs[6][t] = lc.b0, cs[7][t] = lc.b1, cs[8][t] = lc.b2;
+    }
+    chi = block_sum(chi, sm); // contains the barrier that publishes cs[]
     if (threadIdx.x == 0)
         partials[blockIdx.x] = chi;
-}
-
-// ---------------------------------------------------------------- build: landmarks -----
-// Hll[l] = sum w JL^T JL, bl[l] = sum w JL^T e over the landmark's edges, fixed order
-__global__ __launch_bounds__(BS) void k_build_landmarks(EV ev, const double* __restrict__ poses,
-                                                        const double* __restrict__ lms, Robust2 rk,
-                                                        double* __restrict__ Hll,
-                                                        double* __restrict__ bl)
-{
-    const int l = blockIdx.x * BS + threadIdx.x;
-    if (l >= ev.L)
-        return;
-    const double Xw[3] = {lms[3 * (size_t)l], lms[3 * (size_t)l + 1], lms[3 * (size_t)l + 2]};
-    double h00 = 0, h01 = 0, h02 = 0, h11 = 0, h12 = 0, h22 = 0, b0 = 0, b1 = 0, b2 = 0;
-    const int e0 = ev.lm_ptr[l], e1 = ev.lm_ptr[l + 1];
-    for (int e = e0; e < e1; e++)
-    {
-        const uint8_t fl = ev.flags[e];
-        if (fl & CUGO_EDGE_INACTIVE)
-            continue;
-        const EdgeIn in = load_edge(ev, e, fl);
-        const double* pose = poses + 7 * (size_t)in.ip;
-        EdgeGeom g;
-        edge_residual(pose, Xw, in.mu, in.mv, in.mr, in.stereo, in.omega, in.cam, in.stereo ? rk.s : rk.m, g);
-        double JL[3][3];
-        jac_landmark(g.Xc, pose, in.cam, in.stereo, JL);
-        const int dim = in.stereo ? 3 : 2;
-        double s00 = 0, s01 = 0, s02 = 0, s11 = 0, s12 = 0, s22 = 0, t0 = 0, t1 = 0, t2 = 0;
-        for (int m = 0; m < dim; m++)
+    if (l >= 0 && l < ev.L && ev.lm_ptr[l] == e)
+    { // owner of landmark l
+        const int e1 = ev.lm_ptr[l + 1];
+        const int bend = min(e1, (int)(blockIdx.x + 1) * BS);
+        double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int ee = e; ee < bend; ee++)
         {
-            s00 += JL[m][0] * JL[m][0];
-            s01 += JL[m][0] * JL[m][1];
-            s02 += JL[m][0] * JL[m][2];
-            s11 += JL[m][1] * JL[m][1];
-            s12 += JL[m][1] * JL[m][2];
-            s22 += JL[m][2] * JL[m][2];
-            t0 += JL[m][0] * g.e[m];
-            t1 += JL[m][1] * g.e[m];
-            t2 += JL[m][2] * g.e[m];
+            const int t = ee - blockIdx.x * BS;
+#pragma unroll
+            for (int v = 0; v < 9; v++)
+                a[v] += cs[v][t];
         }
-        h00 += g.w * s00, h01 += g.w * s01, h02 += g.w * s02;
-        h11 += g.w * s11, h12 += g.w * s12, h22 += g.w * s22;
-        b0 += g.w * t0, b1 += g.w * t1, b2 += g.w * t2;
+        for (int ee = bend; ee < e1; ee++)
+        { // edges of this landmark beyond the block (never with the engine's padded layout)
+            const uint8_t fl = ev.flags[ee];
+            if (fl & CUGO_EDGE_INACTIVE)
+                continue;
+            const EdgeIn in = load_edge(ev, ee, fl);
+            const double* pose = poses + 7 * (size_t)in.ip;
+            EdgeGeom g;
+            edge_residual(pose, lms + 3 * (size_t)in.il, in.mu, in.mv, in.mr, in.stereo, in.omega,
+                          in.cam, in.stereo ? rk.s : rk.m, g);
+            double JL[3][3];
+            jac_landmark(g.Xc, pose, in.cam, in.stereo, JL);
+            const LmContrib c2 = lm_contrib(JL, g, in.stereo);
+            a[0] += c2.h00, a[1] += c2.h01, a[2] += c2.h02, a[3] += c2.h11, a[4] += c2.h12;
+            a[5] += c2.h22, a[6] += c2.b0, a[7] += c2.b1, a[8] += c2.b2;
+        }
+        double* H = Hll + 9 * (size_t)l;
+        H[0] = a[0], H[1] = a[1], H[2] = a[2];
+        H[3] = a[1], H[4] = a[3], H[5] = a[4];
+        H[6] = a[2], H[7] = a[4], H[8] = a[5];
+        bl[3 * (size_t)l] = a[6], bl[3 * (size_t)l + 1] = a[7], bl[3 * (size_t)l + 2] = a[8];
     }
-    double* H = Hll + 9 * (size_t)l;
-    H[0] = h00, H[1] = h01, H[2] = h02;
-    H[3] = h01, H[4] = h11, H[5] = h12;
-    H[6] = h02, H[7] = h12, H[8] = h22;
-    bl[3 * (size_t)l] = b0, bl[3 * (size_t)l + 1] = b1, bl[3 * (size_t)l + 2] = b2;
+    if (e < ev.L && ev.lm_ptr[e] == ev.lm_ptr[e + 1])
+    { // landmark without any edge
+        double* H = Hll + 9 * (size_t)e;
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+            H[i] = 0;
+        bl[3 * (size_t)e] = 0, bl[3 * (size_t)e + 1] = 0, bl[3 * (size_t)e + 2] = 0;
+    }
 }
 
 // 27 accumulators of one workgroup -> 27 sums, fixed order (thread-major then 8x32 tree)
@@ -711,15 +749,12 @@ void launch_build(hipStream_t s, const cugo_edges& e, const double* d_poses, con
 {
     const EV ev = make_ev(e);
     const Robust2 r{{rk.type, rk.delta}, {rk.type_stereo, rk.delta_stereo}};
-    const int nb = div_up(ev.E, BS);
+    const int nb = div_up(ev.E > ev.L ? ev.E : ev.L, BS); // also covers the edgeless landmarks
     if (nb > 0)
-        CUGO_LAUNCH(k_build_edges, dim3(nb), dim3(BS), 0, s, ev, d_poses, d_lms, r, d_Hpl,
-                           rs.d_partials);
+        CUGO_LAUNCH(k_build_edges, dim3(nb), dim3(BS), 0, s, ev, d_poses, d_lms, r, d_Hpl, d_Hll,
+                           d_bl, rs.d_partials);
     if (d_chi)
         CUGO_LAUNCH(k_sum_partials, dim3(1), dim3(BS), 0, s, rs.d_partials, nb, d_chi);
-    if (ev.L > 0)
-        CUGO_LAUNCH(k_build_landmarks, dim3(div_up(ev.L, BS)), dim3(BS), 0, s, ev, d_poses,
-                           d_lms, r, d_Hll, d_bl);
     if (ev.P > 0)
         CUGO_LAUNCH(k_build_poses, dim3(ev.P), dim3(BS), (27 * BS + 32) * sizeof(double), s,
                            ev, d_poses, d_lms, r, d_Hpp, d_bp);

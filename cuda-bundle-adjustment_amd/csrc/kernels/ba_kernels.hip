@@ -638,6 +638,27 @@ __global__ __launch_bounds__(BS) void k_hsc_offdiag(int nblocks,
 // xl = invHll (bl - sum Hpl^T xp), landmark update, scale partials
 // (ref: schurComplementPostKernel .cu:1419, updateLandmarksKernel .cu:1457,
 //  computeScaleKernel .cu:1471 — fused)
+// One workgroup per 256 consecutive edges.  The 256 Hpl blocks (36 KB, contiguous) are
+// streamed into LDS with fully coalesced 16-B loads — a lane-per-landmark walk over its edges
+// touches 64 cache lines per load instruction and is bound by the vector memory path, not by
+// HBM.  Lane e then forms Hpl[e]^T xp[pose(e)] from LDS, and the lane holding a landmark's
+// first edge subtracts the contributions of its edges in edge order (fixed order) and
+// finishes the landmark.  Edges of a landmark beyond the block (never with the engine's
+// padded layout) are recomputed from global memory by the owner.
+__device__ __forceinline__ void hplT_x(const double* __restrict__ H, const double* __restrict__ x,
+                                       double& s0, double& s1, double& s2)
+{
+    s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+    for (int m = 0; m < 6; m++)
+    {
+        const double xm = x[m];
+        s0 += H[m] * xm;
+        s1 += H[6 + m] * xm;
+        s2 += H[12 + m] * xm;
+    }
+}
+
 __global__ __launch_bounds__(BS) void k_backsubst_landmarks(
     EV ev, double lambda, const double* __restrict__ invHll, const double* __restrict__ bl,
     const double* __restrict__ Hpl, const double* __restrict__ xp, double* __restrict__ xl,
@@ -645,44 +666,82 @@ __global__ __launch_bounds__(BS) void k_backsubst_landmarks(
     double* __restrict__ partials)
 {
     __shared__ double sm[BS / 64];
-    const int l = blockIdx.x * BS + threadIdx.x;
-    double sc = 0;
-    if (l < ev.L)
+    __shared__ double2 hs[BS * 9 + 1];
+    __shared__ double cs[3][BS];
+    const int t = threadIdx.x;
+    const int ebase = blockIdx.x * BS;
+    const int e = ebase + t;
+    { // stream the block's Hpl slots into LDS (zeros past the end)
+        const double2* src = reinterpret_cast<const double2*>(Hpl) + 9 * (size_t)ebase;
+        const long nvalid = 9L * max(0, min(BS, ev.E - ebase));
+        double2 v[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+        {
+            const int idx = i * BS + t;
+            v[i] = src[min((long)idx, max(nvalid - 1, 0L))];
+        }
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+            hs[i * BS + t] = v[i];
+    }
+    int l = -1;
+    bool act = false;
+    double x[6] = {0, 0, 0, 0, 0, 0};
+    if (e < ev.E)
     {
+        l = ev.lm[e];
+        const uint8_t fl = ev.flags[e];
+        act = !(fl & (CUGO_EDGE_FIXED_L | CUGO_EDGE_FIXED_P | CUGO_EDGE_INACTIVE));
+        if (act)
+        {
+            const double2* px = reinterpret_cast<const double2*>(xp + 6 * (size_t)ev.pose[e]);
+            const double2 a = px[0], b = px[1], c = px[2];
+            x[0] = a.x, x[1] = a.y, x[2] = b.x, x[3] = b.y, x[4] = c.x, x[5] = c.y;
+        }
+    }
+    __syncthreads();
+    {
+        double s0 = 0, s1 = 0, s2 = 0;
+        if (act)
+            hplT_x(reinterpret_cast<const double*>(hs) + 18 * t, x, s0, s1, s2);
+        cs[0][t] = s0, cs[1][t] = s1, cs[2][t] = s2;
+    }
+    __syncthreads();
+    double sc = 0;
+    if (l >= 0 && l < ev.L && ev.lm_ptr[l] == e)
+    { // owner of landmark l
         double c0 = bl[3 * (size_t)l], c1 = bl[3 * (size_t)l + 1], c2 = bl[3 * (size_t)l + 2];
         const double b0 = c0, b1 = c1, b2 = c2;
-        const int e0 = ev.lm_ptr[l], e1 = ev.lm_ptr[l + 1];
-        double x0 = 0, x1 = 0, x2 = 0;
-        if (e1 > e0)
-        {
-            for (int e = e0; e < e1; e++)
-            {
-                const uint8_t fl = ev.flags[e];
-                if (fl & (CUGO_EDGE_FIXED_L | CUGO_EDGE_FIXED_P | CUGO_EDGE_INACTIVE))
-                    continue;
-                const double* H = Hpl + 18 * (size_t)e;
-                const double* x = xp + 6 * (size_t)ev.pose[e];
-                double s0 = 0, s1 = 0, s2 = 0;
-#pragma unroll
-                for (int m = 0; m < 6; m++)
-                {
-                    const double xm = x[m];
-                    s0 += H[m] * xm;
-                    s1 += H[6 + m] * xm;
-                    s2 += H[12 + m] * xm;
-                }
-                c0 -= s0, c1 -= s1, c2 -= s2;
-            }
-            const double* iv = invHll + 9 * (size_t)l;
-            x0 = iv[0] * c0 + iv[3] * c1 + iv[6] * c2;
-            x1 = iv[1] * c0 + iv[4] * c1 + iv[7] * c2;
-            x2 = iv[2] * c0 + iv[5] * c1 + iv[8] * c2;
+        const int e1 = ev.lm_ptr[l + 1];
+        const int bend = min(e1, ebase + BS);
+        for (int ee = e; ee < bend; ee++)
+            c0 -= cs[0][ee - ebase], c1 -= cs[1][ee - ebase], c2 -= cs[2][ee - ebase];
+        for (int ee = bend; ee < e1; ee++)
+        { // beyond the block: straight from global memory
+            const uint8_t fl = ev.flags[ee];
+            if (fl & (CUGO_EDGE_FIXED_L | CUGO_EDGE_FIXED_P | CUGO_EDGE_INACTIVE))
+                continue;
+            double s0, s1, s2;
+            hplT_x(Hpl + 18 * (size_t)ee, xp + 6 * (size_t)ev.pose[ee], s0, s1, s2);
+            c0 -= s0, c1 -= s1, c2 -= s2;
         }
+        const double* iv = invHll + 9 * (size_t)l;
+        const double x0 = iv[0] * c0 + iv[3] * c1 + iv[6] * c2;
+        const double x1 = iv[1] * c0 + iv[4] * c1 + iv[7] * c2;
+        const double x2 = iv[2] * c0 + iv[5] * c1 + iv[8] * c2;
         xl[3 * (size_t)l] = x0, xl[3 * (size_t)l + 1] = x1, xl[3 * (size_t)l + 2] = x2;
         lms_out[3 * (size_t)l] = lms_in[3 * (size_t)l] + x0;
         lms_out[3 * (size_t)l + 1] = lms_in[3 * (size_t)l + 1] + x1;
         lms_out[3 * (size_t)l + 2] = lms_in[3 * (size_t)l + 2] + x2;
         sc = x0 * (lambda * x0 + b0) + x1 * (lambda * x1 + b1) + x2 * (lambda * x2 + b2);
+    }
+    if (e < ev.L && ev.lm_ptr[e] == ev.lm_ptr[e + 1])
+    { // landmark without any edge: zero step
+        xl[3 * (size_t)e] = 0, xl[3 * (size_t)e + 1] = 0, xl[3 * (size_t)e + 2] = 0;
+        lms_out[3 * (size_t)e] = lms_in[3 * (size_t)e];
+        lms_out[3 * (size_t)e + 1] = lms_in[3 * (size_t)e + 1];
+        lms_out[3 * (size_t)e + 2] = lms_in[3 * (size_t)e + 2];
     }
     sc = block_sum(sc, sm);
     if (threadIdx.x == 0)
@@ -798,7 +857,7 @@ void launch_backsubst_update(hipStream_t s, const cugo_edges& e, double lambda, 
                              double* d_lms_out, ReduceScratch rs, double* d_scale)
 {
     const EV ev = make_ev(e);
-    const int nbl = div_up(ev.L, BS), nbp = div_up(ev.P, BS);
+    const int nbl = div_up(ev.E > ev.L ? ev.E : ev.L, BS), nbp = div_up(ev.P, BS);
     if (nbl > 0)
         CUGO_LAUNCH(k_backsubst_landmarks, dim3(nbl), dim3(BS), 0, s, ev, lambda, d_invHll,
                            d_bl, d_Hpl, d_xp, d_xl, d_lms_in, d_lms_out, rs.d_partials);

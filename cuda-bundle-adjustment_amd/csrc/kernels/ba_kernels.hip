@@ -486,7 +486,21 @@ __global__ __launch_bounds__(BS) void k_schur_edges(EV ev, double lambda,
 
 // ---------------------------------------------------------------- Schur: diagonal ------
 // Hsc(p,p) = Hpp[p] (+lambda I) - sum_e T_e Hpl_e^T ; bsc[p] = bp[p] - sum_e T_e bl[l(e)]
-__global__ __launch_bounds__(BS) void k_hsc_diag(EV ev, const int32_t* __restrict__ rowptr,
+// One workgroup per pose, its edge list dealt to the four waves in chunks of 7 edges.  As in
+// k_hsc_offdiag the 144-B operands of a chunk are fetched by one pair of 16-B loads (lanes
+// 9j..9j+8 read edge j's T and Hpl blocks: ~2 cache lines per block instead of 64 lines per
+// instruction), staged in a per-wave LDS slot, and LANE = OUTPUT ELEMENT: lanes 0..20 own the
+// 21 upper-triangle entries of the 6x6 sum, lanes 21..26 the 6 entries of the rhs sum.  The
+// per-wave partial sums are added in wave order: fixed order, bit-reproducible.
+constexpr int HD_CH = 7;
+constexpr int HD_BS = 1024; // 16 waves per pose: the per-wave chain of dependent loads is what costs
+constexpr int HD_W = HD_BS / 64;
+__device__ __forceinline__ void wave_sync_lds0()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+__global__ __launch_bounds__(HD_BS) void k_hsc_diag(EV ev, const int32_t* __restrict__ rowptr,
                                                  double lambda_diag,
                                                  const double* __restrict__ Hpp,
                                                  const double* __restrict__ bp,
@@ -496,56 +510,96 @@ __global__ __launch_bounds__(BS) void k_hsc_diag(EV ev, const int32_t* __restric
                                                  double* __restrict__ Hsc,
                                                  double* __restrict__ bsc)
 {
-    extern __shared__ double smem[];
-    double* red = smem;
-    double* out = smem + 27 * BS;
+    __shared__ double2 sT2[HD_W][HD_CH * 9 + 1]; // T blocks as loaded
+    __shared__ double sU[HD_W][HD_CH * 21 + 3];  // per edge: 3 rows of [H[6m..6m+5], bl[m]]
+    __shared__ double part[HD_W][28];
     const int p = blockIdx.x;
-    double acc[27];
-#pragma unroll
-    for (int i = 0; i < 27; i++)
-        acc[i] = 0;
-    const int i0 = ev.pose_ptr[p], i1 = ev.pose_ptr[p + 1];
-    for (int i = i0 + threadIdx.x; i < i1; i += BS)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // output element of this lane: v < 21 -> (r, c) of the upper triangle, else rhs row r
+    const int v = lane < 27 ? lane : 26;
+    int r = 0, cc = 6;
+    if (v < 21)
     {
-        const int e = ev.pose_edge[i];
-        const uint8_t fl = ev.flags[e];
-        if (fl & (CUGO_EDGE_FIXED_L | CUGO_EDGE_FIXED_P | CUGO_EDGE_INACTIVE))
-            continue;
-        const int l = ev.lm[e];
-        const double2* ph = reinterpret_cast<const double2*>(Hpl + 18 * (size_t)e);
-        const double2* pt = reinterpret_cast<const double2*>(T + 18 * (size_t)e);
-        double H[18], Tt[18];
-#pragma unroll
-        for (int k = 0; k < 9; k++)
+        int k = v;
+        while (k >= 6 - r)
         {
-            const double2 a = ph[k], b = pt[k];
-            H[2 * k] = a.x, H[2 * k + 1] = a.y;
-            Tt[2 * k] = b.x, Tt[2 * k + 1] = b.y;
+            k -= 6 - r;
+            r++;
         }
-        const double b0 = bl[3 * (size_t)l], b1 = bl[3 * (size_t)l + 1], b2 = bl[3 * (size_t)l + 2];
-        int k = 0;
-#pragma unroll
-        for (int r = 0; r < 6; r++)
-#pragma unroll
-            for (int c = r; c < 6; c++)
-                acc[k++] += Tt[r] * H[c] + Tt[6 + r] * H[6 + c] + Tt[12 + r] * H[12 + c];
-#pragma unroll
-        for (int r = 0; r < 6; r++)
-            acc[21 + r] += Tt[r] * b0 + Tt[6 + r] * b1 + Tt[12 + r] * b2;
+        cc = r + k;
     }
-    block_reduce_vec<27>(acc, red, out);
+    else
+        r = v - 21;
+    const int pj = min(lane / 9, HD_CH - 1), part9 = lane - 9 * (lane / 9);
+    const bool writer = lane < 9 * HD_CH;
+    const double2* T2 = reinterpret_cast<const double2*>(T);
+    const double2* H2 = reinterpret_cast<const double2*>(Hpl);
+    const double* sT = reinterpret_cast<const double*>(sT2[w]);
+    double* su = sU[w];
+    const int i0 = ev.pose_ptr[p], i1 = ev.pose_ptr[p + 1];
+    const int nch = (i1 - i0 + HD_CH - 1) / HD_CH;
+    double acc = 0;
+    int e_next = 0;
+    if (w < nch)
+        e_next = ev.pose_edge[min(i0 + HD_CH * w + pj, i1 - 1)];
+    for (int ch = w; ch < nch; ch += HD_W)
+    {
+        const int i = i0 + HD_CH * ch + pj;
+        const int e = e_next;
+        if (ch + HD_W < nch)
+            e_next = ev.pose_edge[min(i + HD_CH * HD_W, i1 - 1)];
+        const uint8_t fl = ev.flags[e];
+        const int l = ev.lm[e];
+        const bool act = i < i1 && !(fl & (CUGO_EDGE_FIXED_L | CUGO_EDGE_FIXED_P | CUGO_EDGE_INACTIVE));
+        // fixed-landmark edges have l >= L: no bl entry (and they are never active)
+        const int lsafe = act ? l : 0;
+        double2 tv = T2[9 * (size_t)e + part9], hv = H2[9 * (size_t)e + part9];
+        const double bv = bl[3 * (size_t)lsafe + min(part9, 2)];
+        if (!act)
+            tv = make_double2(0, 0); // the edge contributes nothing
+        if (writer)
+        {
+            sT2[w][9 * pj + part9] = tv;
+            const int k0 = 2 * part9, k1 = k0 + 1;
+            su[21 * pj + 7 * (k0 / 6) + k0 % 6] = hv.x;
+            su[21 * pj + 7 * (k1 / 6) + k1 % 6] = hv.y;
+            if (part9 < 3)
+                su[21 * pj + 7 * part9 + 6] = bv;
+        }
+        wave_sync_lds0();
+        const int n = min(HD_CH, i1 - i0 - HD_CH * ch);
+#pragma unroll
+        for (int u = 0; u < HD_CH; u++)
+            if (u < n) // wave-uniform
+                acc += sT[18 * u + r] * su[21 * u + cc] + sT[18 * u + 6 + r] * su[21 * u + 7 + cc] +
+                       sT[18 * u + 12 + r] * su[21 * u + 14 + cc];
+        wave_sync_lds0(); // the slot is rewritten by the next chunk
+    }
+    if (lane < 27)
+        part[w][lane] = acc;
+    __syncthreads();
     const int t = threadIdx.x;
     if (t < 36)
     {
-        const int r = t % 6, c = t / 6;
-        const int a = r < c ? r : c, b = r < c ? c : r;
-        double v = Hpp[36 * (size_t)p + t] - out[tri6(a, b)];
-        if (r == c)
-            v += lambda_diag;
-        Hsc[36 * (size_t)rowptr[p] + t] = v;
+        const int rr = t % 6, c = t / 6;
+        const int a = rr < c ? rr : c, b = rr < c ? c : rr;
+        const int k = tri6(a, b);
+        double sum = 0;
+        for (int q = 0; q < HD_W; q++)
+            sum += part[q][k];
+        double val = Hpp[36 * (size_t)p + t] - sum;
+        if (rr == c)
+            val += lambda_diag;
+        Hsc[36 * (size_t)rowptr[p] + t] = val;
     }
     else if (t < 42)
-        bsc[6 * (size_t)p + (t - 36)] = bp[6 * (size_t)p + (t - 36)] - out[21 + (t - 36)];
+    {
+        const int k = 21 + (t - 36);
+        double sum = 0;
+        for (int q = 0; q < HD_W; q++)
+            sum += part[q][k];
+        bsc[6 * (size_t)p + (t - 36)] = bp[6 * (size_t)p + (t - 36)] - sum;
+    }
 }
 
 // ---------------------------------------------------------------- Schur: off-diagonal --
@@ -845,7 +899,7 @@ void launch_schur(hipStream_t s, const cugo_edges& e, const cugo_hsc_struct& hs,
         CUGO_LAUNCH(k_hsc_offdiag, dim3(div_up(hs.n_blocks, BS / 64)), dim3(BS), 0, s,
                            hs.n_blocks, hs.d_off_ptr, hs.d_off_ei, hs.d_off_ej, d_Hpl, d_T, d_Hsc);
     if (ev.P > 0)
-        CUGO_LAUNCH(k_hsc_diag, dim3(ev.P), dim3(BS), (27 * BS + 32) * sizeof(double), s, ev,
+        CUGO_LAUNCH(k_hsc_diag, dim3(ev.P), dim3(HD_BS), 0, s, ev,
                            hs.d_rowptr, damp_hsc_diag ? lambda : 0.0, d_Hpp, d_bp, d_bl, d_Hpl, d_T,
                            d_Hsc, d_bsc);
 }

@@ -13,7 +13,7 @@ void cugo_chol::upload(hipStream_t s)
 {
     const CholPlan& P = plan;
     d_ncb.upload(P.ncb, s), d_nb.upload(P.nb, s), d_off.upload(P.off, s), d_col0.upload(P.col0, s);
-    d_woff.upload(P.woff, s);
+    d_woff.upload(P.woff, s), d_l21off.upload(P.l21off, s);
     d_rows_ptr.upload(P.rows_ptr, s), d_rows.upload(P.rows, s);
     d_child_ptr.upload(P.child_ptr, s), d_child.upload(P.child, s);
     d_rel_ptr.upload(P.rel_ptr, s), d_rel.upload(P.rel, s);
@@ -26,6 +26,7 @@ void cugo_chol::upload(hipStream_t s)
     d_xnew.resize((size_t)6 * P.n + 16);
     d_junk.resize(64 * 1024);
     d_winv.resize((size_t)P.winv_doubles + 16);
+    d_l21.resize((size_t)P.l21_doubles + 16);
     CUGO_HIP(hipStreamSynchronize(s)); // host vectors may be reused after return
 
     cugo_k::CholPlanDev& D = dev;
@@ -42,6 +43,7 @@ void cugo_chol::upload(hipStream_t s)
     D.n = P.n, D.perm = d_perm.data(), D.col_front = d_col_front.data();
     D.junk = d_junk.data();
     D.woff = d_woff.data(), D.winv = d_winv.data(), D.nc_max = P.nc_max;
+    D.l21off = d_l21off.data(), D.l21 = d_l21.data();
     lds_factor = cugo_k::chol_lds_factor_bytes(P.nc_max);
     lds_backward = cugo_k::chol_lds_backward_bytes(P.nc_max, P.ld_max);
 }
@@ -84,8 +86,7 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
             cugo_k::launch_chol_upper_stage(
                 s, dev, d_fronts.data(), t0, t1 - t0, d_wl.data(), plan.ea_ptr[st],
                 plan.ea_ptr[st + 1] - plan.ea_ptr[st], plan.eab_ptr[st],
-                plan.eab_ptr[st + 1] - plan.eab_ptr[st], plan.trsm_ptr[st],
-                plan.trsm_ptr[st + 1] - plan.trsm_ptr[st], plan.syrk_ptr[st],
+                plan.eab_ptr[st + 1] - plan.eab_ptr[st], plan.syrk_ptr[st],
                 plan.syrk_ptr[st + 1] - plan.syrk_ptr[st], lds_factor, d_fail);
     }
     for (int st = plan.n_stages - 1; st >= 0; st--)

@@ -16,9 +16,9 @@ struct cugo_chol
     cugo_host::DevBuf<int32_t> d_ncb, d_nb, d_col0, d_rows_ptr, d_rows, d_child_ptr, d_child,
         d_rel_ptr, d_rel, d_task_ptr, d_task_fronts, d_blk_front, d_blk_row, d_blk_col, d_perm,
         d_col_front, d_wl;
-    cugo_host::DevBuf<int64_t> d_off, d_woff;
+    cugo_host::DevBuf<int64_t> d_off, d_woff, d_l21off;
     cugo_host::DevBuf<uint8_t> d_blk_trans;
-    cugo_host::DevBuf<double> d_fronts, d_xnew, d_junk, d_winv;
+    cugo_host::DevBuf<double> d_fronts, d_xnew, d_junk, d_winv, d_l21;
 
     void analyze(int n, const int32_t* rowptr, const int32_t* colind);
     void upload(hipStream_t s);

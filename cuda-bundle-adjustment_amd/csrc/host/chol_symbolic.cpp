@@ -685,8 +685,10 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
     P.nc_max = 6;
     for (int s = 0; s < ns; s++)
         P.nc_max = std::max(P.nc_max, 6 * P.ncb[s]);
-    P.ea_ptr.assign(1, 0), P.eab_ptr.assign(1, 0), P.trsm_ptr.assign(1, 0), P.syrk_ptr.assign(1, 0);
-    std::vector<int32_t> ea, eab, tr, sy;
+    P.ea_ptr.assign(1, 0), P.eab_ptr.assign(1, 0), P.syrk_ptr.assign(1, 0);
+    P.l21off.assign(ns, -1);
+    P.l21_doubles = 0;
+    std::vector<int32_t> ea, eab, sy;
     for (int st = 0; st < P.n_stages; st++)
     {
         const bool subtree = P.has_subtree_stage && st == 0;
@@ -721,37 +723,37 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
                         eab.push_back(f), eab.push_back(c0), eab.push_back(std::min(nb, c0 + cols));
                     }
                 }
-                const int nbelow = 6 * (nb - ncb) + 1; // boundary rows + rhs row
-                for (int r0 = 0; r0 < nbelow; r0 += 64)
-                {
-                    tr.push_back(f), tr.push_back(r0), tr.push_back(std::min(nbelow, r0 + 64));
-                }
-                const int nrs = 6 * (nb - ncb);
+                // fused trsm + syrk items (front, tile row ti, tile column tj) over the lower
+                // triangle of 64x64 tiles of the update matrix (rows: boundary rows + rhs row);
+                // tj = -1: a tile row without a diagonal tile (only the rhs row, or no boundary
+                // at all) still needs its L21 rows solved and stored
+                const int nrs = 6 * (nb - ncb), nbelow = nrs + 1;
                 const int nti = (nbelow + 63) / 64, ntj = (nrs + 63) / 64;
-                int tile = 0; // linear index, column-major over the lower triangle of tiles
                 for (int tj = 0; tj < ntj; tj++)
-                    for (int ti = tj; ti < nti; ti++, tile++)
+                    for (int ti = tj; ti < nti; ti++)
                     {
-                        sy.push_back(f), sy.push_back(tile), sy.push_back(tj);
+                        sy.push_back(f), sy.push_back(ti), sy.push_back(tj);
                     }
+                for (int ti = ntj; ti < nti; ti++)
+                {
+                    sy.push_back(f), sy.push_back(ti), sy.push_back(-1);
+                }
+                P.l21off[f] = P.l21_doubles;
+                P.l21_doubles += (int64_t)6 * ncb * nbelow;
             }
         P.ea_ptr.push_back((int)ea.size() / 3);
         P.eab_ptr.push_back((int)eab.size() / 3);
-        P.trsm_ptr.push_back((int)tr.size() / 3);
         P.syrk_ptr.push_back((int)sy.size() / 3);
     }
-    // one array: [ea | eab | trsm | syrk]; the ptr arrays index items within their own section
+    // one array: [ea | eab | trsyrk]; the ptr arrays index items within their own section
     P.wl.clear();
     P.wl.insert(P.wl.end(), ea.begin(), ea.end());
     P.wl.insert(P.wl.end(), eab.begin(), eab.end());
-    P.wl.insert(P.wl.end(), tr.begin(), tr.end());
     P.wl.insert(P.wl.end(), sy.begin(), sy.end());
     for (auto& v : P.eab_ptr)
         v += (int)ea.size() / 3;
-    for (auto& v : P.trsm_ptr)
-        v += (int)(ea.size() + eab.size()) / 3;
     for (auto& v : P.syrk_ptr)
-        v += (int)(ea.size() + eab.size() + tr.size()) / 3;
+        v += (int)(ea.size() + eab.size()) / 3;
 }
 
 } // namespace cugo_host

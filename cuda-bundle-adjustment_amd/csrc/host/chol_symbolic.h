@@ -33,6 +33,11 @@ struct CholPlan
     int64_t front_doubles = 0;
     std::vector<int64_t> woff; // per front: offset of W = L11^-1 (pad16(6*ncb)^2 doubles)
     int64_t winv_doubles = 0;
+    // per front of an upper stage: offset of its L21 (+ forward-solved rhs row) in the compact
+    // l21 buffer, column-major with leading dimension 6*(nb-ncb)+1; -1 for subtree-stage fronts
+    // (their L21 stays in the front matrix)
+    std::vector<int64_t> l21off;
+    int64_t l21_doubles = 0;
     std::vector<int32_t> col_front;      // new column -> supernode
 
     int n_stages = 0;
@@ -45,7 +50,7 @@ struct CholPlan
     //   trsm        : scalar rows [a, b) below the pivot block (relative to row 6*ncb)
     //   syrk        : 64x64 tile (row tile a, col tile b), a >= b
     std::vector<int32_t> wl;
-    std::vector<int32_t> ea_ptr, eab_ptr, trsm_ptr, syrk_ptr; // [n_stages+1] item ranges per stage
+    std::vector<int32_t> ea_ptr, eab_ptr, syrk_ptr; // [n_stages+1] item ranges per stage
     // ea = extend-add of the pivot block columns (before potrf), eab = of the boundary columns
     // (same launch as trsm)
     int nc_max = 6; // widest pivot block in scalars (LDS sizing)

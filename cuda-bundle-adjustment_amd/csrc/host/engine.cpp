@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstring>
 #include <cstdio>
 #include <cstdlib>
 #include <numeric>
@@ -586,6 +587,7 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
     if (m.structure_dirty)
         build_structure();
     const bool sharded = m.world > 1;
+    int32_t* d_fail = reinterpret_cast<int32_t*>(m.d_scal.data() + 4);
     auto sync_prof = [&](int item, Clock::time_point t0) {
         if (m.profile)
         {
@@ -619,18 +621,22 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
             cugo_k::launch_max_diagonal(s, hpp, m.P, m.d_Hll.data(), m.L, m.rs(),
                                         m.d_scal.data() + 1);
         }
-        if (sharded)
-        {
-            m.exchange(m.d_scal.data(), 1, 0);
-            if (iteration == 0)
-                m.exchange(m.d_scal.data() + 1, 1, 1);
-        }
-        CUGO_HIP(hipMemcpyAsync(m.h_scal.data(), m.d_scal.data(), 2 * sizeof(double),
-                                hipMemcpyDeviceToHost, s));
-        CUGO_HIP(hipStreamSynchronize(s));
-        F = m.h_scal[0];
+        // chi2 at the current estimates is only read back in the first iteration: afterwards it is
+        // the F-hat of the accepted trial (same edges, same estimates), so the host does not have
+        // to wait for the build pass before queueing the Schur complement
         if (iteration == 0)
+        {
+            if (sharded)
+            {
+                m.exchange(m.d_scal.data(), 1, 0);
+                m.exchange(m.d_scal.data() + 1, 1, 1);
+            }
+            CUGO_HIP(hipMemcpyAsync(m.h_scal.data(), m.d_scal.data(), 2 * sizeof(double),
+                                    hipMemcpyDeviceToHost, s));
+            CUGO_HIP(hipStreamSynchronize(s));
+            F = m.h_scal[0];
             lambda = tau * m.h_scal[1];
+        }
 
         int q = 0;
         double rho = -1.0;
@@ -647,7 +653,7 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
             sync_prof(PROF_SCHUR, ts);
             auto tn = Clock::now();
             m.timed("cholesky", [&] {
-                m.chol.factor_solve(m.Hsc(), lambda, m.bsc(), m.xp(), m.d_fail.data());
+                m.chol.factor_solve(m.Hsc(), lambda, m.bsc(), m.xp(), d_fail);
             });
             sync_prof(PROF_NUMERIC, tn);
             auto tu = Clock::now();
@@ -667,12 +673,13 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
             sync_prof(PROF_COMPUTE_ERROR, te);
             if (sharded)
                 m.exchange(m.d_scal.data() + 2, 2, 0);
-            CUGO_HIP(hipMemcpyAsync(m.h_scal.data() + 2, m.d_scal.data() + 2, 2 * sizeof(double),
-                                    hipMemcpyDeviceToHost, s));
-            CUGO_HIP(hipMemcpyAsync(m.h_fail.data(), m.d_fail.data(), sizeof(int32_t),
+            // F-hat, scale and the factorisation flag (slot 4) in one read-back
+            CUGO_HIP(hipMemcpyAsync(m.h_scal.data() + 2, m.d_scal.data() + 2, 3 * sizeof(double),
                                     hipMemcpyDeviceToHost, s));
             CUGO_HIP(hipStreamSynchronize(s));
-            const bool success = m.h_fail[0] == 0;
+            int32_t fail_flag;
+            std::memcpy(&fail_flag, m.h_scal.data() + 4, sizeof fail_flag);
+            const bool success = fail_flag == 0;
             const double Fhat = m.h_scal[2];
             const double scale = (success ? m.h_scal[3] : 0.0) + 1e-3;
             const double Fdiff = Fhat - F;

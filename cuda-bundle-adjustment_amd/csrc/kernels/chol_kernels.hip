@@ -582,6 +582,21 @@ __device__ __forceinline__ void dev_winv(const double* __restrict__ Ls, int ncp,
         }
 }
 
+// deal the 16-column blocks of X (block cb costs cb+1 K-blocks) to the 4 wave groups: largest
+// first, each to the least loaded group; a group gets at most two blocks / 6 K-blocks.
+// Tabulated (nblk <= 6): nibbles of `tab`, low = first block, high = second (15 = none).
+__device__ __forceinline__ void deal_col_blocks(int nblk, int g, int& cbA, int& cbB)
+{
+    // nblk: 1 -> {0},{},{},{}  2 -> {1},{0},{},{}  3 -> {2},{1},{0},{}  4 -> {3},{2},{1},{0}
+    //       5 -> {4},{3},{2},{1,0}  6 -> {5},{4},{3,0},{2,1}
+    const unsigned tabs[7] = {0xFFFFFFFFu, 0xFFFFFFF0u, 0xFFFFF0F1u, 0xFFF0F1F2u,
+                              0xF0F1F2F3u, 0x01F2F3F4u, 0x1203F4F5u};
+    const unsigned e = (tabs[nblk] >> (8 * g)) & 0xFFu;
+    const int lo = e & 15, hi = e >> 4;
+    cbA = lo == 15 ? -1 : lo;
+    cbB = hi == 15 ? -1 : hi;
+}
+
 // rows [row0, row0+nrows) (absolute scalar rows, nrows <= 64) of F21:  X = B W^T  (X L11^T = B)
 // as a GEMM on the f64 matrix cores.  The B tile is staged in LDS k-major (Bt[k*PST + r]); wave
 // w owns row group w&3 and one or two 16-column blocks cb of X (dealt so that every wave has at
@@ -596,27 +611,8 @@ __device__ __forceinline__ void dev_trsm_w(double* __restrict__ F, long ld, int 
     const int ncp = pad16(nc), nblk = ncp >> 4;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, ln = lane & 15, lk = lane >> 4;
     const int rg = w & 3, g = w >> 2;
-    // deal the column blocks (cost cb+1) to the 4 wave groups: largest first, to the least loaded
-    int cbA = -1, cbB = -1;
-    {
-        int load[4] = {0, 0, 0, 0};
-        for (int cb = nblk - 1; cb >= 0; cb--)
-        {
-            int best = 0;
-#pragma unroll
-            for (int t = 1; t < 4; t++)
-                if (load[t] < load[best])
-                    best = t;
-            load[best] += cb + 1;
-            if (best == g)
-            {
-                if (cbA < 0)
-                    cbA = cb;
-                else
-                    cbB = cb;
-            }
-        }
-    }
+    int cbA, cbB;
+    deal_col_blocks(nblk, g, cbA, cbB);
     const int nA = cbA + 1, nU = nA + cbB + 1; // K-blocks of the first block / in total (<= 6)
     double a[6][4];
 #pragma unroll
@@ -788,6 +784,153 @@ __device__ __forceinline__ void dev_syrk_tiles(double* __restrict__ F, long ld, 
     }
 }
 
+// Fused trsm + syrk for ONE 64x64 tile (ti, tj) of the update matrix of a front (upper stages):
+//   X_i = B_i W^T, X_j = B_j W^T   (B = rows of F21 of tile rows ti / tj, 64 x ncs each)
+//   U(ti,tj) -= X_i X_j^T
+// Every tile recomputes the two L21 row tiles it needs from B and W instead of waiting for a
+// separate trsm kernel: the redundant MFMAs are cheap next to a kernel boundary (launch gap +
+// prologue + the L21 round trip through memory), and the whole tile is still one global load
+// round trip.  B stays untouched in the front (other tiles read it concurrently); the tile
+// with tj == ti (or tj < 0: a tile row that has no diagonal tile) stores X_i to the compact
+// L21 buffer that the backward substitution reads.
+// LDS: Pi | Pj, k-major panels (stride PST) that first hold B and then, in place, X.
+__device__ __forceinline__ void dev_trsyrk_tile(double* __restrict__ F, long ld, int ncs, int nt, int nrs,
+                                                int ti, int tj, const double* __restrict__ Wg,
+                                                double* __restrict__ L21, long ld2,
+                                                double* __restrict__ lds, double* __restrict__ junk)
+{
+    constexpr int KC = KC_SYRK;
+    double* sink = junk + ((blockIdx.x & 63) << 10) + threadIdx.x; // private slot of this lane
+    const int ncp = pad16(ncs), nblk = ncp >> 4;
+    const int tt = threadIdx.x, lane = tt & 63, w = tt >> 6, ln = lane & 15, lk = lane >> 4;
+    const int rg = w & 3, g = w >> 2; // trsm role: row group, column-block group
+    const int wc = w & 3, wr = w >> 2; // syrk role: column / row sub-tile
+    const bool solo = tj < 0, diag = tj == ti, two = !solo && !diag;
+    double* Pi = lds;
+    double* Pj = lds + KC * PST;
+    double* U = F + (long)ncs * ld + ncs;
+    int cbA, cbB;
+    deal_col_blocks(nblk, g, cbA, cbB);
+    const int nA = cbA + 1, nU = nA + cbB + 1;
+    stamp(4, 1);
+    // ---- all global loads first: W operands, the B tile(s), the U entries to update
+    double a[6][4];
+#pragma unroll
+    for (int u = 0; u < 6; u++)
+    {
+        const int cb = u < nA ? cbA : cbB, kb = u < nA ? u : u - nA;
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++)
+            a[u][kk] = (u < nU) ? Wg[(unsigned)((16 * kb + lk + 4 * kk) * ncp + 16 * cb + ln)] : 0.0;
+    }
+    {
+        const int r = tt & 63, kq = tt >> 6;
+        const int gi = 64 * ti + r, gj = 64 * tj + r;
+        const double* B = F + ncs; // (row i, col k) = B[k*ld + i]; 32-bit offsets from the uniform base
+        const unsigned uld = (unsigned)ld;
+        double vi[6], vj[6];
+#pragma unroll
+        for (int u = 0; u < 6; u++)
+        {
+            const int k = kq + 16 * u;
+            vi[u] = (k < ncs && gi < nt) ? B[(unsigned)k * uld + (unsigned)gi] : 0.0;
+            vj[u] = (two && k < ncs && gj < nt) ? B[(unsigned)k * uld + (unsigned)gj] : 0.0;
+        }
+        double uold[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+        { // masked lanes read their private sink slot: no branch
+            const int i = 64 * ti + 16 * wr + ln, j = 64 * tj + 16 * wc + lk + 4 * q;
+            const bool ok = !solo && i < nt && j < nrs && i >= j;
+            const double* src = ok ? U + ((long)j * ld + i) : sink;
+            uold[q] = *src;
+        }
+#pragma unroll
+        for (int u = 0; u < 6; u++)
+        {
+            const int k = kq + 16 * u;
+            if (k < ncp)
+            {
+                Pi[k * PST + r] = vi[u];
+                if (two)
+                    Pj[k * PST + r] = vj[u];
+            }
+        }
+        stamp(4, 2);
+        __syncthreads();
+        stamp(4, 3);
+        // ---- X = B W^T for this wave's row group and column blocks (both panels)
+        double4_t xi[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, xj[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        {
+            double4_t ai = {0, 0, 0, 0}, aj = {0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < 6; u++)
+            {
+                if (u < nU)
+                {
+                    const int kb = u < nA ? u : u - nA;
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++)
+                    {
+                        const int ko = (16 * kb + lk + 4 * kk) * PST + 16 * rg + ln;
+                        ai = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][kk], Pi[ko], ai, 0, 0, 0);
+                        if (two)
+                            aj = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][kk], Pj[ko], aj, 0, 0, 0);
+                    }
+                    if (u == nA - 1)
+                        xi[0] = ai, xj[0] = aj, ai = double4_t{0, 0, 0, 0}, aj = double4_t{0, 0, 0, 0};
+                    else if (u == nU - 1)
+                        xi[1] = ai, xj[1] = aj;
+                }
+            }
+        }
+        stamp(4, 4);
+        __syncthreads(); // every wave has read B: the panels may be overwritten with X
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+        {
+            const int cb = h == 0 ? cbA : cbB;
+            if (cb >= 0)
+            {
+                const int row = 64 * ti + 16 * rg + ln;
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                {
+                    const int c = 16 * cb + lk + 4 * q;
+                    Pi[c * PST + 16 * rg + ln] = xi[h][q];
+                    if (two)
+                        Pj[c * PST + 16 * rg + ln] = xj[h][q];
+                    if (!two && c < ncs && row < nt) // diag or solo: this tile owns L21 rows ti
+                        L21[(long)c * ld2 + row] = xi[h][q];
+                }
+            }
+        }
+        __syncthreads();
+        stamp(4, 5);
+        if (!solo)
+        { // ---- U(ti,tj) -= X_i X_j^T, one 16x16 sub-tile per wave
+            const double* Pa = diag ? Pi : Pj;
+            double4_t acc = {0, 0, 0, 0};
+            for (int k0 = 0; k0 < ncs; k0 += 4)
+            {
+                const int k = min(k0 + lk, ncs - 1); // clamped: no branch around the LDS reads
+                const bool kok = k0 + lk < ncs;
+                const double av = Pa[k * PST + 16 * wc + ln];
+                const double bv = Pi[k * PST + 16 * wr + ln];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(kok ? av : 0.0, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+            { // branch-free: masked lanes store into their sink slot
+                const int i = 64 * ti + 16 * wr + ln, j = 64 * tj + 16 * wc + lk + 4 * q;
+                const bool ok = i < nt && j < nrs && i >= j;
+                double* dst = ok ? U + ((long)j * ld + i) : sink;
+                *dst = uold[q] - acc[q];
+            }
+        }
+    }
+}
+
 // backward substitution of one front: x_J = W^T (y_J - L21^T x_R), W = L11^-1 from dev_winv.
 // Both halves are matrix-vector products: 16 lanes per pivot column, all loads of a lane in
 // flight together, a 16-lane butterfly at the end.  No serial triangular solve.
@@ -798,7 +941,10 @@ __device__ __forceinline__ void dev_backward(const CholPlanDev& p, const double*
     const int ncb = p.ncb[f], nb = p.nb[f];
     const long ld = 6L * nb + 1;
     const int ncs = 6 * ncb, nrs = 6 * (nb - ncb), ncp = pad16(ncs);
-    const double* F = fronts + p.off[f];
+    // L21 and the forward-solved rhs row: compact buffer (upper stages) or the front itself
+    const long l21o = p.l21off[f];
+    const double* L = l21o >= 0 ? p.l21 + l21o : fronts + p.off[f] + ncs;
+    const long ldl = l21o >= 0 ? nrs + 1 : ld;
     const double* Wg = p.winv + p.woff[f];
     const int c0 = p.col0[f];
     double* vs = lds;      // ncp
@@ -819,8 +965,8 @@ __device__ __forceinline__ void dev_backward(const CholPlanDev& p, const double*
     // v_j = y_j - sum_i L21[i,j] x_R[i]
     for (int j = g; j < ncs; j += ng)
     {
-        const double* col = F + (long)j * ld + ncs;
-        const double y = F[(long)j * ld + (ld - 1)];
+        const double* col = L + (long)j * ldl;
+        const double y = col[nrs];
         double s = 0;
         for (int i = l16; i < nrs; i += 128)
         { // eight independent loads in flight per lane
@@ -923,10 +1069,20 @@ __global__ __launch_bounds__(BIG) void k_up_extend_add(CholPlanDev p, double* __
     stamp(5, 7);
 }
 
+// potrf of the stage's fronts and, in the same launch, the extend-add of their BOUNDARY columns
+// (blocks >= npotrf): independent data (F11 vs F22), one kernel boundary less
 __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restrict__ fronts,
-                                                  int task0, int32_t* __restrict__ fail)
+                                                  int task0, int npotrf,
+                                                  const int32_t* __restrict__ wl_ea,
+                                                  int32_t* __restrict__ fail)
 {
     extern __shared__ double lds[];
+    if ((int)blockIdx.x >= npotrf)
+    {
+        const int32_t* it = wl_ea + 3 * (blockIdx.x - npotrf);
+        dev_extend_add(p, fronts, it[0], it[1], it[2]);
+        return;
+    }
     stamp(0, 0);
     const int f = p.task_fronts[p.task_ptr[task0 + blockIdx.x]];
     const int ncs = 6 * p.ncb[f];
@@ -947,42 +1103,17 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
     stamp(0, 7);
 }
 
-// trsm tiles (touch the pivot columns; LDS = one 64-row B tile) and, in the same launch, the extend-add of the
-// boundary columns (touch the update region): independent data, one kernel boundary less
-__global__ __launch_bounds__(BIG) void k_up_trsm(CholPlanDev p, double* __restrict__ fronts,
-                                                 const int32_t* __restrict__ wl, int ntr,
-                                                 const int32_t* __restrict__ wl_ea)
-{
-    extern __shared__ double lds[];
-    if ((int)blockIdx.x >= ntr)
-    {
-        const int32_t* it = wl_ea + 3 * (blockIdx.x - ntr);
-        dev_extend_add(p, fronts, it[0], it[1], it[2]);
-        return;
-    }
-    const int32_t* it = wl + 3 * blockIdx.x;
-    const int f = it[0];
-    const int ncs = 6 * p.ncb[f];
-    const long ld = 6L * p.nb[f] + 1;
-    double* F = fronts + p.off[f];
-    stamp(1, 0);
-    dev_trsm_w(F, ld, ncs, ncs + it[1], it[2] - it[1], p.winv + p.woff[f], lds);
-    stamp(1, 7);
-    stamp_value(1, 6, ncs);
-}
-
-// one workgroup per 64x64 tile; it[1] = linear tile index
-__global__ __launch_bounds__(BIG) void k_up_syrk(CholPlanDev p, double* __restrict__ fronts,
-                                                 const int32_t* __restrict__ wl)
+// fused trsm + syrk: one workgroup per item (front, ti, tj), see dev_trsyrk_tile
+__global__ __launch_bounds__(BIG) void k_up_trsyrk(CholPlanDev p, double* __restrict__ fronts,
+                                                   const int32_t* __restrict__ wl)
 {
     extern __shared__ double lds[];
     stamp(4, 0);
     const int32_t* it = wl + 3 * blockIdx.x;
     const int f = it[0];
     const int ncs = 6 * p.ncb[f], nrs = 6 * (p.nb[f] - p.ncb[f]);
-    stamp(4, 1);
-    dev_syrk_tiles(fronts + p.off[f], 6L * p.nb[f] + 1, ncs, nrs + 1, nrs, it[1], it[1] + 1,
-                   (nrs + 63) / 64, lds, p.junk);
+    dev_trsyrk_tile(fronts + p.off[f], 6L * p.nb[f] + 1, ncs, nrs + 1, nrs, it[1], it[2],
+                    p.winv + p.woff[f], p.l21 + p.l21off[f], nrs + 1, lds, p.junk);
     stamp(4, 7);
     stamp_value(4, 6, 1000L * ncs + nrs);
 }
@@ -1069,27 +1200,21 @@ void launch_chol_subtree_stage(hipStream_t s, const CholPlanDev& p, double* d_fr
 
 void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,
                              int ntasks, const int32_t* d_wl, int eap0, int neap, int ea0, int nea,
-                             int tr0, int ntr, int sy0, int nsy, size_t lds_bytes, int32_t* d_fail)
+                             int sy0, int nsy, size_t lds_bytes, int32_t* d_fail)
 {
+    (void)lds_bytes;
     if (ntasks <= 0)
         return;
     if (neap > 0) // children -> pivot columns
         CUGO_LAUNCH(k_up_extend_add, dim3(neap), dim3(BIG), 0, s, p, d_fronts,
                            d_wl + 3L * eap0);
     ensure_lds(reinterpret_cast<const void*>(k_up_potrf), chol_lds_potrf_bytes());
-    CUGO_LAUNCH(k_up_potrf, dim3(ntasks), dim3(BIG), chol_lds_potrf_bytes(), s, p, d_fronts, task0,
-                d_fail);
-    if (ntr + nea > 0)
-    {
-        const size_t lds_trsm = chol_lds_trsm_bytes(p.nc_max);
-        ensure_lds(reinterpret_cast<const void*>(k_up_trsm), lds_trsm);
-        CUGO_LAUNCH(k_up_trsm, dim3(ntr + nea), dim3(BIG), lds_trsm, s, p, d_fronts,
-                           d_wl + 3L * tr0, ntr, d_wl + 3L * ea0);
-    }
+    CUGO_LAUNCH(k_up_potrf, dim3(ntasks + nea), dim3(BIG), chol_lds_potrf_bytes(), s, p, d_fronts,
+                task0, ntasks, d_wl + 3L * ea0, d_fail);
     if (nsy > 0)
     {
-        ensure_lds(reinterpret_cast<const void*>(k_up_syrk), syrk_lds() * sizeof(double));
-        CUGO_LAUNCH(k_up_syrk, dim3(nsy), dim3(BIG), syrk_lds() * sizeof(double), s, p, d_fronts,
+        ensure_lds(reinterpret_cast<const void*>(k_up_trsyrk), syrk_lds() * sizeof(double));
+        CUGO_LAUNCH(k_up_trsyrk, dim3(nsy), dim3(BIG), syrk_lds() * sizeof(double), s, p, d_fronts,
                            d_wl + 3L * sy0);
     }
 }

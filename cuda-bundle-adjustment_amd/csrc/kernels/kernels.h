@@ -87,6 +87,8 @@ struct CholPlanDev
     const int64_t* off;        // offset (doubles) of the front matrix in `fronts`
     const int64_t* woff;       // offset (doubles) of W = L11^-1 (pad16(6*ncb)^2, column-major) in winv
     double* winv;
+    const int64_t* l21off;     // offset of the front's L21 (+ rhs row) in l21, or -1: in the front itself
+    double* l21;               // column-major, leading dimension 6*(nb-ncb)+1
     int nc_max;                // widest pivot block (scalars)
     const int32_t* col0;       // first pivot column (new ordering, block units)
     const int32_t* rows_ptr;   // [n_fronts+1] into rows: boundary block rows (new ordering)
@@ -118,10 +120,11 @@ void launch_chol_assemble(hipStream_t s, const CholPlanDev& p, double* d_fronts,
                           const double* d_Hsc, double lambda, const double* d_bsc);
 void launch_chol_subtree_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,
                                int ntasks, size_t lds_bytes, int32_t* d_fail);
-// one etree level: extend-add / potrf / trsm / syrk kernels over the work items d_wl[...]
+// one etree level: extend-add(pivot columns) / potrf (+ extend-add of the boundary columns) /
+// fused trsm+syrk kernels over the work items d_wl[...]
 void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,
                              int ntasks, const int32_t* d_wl, int eap0, int neap, int ea0, int nea,
-                             int tr0, int ntr, int sy0, int nsy, size_t lds_bytes, int32_t* d_fail);
+                             int sy0, int nsy, size_t lds_bytes, int32_t* d_fail);
 void launch_chol_backward_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,
                                 int ntasks, size_t lds_bytes, double* d_xnew, double* d_x);
 // LDS bytes of the factor kernels (L11 + one 64-row tile) and of the backward kernel

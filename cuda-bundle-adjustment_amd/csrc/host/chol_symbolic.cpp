@@ -26,6 +26,8 @@ CholOptions CholOptions::from_env()
         o.zero_frac = std::atof(s);
     if (const char* s = std::getenv("CUGO_TARGET_TASKS"))
         o.target_tasks = std::max(1, std::atoi(s));
+    if (const char* s = std::getenv("CUGO_MIN_SUBTREE_TASKS"))
+        o.min_subtree_tasks = std::max(0, std::atoi(s));
     if (const char* s = std::getenv("CUGO_MAX_FRONT_COLS"))
         o.max_front_cols = std::min(16, std::max(1, std::atoi(s)));
     return o;
@@ -609,6 +611,14 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
     std::vector<char> lower(ns);
     for (int s = 0; s < ns; s++)
         lower[s] = sub[s] <= wtask;
+    {
+        int nroots = 0;
+        for (int s = 0; s < ns; s++)
+            if (lower[s] && (P.sparent[s] < 0 || !lower[P.sparent[s]]))
+                nroots++;
+        if (nroots < opt.min_subtree_tasks)
+            std::fill(lower.begin(), lower.end(), 0);
+    }
     std::vector<int> lvl(ns, 0);
     int max_lvl = 0;
     for (int s = 0; s < ns; s++)

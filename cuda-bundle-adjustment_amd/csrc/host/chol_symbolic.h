@@ -13,6 +13,8 @@ struct CholOptions
     int max_super_cols = 8;  // relaxed supernodes: at most this many block columns
     double zero_frac = 0.35; // relaxed supernodes: tolerated share of explicit zero blocks
     int target_tasks = 1024; // subtree-to-workgroup granularity of stage 0
+    int min_subtree_tasks = 64; // fewer bottom subtrees than this: no subtree stage (a handful of
+                                // workgroups walking whole subtrees serially is slower than the batched kernels)
     int max_front_cols = 16; // hard cap on pivot block columns of a front (LDS-resident L11)
     static CholOptions from_env();
 };

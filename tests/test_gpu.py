@@ -154,9 +154,12 @@ def test_schur_complement_and_backsubst_vs_oracle(ctx, oracle_lib):
     cugo.lib().cugo_chol_destroy(s)
 
 
-@pytest.mark.parametrize("env", [{}, {"CUGO_ND_LEAF": "4", "CUGO_MAX_SUPER_COLS": "3", "CUGO_TARGET_TASKS": "4"},
+# CUGO_MIN_SUBTREE_TASKS=0 forces the subtree stage (k_subtree_factor) that small graphs skip
+@pytest.mark.parametrize("env", [{}, {"CUGO_MIN_SUBTREE_TASKS": "0"},
+                                 {"CUGO_ND_LEAF": "4", "CUGO_MAX_SUPER_COLS": "3", "CUGO_TARGET_TASKS": "4",
+                                  "CUGO_MIN_SUBTREE_TASKS": "0"},
                                  {"CUGO_ND_LEAF": "1000", "CUGO_MAX_SUPER_COLS": "1", "CUGO_TARGET_TASKS": "100000"},
-                                 {"CUGO_MAX_SUPER_COLS": "24", "CUGO_ZERO_FRAC": "0.9"}])
+                                 {"CUGO_MAX_SUPER_COLS": "24", "CUGO_ZERO_FRAC": "0.9", "CUGO_MIN_SUBTREE_TASKS": "0"}])
 def test_sparse_cholesky_vs_numpy(ctx, env, monkeypatch):
     from test_host import covis_pattern, patterns, random_spd_bsr
     for k, v in env.items():
@@ -249,7 +252,10 @@ def rmse(a, b):
     return float(np.sqrt(np.mean((a - b) ** 2)))
 
 
-def test_medium_synthetic_vs_oracle(oracle_lib):
+@pytest.mark.parametrize("subtree_stage", [False, True])
+def test_medium_synthetic_vs_oracle(oracle_lib, subtree_stage, monkeypatch):
+    if subtree_stage:
+        monkeypatch.setenv("CUGO_MIN_SUBTREE_TASKS", "0")
     d, prob = synth_problem(oracle_lib, 400, 8000, 33000, seed=11, lc=200)
     out = run_graph(d, 10)
     ref = prob.optimize(10)

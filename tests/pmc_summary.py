@@ -1,7 +1,7 @@
 """summarise rocprofv3 --pmc counter_collection.csv per kernel: mean counter value per dispatch"""
 import csv, glob, sys, collections
 for d in sys.argv[1:]:
-    f = glob.glob(d + '/*/*_counter_collection.csv')
+    f = sorted(glob.glob(d + '/*/*_counter_collection.csv'), key=__import__('os').path.getmtime)[-1:]
     if not f:
         print(d, "no counter file"); continue
     acc = collections.defaultdict(lambda: collections.defaultdict(list))

@@ -409,6 +409,7 @@ int cugo_graph_set_robust_kernel(cugo_graph* g, int dim, int type, double delta)
 {
     const cugo::RobustKernelType t = type == CUGO_RK_CAUCHY  ? cugo::RobustKernelType::Cauchy
                                      : type == CUGO_RK_TUKEY ? cugo::RobustKernelType::Tukey
+                                     : type == CUGO_RK_HUBER ? cugo::RobustKernelType::Huber
                                                              : cugo::RobustKernelType::None;
     if (dim == 3)
         g->stereo.setRobustKernel(t, delta);

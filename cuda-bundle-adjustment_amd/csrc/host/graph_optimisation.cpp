@@ -67,6 +67,8 @@ static int rk_code(RobustKernelType t)
         return CUGO_RK_CAUCHY;
     case RobustKernelType::Tukey:
         return CUGO_RK_TUKEY;
+    case RobustKernelType::Huber:
+        return CUGO_RK_HUBER;
     default:
         return CUGO_RK_NONE;
     }

@@ -25,6 +25,8 @@ __device__ __forceinline__ double rk_rho(const Robust rk, double x)
     }
     if (rk.type == 1)
         return d2 * log((1.0 / d2) * x + 1.0);
+    if (rk.type == 3) // Huber (not in the reference's enum; g2o RobustKernelHuber, what ORB-SLAM2 uses)
+        return x <= d2 ? x : 2.0 * rk.delta * sqrt(x) - d2;
     return x;
 }
 __device__ __forceinline__ double rk_drho(const Robust rk, double x)
@@ -37,6 +39,8 @@ __device__ __forceinline__ double rk_drho(const Robust rk, double x)
     }
     if (rk.type == 1)
         return 1.0 / ((1.0 / d2) * x + 1.0);
+    if (rk.type == 3)
+        return x <= d2 ? 1.0 : rk.delta / sqrt(x);
     return 1.0;
 }
 

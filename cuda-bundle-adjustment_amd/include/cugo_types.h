@@ -143,7 +143,8 @@ enum class RobustKernelType
 {
     None,
     Cauchy,
-    Tukey
+    Tukey,
+    Huber // extension (the reference stops at Tukey): g2o RobustKernelHuber, ORB-SLAM2's kernel
 };
 
 // Per-edge-set robust kernel parameters, passed to the kernels by value.

@@ -34,7 +34,8 @@ extern "C" {
 #define CUGO_ERR_NUMERIC (-4) /* zero pivot: ref src/cuda_linear_solver.cpp:44-52 */
 
 /* ref: src/robust_kernel.h:12-17 */
-enum { CUGO_RK_NONE = 0, CUGO_RK_CAUCHY = 1, CUGO_RK_TUKEY = 2 };
+enum { CUGO_RK_NONE = 0, CUGO_RK_CAUCHY = 1, CUGO_RK_TUKEY = 2,
+       CUGO_RK_HUBER = 3 /* extension: g2o RobustKernelHuber, rho(x) = x | 2*delta*sqrt(x) - delta^2 */ };
 
 /* edge flag bits; bits 0/1 are the reference's EdgeFlag (ref: src/constants.h:28-32) */
 enum

@@ -84,6 +84,8 @@ double ba_rk_rho(int type, double delta, double x)
         const double r = 1.0 / d2;
         return d2 * log(r * x + 1.0);
     }
+    if (type == BA_RK_HUBER) /* extension, g2o RobustKernelHuber: rho[0] = 2*delta*sqrt(e2) - delta^2 beyond delta */
+        return x <= d2 ? x : 2.0 * delta * sqrt(x) - d2;
     return x;
 }
 
@@ -100,6 +102,8 @@ double ba_rk_drho(int type, double delta, double x)
         const double r = 1.0 / d2;
         return 1.0 / (r * x + 1.0);
     }
+    if (type == BA_RK_HUBER)
+        return x <= d2 ? 1.0 : delta / sqrt(x);
     return 1;
 }
 

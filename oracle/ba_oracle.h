@@ -24,7 +24,8 @@
 extern "C" {
 #endif
 
-enum { BA_RK_NONE = 0, BA_RK_CAUCHY = 1, BA_RK_TUKEY = 2 }; /* src/robust_kernel.h:12-17 */
+enum { BA_RK_NONE = 0, BA_RK_CAUCHY = 1, BA_RK_TUKEY = 2, /* src/robust_kernel.h:12-17 */
+       BA_RK_HUBER = 3 /* extension beyond the reference: g2o RobustKernelHuber */ };
 
 /* A BA problem as flat arrays.  Vertices are listed in ascending-id order (the order
  * std::map iteration gives the reference, src/optimisable_graph.hpp:95).  Edges refer to

@@ -21,7 +21,7 @@ def golden_path(name):
 PROBLEM_KEYS = ["pose", "pose_fixed", "lm", "lm_fixed", "e_pose", "e_lm", "e_stereo", "e_meas",
                 "e_omega", "e_cam"]
 GOLDEN_GRAPHS = ["tiny_3x8", "small_10x200", "loop_12x150", "reject_8x60", "zero_noise_6x40",
-                 "cauchy_8x80", "tukey_8x80"]
+                 "cauchy_8x80", "tukey_8x80", "huber_8x80"]
 # chi2 relative tolerance per fixture.  1e-10 is the north-star bar; reject_8x60 starts 4
 # orders of magnitude from the optimum with rejected trials and amplifies round-off (the two
 # independent CPU restatements already differ by 2e-9 on it), so it is a control-flow fixture.

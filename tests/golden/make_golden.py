@@ -40,6 +40,8 @@ def rho(kind, delta, x):
         return (d2 / 3) * (1 - (1 - x / d2) ** 3) if x <= d2 else d2 / 3
     if kind == 1:  # Cauchy
         return d2 * np.log1p(x / d2)
+    if kind == 3:  # Huber (g2o RobustKernelHuber)
+        return x if x <= d2 else 2 * delta * np.sqrt(x) - d2
     return x
 
 
@@ -49,6 +51,8 @@ def drho(kind, delta, x):
         return (1 - x / d2) ** 2 if x <= d2 else 0.0
     if kind == 1:
         return 1.0 / (1.0 + x / d2)
+    if kind == 3:
+        return 1.0 if x <= d2 else delta / np.sqrt(x)
     return 1.0
 
 
@@ -233,8 +237,10 @@ def kat_edges(seed=3, n=12):
 
 def main():
     np.set_printoptions(precision=12)
+    only = set(sys.argv[1:])  # optional: regenerate just the named graph fixtures
     # ---- per-edge KATs ------------------------------------------------------------
-    np.savez(os.path.join(OUT, "kat_edges.npz"), **kat_edges())
+    if not only:
+        np.savez(os.path.join(OUT, "kat_edges.npz"), **kat_edges())
     # ---- exp-map KATs (incl. theta < 1e-5 branch and w<0 flip) ---------------------
     rng = np.random.default_rng(11)
     poses, dxs, outs = [], [], []
@@ -252,7 +258,8 @@ def main():
                        e_lm=[0], e_stereo=[0], e_meas=[np.zeros(3)], e_omega=[1.0], e_cam=[synth.KITTI_CAM]))
         g.apply(np.concatenate([dx]))
         poses.append(pose); dxs.append(dx); outs.append(g.pose[0].copy())
-    np.savez(os.path.join(OUT, "kat_expmap.npz"), pose=np.array(poses), dx=np.array(dxs), out=np.array(outs))
+    if not only:
+        np.savez(os.path.join(OUT, "kat_expmap.npz"), pose=np.array(poses), dx=np.array(dxs), out=np.array(outs))
 
     # ---- small graphs: 10-iteration trajectories -----------------------------------
     cases = {
@@ -263,10 +270,14 @@ def main():
         "zero_noise_6x40": dict(n_poses=6, n_landmarks=40, seed=13, pix_noise=0.0, pose_noise=(0, 0), lm_noise=0.0),
         "cauchy_8x80": dict(n_poses=8, n_landmarks=80, seed=17, mean_obs=3.0),
         "tukey_8x80": dict(n_poses=8, n_landmarks=80, seed=19, mean_obs=3.0),
+        "huber_8x80": dict(n_poses=8, n_landmarks=80, seed=23, mean_obs=3.0, pix_noise=2.0),
     }
     for name, kw in cases.items():
+        if only and name not in only:
+            continue
         d = synth.make_problem(**kw)
-        rk = (1, 3.0) if name.startswith("cauchy") else (2, 8.0) if name.startswith("tukey") else (0, 1.0)
+        rk = ((1, 3.0) if name.startswith("cauchy") else (2, 8.0) if name.startswith("tukey")
+              else (3, 1.5) if name.startswith("huber") else (0, 1.0))
         g = Graph(d, rk)
         H, b = g.normal_equations()
         lam0 = 1e-5 * max(0.0, np.diag(H).max())

@@ -56,7 +56,7 @@ def build_on_gpu(ctx, f, ev, rk=RK0):
     return d
 
 
-@pytest.mark.parametrize("rk", [(0, 1.0), (1, 2.5), (2, 6.0)])
+@pytest.mark.parametrize("rk", [(0, 1.0), (1, 2.5), (2, 6.0), (3, 1.5)])
 def test_errors_and_quadratic_form_vs_oracle(ctx, oracle_lib, rk):
     import devmem
     prob = mixed_problem(oracle_lib)

@@ -174,6 +174,19 @@ class Graph:
     def set_robust_kernel(self, dim, rk_type, delta):
         check(lib().cugo_graph_set_robust_kernel(self._g, dim, int(rk_type), C.c_double(delta)))
 
+    def set_outlier_threshold(self, dim, threshold):
+        """edges of the set (dim 2 mono / 3 stereo) with chi2 > threshold are inactivated at the
+        end of optimize(); 0 disables (ref: EdgeSet::setOutlierThreshold / updateEdges)"""
+        check(lib().cugo_graph_set_outlier_threshold(self._g, dim, C.c_double(threshold)))
+
+    def n_outliers(self, dim):
+        return lib().cugo_graph_n_outliers(self._g, dim)
+
+    def edge_active(self, dim, n):
+        out = np.zeros(n, np.uint8)
+        check(lib().cugo_graph_get_edge_active(self._g, dim, n, _p(out, _u8p)))
+        return out.astype(bool)
+
     def set_shard(self, rank, world, fn):
         """fn(device_ptr:int, n_doubles:int, op:int) must all-reduce in place"""
         def _cb(ptr, n, op, user):

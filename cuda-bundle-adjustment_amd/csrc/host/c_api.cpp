@@ -417,6 +417,29 @@ int cugo_graph_set_robust_kernel(cugo_graph* g, int dim, int type, double delta)
         g->mono.setRobustKernel(t, delta);
     return CUGO_OK;
 }
+int cugo_graph_set_outlier_threshold(cugo_graph* g, int dim, double threshold)
+{
+    if (dim == 3)
+        g->stereo.setOutlierThreshold(threshold);
+    else
+        g->mono.setOutlierThreshold(threshold);
+    return CUGO_OK;
+}
+int cugo_graph_n_outliers(cugo_graph* g, int dim)
+{
+    return (int)(dim == 3 ? g->stereo.getOutlierCount() : g->mono.getOutlierCount());
+}
+int cugo_graph_get_edge_active(cugo_graph* g, int dim, int n, uint8_t* active)
+{
+    return guarded([&] {
+        if (dim == 3)
+            for (int i = 0; i < n && i < (int)g->stereo_store.size(); i++)
+                active[i] = g->stereo_store[i].isActive() ? 1 : 0;
+        else
+            for (int i = 0; i < n && i < (int)g->mono_store.size(); i++)
+                active[i] = g->mono_store[i].isActive() ? 1 : 0;
+    });
+}
 int cugo_graph_set_shard(cugo_graph* g, int rank, int world, cugo_exchange_fn fn, void* user)
 {
     return guarded([&] { g->opt->setShard(rank, world, fn, user); });

@@ -64,6 +64,10 @@ struct Engine::Impl : cugo_k::LaunchHook
 
     // host copies (sorted, local shard)
     std::vector<int32_t> h_e_pose, h_e_lm, h_lm_ptr, h_pose_ptr, h_pose_edge;
+    std::vector<int32_t> slot_edge;     // slot -> edge index of the FlatGraph (-1: padding)
+    std::vector<double> slot_threshold; // slot -> outlier threshold (empty: rejection disabled)
+    int last_err_buf = 0;               // estimate buffer of the last error pass
+    int Etot = 0;
     std::vector<uint8_t> h_flags;
     // global co-visibility: free landmark -> sorted free poses (free-free active edges, all shards)
     std::vector<int32_t> cov_ptr, cov_pose;
@@ -347,6 +351,15 @@ void Engine::initialize(FlatGraph&& g)
         omega.assign(1, g.e_omega.empty() ? 1.0 : g.e_omega[0]);
     if (m.n_cams > 1)
         cam.resize(E);
+    m.slot_edge.assign(E, -1);
+    m.slot_threshold.clear();
+    bool any_threshold = false;
+    for (double t : g.e_outlier_threshold)
+        any_threshold = any_threshold || t > 0.0;
+    if (any_threshold)
+        m.slot_threshold.assign(E, 0.0);
+    m.Etot = Etot;
+    m.last_err_buf = 0;
     for (int i = 0; i < E; i++)
     {
         if (slot_src[i] < 0)
@@ -362,6 +375,9 @@ void Engine::initialize(FlatGraph&& g)
             continue;
         }
         const int e = order[slot_src[i]];
+        m.slot_edge[i] = e;
+        if (any_threshold)
+            m.slot_threshold[i] = g.e_outlier_threshold[e];
         m.h_e_pose[i] = g.e_pose[e];
         m.h_e_lm[i] = g.e_lm[e];
         m.h_flags[i] = g.e_flags[e];
@@ -670,6 +686,7 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
                 cugo_k::launch_errors(s, m.ev, m.d_poses[nxt].data(), m.d_lms[nxt].data(), m.rk,
                                       m.rs(), m.d_scal.data() + 2);
             });
+            m.last_err_buf = nxt;
             sync_prof(PROF_COMPUTE_ERROR, te);
             if (sharded)
                 m.exchange(m.d_scal.data() + 2, 2, 0);
@@ -712,6 +729,58 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
             break;
     }
     m.collect_times();
+}
+
+std::vector<int32_t> Engine::reject_outliers()
+{
+    Impl& m = *impl_;
+    std::vector<int32_t> out;
+    if (m.slot_threshold.empty() || m.E == 0)
+        return out;
+    hipStream_t s = m.ctx.stream;
+    // chi2 per slot at the estimates of the last error pass (a rejected trial's estimates if the
+    // last trial was rejected: the reference reads whatever d_chiValues holds at that point)
+    DevBuf<double> d_chi;
+    d_chi.resize((size_t)m.E + 16);
+    cugo_k::launch_edge_chi(s, m.ev, m.d_poses[m.last_err_buf].data(), m.d_lms[m.last_err_buf].data(), m.rk,
+                            d_chi.data());
+    std::vector<double> chi(m.E);
+    CUGO_HIP(hipMemcpyAsync(chi.data(), d_chi.data(), sizeof(double) * m.E, hipMemcpyDeviceToHost, s));
+    CUGO_HIP(hipStreamSynchronize(s));
+    std::vector<int32_t> slots;
+    for (int i = 0; i < m.E; i++)
+        if (m.slot_edge[i] >= 0 && m.slot_threshold[i] > 0.0 && !(m.h_flags[i] & CUGO_EDGE_INACTIVE) &&
+            chi[i] > m.slot_threshold[i])
+            slots.push_back(i);
+    for (int i : slots)
+        out.push_back(m.slot_edge[i]);
+    if (m.world > 1)
+    { // every rank needs the union: one sum all-reduce of a 0/1 mask over the global edge ids
+        std::vector<double> mask(m.Etot, 0.0);
+        for (int e : out)
+            mask[e] = 1.0;
+        DevBuf<double> d_mask;
+        d_mask.upload(mask, s);
+        m.exchange(d_mask.data(), (size_t)m.Etot, 0);
+        CUGO_HIP(hipMemcpyAsync(mask.data(), d_mask.data(), sizeof(double) * m.Etot, hipMemcpyDeviceToHost, s));
+        CUGO_HIP(hipStreamSynchronize(s));
+        out.clear();
+        for (int e = 0; e < m.Etot; e++)
+            if (mask[e] > 0.5)
+                out.push_back(e);
+    }
+    else
+        std::sort(out.begin(), out.end());
+    if (!out.empty())
+    { // the flagged edges drop out of a further optimize() on the same initialisation, too
+        for (int i : slots)
+            m.h_flags[i] |= CUGO_EDGE_INACTIVE;
+        m.d_flags.upload(m.h_flags, s);
+        CUGO_HIP(hipStreamSynchronize(s));
+        m.structure_dirty = true;
+        E_global_ -= (int)out.size();
+    }
+    return out;
 }
 
 void Engine::download(std::vector<double>& poses, std::vector<double>& lms)

@@ -26,6 +26,9 @@ struct FlatGraph
     std::vector<uint16_t> e_cam; // E or empty
     std::vector<double> cams;    // n_cams x 5
     cugo_robust rk{CUGO_RK_NONE, 1.0, CUGO_RK_NONE, 1.0};
+    // outlier rejection (ref: EdgeSet::updateEdges, optimisable_graph.hpp:603-640): per edge
+    // the chi2 threshold of its edge set, 0 = disabled; empty = disabled for all
+    std::vector<double> e_outlier_threshold;
     int n_edges() const { return (int)e_pose.size(); }
 };
 
@@ -75,6 +78,10 @@ public:
     void optimize(int niterations, std::vector<IterRecord>& records, bool verbose);
     // estimates back to host (ref: VertexSet::finalise, optimisable_graph.hpp:137-154)
     void download(std::vector<double>& poses, std::vector<double>& lms);
+    // ref: BlockSolver::updateEdges at the end of optimize(): edges whose chi2 in the last error
+    // pass exceeds their set's threshold become inactive.  Returns their indices in the order of
+    // the FlatGraph passed to initialize() (all ranks return the same list).
+    std::vector<int32_t> reject_outliers();
     int n_active_edges() const { return E_global_; }
     const StructureStats& structure_stats() const { return sstats_; }
     const double* profile_ms() const { return prof_; }

@@ -121,7 +121,9 @@ void CudaGraphOptimisationImpl::initialize()
         cap += es->nedges();
     g.e_pose.reserve(cap), g.e_lm.reserve(cap), g.e_flags.reserve(cap);
     g.e_meas.reserve(3 * cap), g.e_omega.reserve(cap), g.e_cam.reserve(cap);
-    bool omega_uniform = true, rk_set[2] = {false, false};
+    flatEdges_.clear(), flatEdgeSets_.clear();
+    flatEdges_.reserve(cap), flatEdgeSets_.reserve(cap);
+    bool omega_uniform = true, rk_set[2] = {false, false}, any_threshold = false;
     cugo_robust rk{CUGO_RK_NONE, 1.0, CUGO_RK_NONE, 1.0};
     for (BaseEdgeSet* es : edgeSets)
     {
@@ -135,6 +137,9 @@ void CudaGraphOptimisationImpl::initialize()
         else
             rk.type = rk_code(k.type()), rk.delta = k.delta(), rk_set[0] = true;
         size_t nactive = 0;
+        const double set_threshold = es->getOutlierThreshold();
+        any_threshold = any_threshold || set_threshold > 0.0;
+        es->setOutlierCount(0);
         const double set_info = es->getInformation();
         const Camera set_cam = es->getCamera();
         for (BaseEdge* e : es->get())
@@ -147,6 +152,8 @@ void CudaGraphOptimisationImpl::initialize()
             if (fp && fl)
                 continue;
             nactive++;
+            flatEdges_.push_back(e), flatEdgeSets_.push_back(es);
+            g.e_outlier_threshold.push_back(set_threshold);
             g.e_pose.push_back(vp->getIndex());
             g.e_lm.push_back(vl->getIndex());
             g.e_flags.push_back((uint8_t)((fl ? CUGO_EDGE_FIXED_L : 0) | (fp ? CUGO_EDGE_FIXED_P : 0) | stereo_bit));
@@ -186,6 +193,8 @@ void CudaGraphOptimisationImpl::initialize()
     }
     if (omega_uniform && !g.e_omega.empty())
         g.e_omega.resize(1);
+    if (!any_threshold)
+        g.e_outlier_threshold.clear();
     if (g.cams.empty())
     {
         const double z[5] = {1, 1, 0, 0, 0};
@@ -211,6 +220,15 @@ void CudaGraphOptimisationImpl::optimize(int niterations)
     if (shouldProfile_)
         for (const auto& kv : timeProfile())
             std::printf("%s:  %f\n", kv.first.c_str(), kv.second);
+    // ref: solver_->updateEdges(edgeSets) (cuda_graph_optimisation.cpp:151): edges whose chi2
+    // exceeds their set's outlier threshold are inactivated; the set becomes dirty
+    for (int32_t id : engine_->reject_outliers())
+    {
+        flatEdges_[id]->inactivate();
+        BaseEdgeSet* es = flatEdgeSets_[id];
+        es->setOutlierCount(es->getOutlierCount() + 1);
+        es->setDirtyState(true);
+    }
     // ref: finalize(): estimates go back into the user's vertex objects
     std::vector<double> poses, lms;
     engine_->download(poses, lms);

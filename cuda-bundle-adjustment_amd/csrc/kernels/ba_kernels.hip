@@ -162,6 +162,28 @@ __global__ __launch_bounds__(BS) void k_errors(EV ev, const double* __restrict__
         partials[blockIdx.x] = chi;
 }
 
+// chi_e = rho(omega |e|^2) per edge slot (0 for inactive slots): only used by the outlier
+// rejection at the end of optimize() (ref: d_chiValues read by computeOutliersKernel .cu:1135)
+__global__ __launch_bounds__(BS) void k_edge_chi(EV ev, const double* __restrict__ poses,
+                                                 const double* __restrict__ lms, Robust2 rk,
+                                                 double* __restrict__ chi_out)
+{
+    const int e = blockIdx.x * BS + threadIdx.x;
+    if (e >= ev.E)
+        return;
+    const uint8_t fl = ev.flags[e];
+    double chi = 0;
+    if (!(fl & CUGO_EDGE_INACTIVE))
+    {
+        const EdgeIn in = load_edge(ev, e, fl);
+        EdgeGeom g;
+        edge_residual(poses + 7 * (size_t)in.ip, lms + 3 * (size_t)in.il, in.mu, in.mv, in.mr,
+                      in.stereo, in.omega, in.cam, in.stereo ? rk.s : rk.m, g);
+        chi = g.chi;
+    }
+    chi_out[e] = chi;
+}
+
 // ---------------------------------------------------------------- build: edges + landmarks
 // One lane per edge: residual and Jacobians are evaluated ONCE and feed both
 //   Hpl[e] = w JP^T JL (6x3 col-major, global) and the chi2 partials, and
@@ -854,6 +876,16 @@ void launch_errors(hipStream_t s, const cugo_edges& e, const double* d_poses, co
         CUGO_LAUNCH(k_errors, dim3(nb), dim3(BS), 0, s, ev, d_poses, d_lms,
                            Robust2{{rk.type, rk.delta}, {rk.type_stereo, rk.delta_stereo}}, rs.d_partials);
     CUGO_LAUNCH(k_sum_partials, dim3(1), dim3(BS), 0, s, rs.d_partials, nb, d_chi);
+}
+
+void launch_edge_chi(hipStream_t s, const cugo_edges& e, const double* d_poses, const double* d_lms,
+                     cugo_robust rk, double* d_chi_e)
+{
+    const EV ev = make_ev(e);
+    const int nb = div_up(ev.E, BS);
+    if (nb > 0)
+        CUGO_LAUNCH(k_edge_chi, dim3(nb), dim3(BS), 0, s, ev, d_poses, d_lms,
+                           Robust2{{rk.type, rk.delta}, {rk.type_stereo, rk.delta_stereo}}, d_chi_e);
 }
 
 void launch_build(hipStream_t s, const cugo_edges& e, const double* d_poses, const double* d_lms,

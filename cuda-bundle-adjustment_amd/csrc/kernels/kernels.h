@@ -76,6 +76,10 @@ void launch_backsubst_update(hipStream_t s, const cugo_edges& ev, double lambda,
 
 size_t reduce_scratch_doubles(int n_edges, int n_poses, int n_landmarks);
 
+// chi_e per edge slot (outlier rejection, ref: computeOutliersKernel cuda_block_solver.cu:1135)
+void launch_edge_chi(hipStream_t s, const cugo_edges& e, const double* d_poses, const double* d_lms,
+                     cugo_robust rk, double* d_chi_e);
+
 // --- multifrontal LL^T (chol_kernels.hip) -------------------------------------------------
 // Device-side plan; all index arrays in units of 6x6 blocks unless noted.
 struct CholPlanDev

@@ -141,6 +141,9 @@ private:
     BatchStatistics stats_;
     std::vector<LmTrace> trace_;
     TimeProfile timeProfile_;
+    // edges handed to the engine at initialize(), in that order (outlier rejection maps back)
+    std::vector<BaseEdge*> flatEdges_;
+    std::vector<BaseEdgeSet*> flatEdgeSets_;
 };
 
 } // namespace cugo

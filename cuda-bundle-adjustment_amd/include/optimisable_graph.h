@@ -313,6 +313,8 @@ public:
     virtual void setDirtyState(bool state) noexcept = 0;
     // set by the optimiser at initialize(): number of edges with at least one free vertex
     virtual void setActiveEdgeCount(size_t n) noexcept = 0;
+    // set by the optimiser: outliers found since initialize() (ref: currOutlierCount_)
+    virtual void setOutlierCount(uint32_t n) noexcept = 0;
 };
 
 // ref: EdgeSet<DIM, E, VertexTypes...> src/optimisable_graph.h:688-816
@@ -358,17 +360,21 @@ public:
     Camera& getCamera() noexcept override { return camera_; }
     void setOutlierThreshold(const Scalar t) noexcept { outlierThreshold = t; }
     Scalar getOutlierThreshold() const noexcept override { return outlierThreshold; }
-    uint32_t getOutlierCount() const noexcept override { return 0; }
-    uint32_t getInlierCount() const noexcept override { return (uint32_t)activeEdgeSize_; }
+    uint32_t getOutlierCount() const noexcept override { return currOutlierCount_; }
+    uint32_t getInlierCount() const noexcept override { return (uint32_t)activeEdgeSize_ - currOutlierCount_; }
     bool isDirty() const noexcept override { return isDirty_; }
     void setDirtyState(bool state) noexcept override { isDirty_ = state; }
     void setActiveEdgeCount(size_t n) noexcept override { activeEdgeSize_ = n; }
+    void setOutlierCount(uint32_t n) noexcept override { currOutlierCount_ = n; }
 
 protected:
     EdgeContainer edges;
     size_t activeEdgeSize_ = 0;
     RobustKernel kernel;
-    Scalar outlierThreshold = 0.0; // 0 = outlier rejection disabled (out of scope)
+    // chi2 threshold above which an edge is inactivated at the end of optimize(); 0 = disabled
+    // (ref: EdgeSet::updateEdges, src/optimisable_graph.hpp:603-640)
+    Scalar outlierThreshold = 0.0;
+    uint32_t currOutlierCount_ = 0;
     Information info_ = 0.0;
     Camera camera_;
     bool isDirty_ = true;

@@ -214,6 +214,15 @@ int cugo_graph_set_robust_kernel(cugo_graph* g, int dim, int type, double delta)
  * called on the host with a DEVICE buffer that must be all-reduced in place over all ranks
  * (op 0 = sum, 1 = max) before it returns (RCCL via torch.distributed in bench.py). */
 typedef void (*cugo_exchange_fn)(void* d_buf, size_t n_doubles, int op, void* user);
+/* ref: EdgeSet::setOutlierThreshold (src/optimisable_graph.h:737-740) + updateEdges
+ * (optimisable_graph.hpp:603-640): at the end of cugo_graph_optimize every edge of the set (dim 2
+ * = mono, 3 = stereo) whose chi2 in the last error pass exceeds `threshold` becomes inactive
+ * (left out by the next initialize / optimize).  0 disables (default). */
+int cugo_graph_set_outlier_threshold(cugo_graph* g, int dim, double threshold);
+/* outliers found since the last initialize (ref: getOutlierCount) */
+int cugo_graph_n_outliers(cugo_graph* g, int dim);
+/* active flag of the first n edges of the set, in insertion order */
+int cugo_graph_get_edge_active(cugo_graph* g, int dim, int n, uint8_t* active);
 int cugo_graph_set_shard(cugo_graph* g, int rank, int world, cugo_exchange_fn fn, void* user);
 /* the landmark index range [*l0, *l1) that shard `rank` of `world` owns, given the number
  * of active edges of every landmark (host only; the rule cugo_graph_initialize applies) */

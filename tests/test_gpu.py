@@ -268,6 +268,56 @@ def test_medium_synthetic_vs_oracle(oracle_lib, subtree_stage, monkeypatch):
     assert out["stats"][-1]["chi2"] < out["stats"][0]["chi2"]
 
 
+def test_outlier_rejection_matches_oracle(oracle_lib):
+    """ref: EdgeSet::setOutlierThreshold + updateEdges (optimisable_graph.hpp:603-640): after
+    optimize() the edges whose chi2 exceeds the set's threshold are inactivated and left out of
+    the next initialize()/optimize()."""
+    d, prob = synth_problem(oracle_lib, 40, 600, 2400, seed=21, lc=0)
+    rng = np.random.default_rng(4)
+    bad = rng.choice(len(d["e_pose"]), 30, replace=False)
+    d["e_meas"] = d["e_meas"].copy()
+    d["e_meas"][bad, :2] += rng.choice([-1.0, 1.0], (30, 2)) * 60.0  # gross outliers
+    prob = oracle_lib.Problem(d["pose"], d["pose_fixed"], d["lm"], d["lm_fixed"], d["e_pose"], d["e_lm"],
+                              d["e_stereo"], d["e_meas"], d["e_omega"], d["e_cam"])
+    th = {2: 5.991, 3: 7.815}
+    g = cugo.graph_from_arrays(d)
+    for dim, t in th.items():
+        g.set_outlier_threshold(dim, t)
+    g.initialize()
+    g.optimize(5)
+    got = g.stats()
+    ref = prob.optimize(5)
+    assert_trajectories_match(got, ref, 1e-10)
+    assert ref[-1]["rho"] > 0  # last trial accepted: the last error pass is at the final estimates
+    # per-edge chi2 at the oracle's final estimates
+    _, err, _ = prob.compute_errors(want_arrays=True)
+    st = d["e_stereo"].astype(bool)
+    chi = d["e_omega"] * np.sum(err ** 2, axis=1)
+    thr = np.where(st, th[3], th[2])
+    expect_out = chi > thr
+    clear = np.abs(chi - thr) > 1e-6
+    # active flags per set, in insertion order (= mono edges then stereo edges of d)
+    act = np.ones(len(chi), bool)
+    act[~st] = g.edge_active(2, int((~st).sum()))
+    act[st] = g.edge_active(3, int(st.sum()))
+    assert np.array_equal(~act[clear], expect_out[clear])
+    assert expect_out[bad].mean() > 0.8 and expect_out.sum() < 0.2 * len(chi)
+    assert g.n_outliers(2) + g.n_outliers(3) == int((~act).sum())
+    assert g.n_active_edges() == len(chi) - int((~act).sum())
+    # next optimisation runs without the flagged edges: same as the oracle on the reduced graph
+    keep = act
+    pose1, lm1 = g.poses(), g.landmarks()
+    g.initialize()
+    g.optimize(5)
+    got2 = g.stats()
+    prob2 = oracle_lib.Problem(pose1, d["pose_fixed"], lm1, d["lm_fixed"], d["e_pose"][keep], d["e_lm"][keep],
+                               d["e_stereo"][keep], d["e_meas"][keep], d["e_omega"][keep], d["e_cam"][keep])
+    ref2 = prob2.optimize(5)
+    assert_trajectories_match(got2, ref2, 1e-9)
+    assert got2[-1]["chi2"] < 0.5 * got[-1]["chi2"]
+    g.close()
+
+
 def test_global_information_and_camera_options(oracle_lib):
     d, prob = synth_problem(oracle_lib, 120, 1500, 6200, seed=5, lc=0)
     d["e_omega"][:] = 0.75

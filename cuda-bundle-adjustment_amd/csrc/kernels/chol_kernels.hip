@@ -8,13 +8,16 @@
 //   front F = [ pivot block columns | boundary block rows | 1 rhs row ]   dense, column-major
 //
 //   stage 0 (optional)  : whole bottom subtrees, one workgroup per subtree, fronts in postorder
-//   upper stages        : one etree level per stage, four batched kernels per level so that a
+//                         (only when there are >= 64 of them; k_subtree_factor)
+//   upper stages        : one etree level per stage, three batched kernels per level so that a
 //                         big front is spread over many workgroups (256 CUs / 8 XCDs):
-//        extend-add  children update matrices -> parent front (fixed child order)
-//        potrf       L11 = chol(F11) in LDS                       (1 workgroup / front)
-//        trsm        L21 = F21 L11^-T, 64-row tiles, L11 + tile in LDS
-//        syrk        U = F22 - L21 L21^T, 64x64 tiles on the f64 matrix cores
-//                    (v_mfma_f64_16x16x4_f64), lower tiles only
+//        k_up_extend_add  children update matrices -> pivot columns of the parents
+//        k_up_potrf       L11 = chol(F11) in LDS, then W = L11^-1 on the matrix cores
+//                         (1 workgroup / front; extra workgroups of the same launch do the
+//                         extend-add of the boundary columns)
+//        k_up_trsyrk      per 64x64 tile of the update matrix: X = B W^T for its two L21 row
+//                         tiles, U -= X_i X_j^T, all v_mfma_f64_16x16x4_f64
+//   backward            : k_backward_stage per level, x_J = W^T (y_J - L21^T x_R): two mat-vecs
 //
 // The right-hand side rides along as the last row of every front, so L y = b is a by-product
 // of the factorisation (y ends in the rhs row of the pivot columns); only the backward
@@ -343,33 +346,6 @@ __device__ __forceinline__ bool panel_factor_wave(double* __restrict__ Ls, int n
     return bad;
 }
 
-// columns [c_lo, c_hi) of the LDS matrix -= (panel at j0)(panel at j0)^T, lower part only;
-// executed by a subset of `nthreads` threads, t = index within the subset (t < 0: not a member);
-// 32 lanes walk the rows of a column.
-// The 6-term dot product is split in two chains: a dependent fp64 FMA costs ~40 cycles.
-__device__ __forceinline__ void panel_update_cols(double* __restrict__ Ls, int nc, int j0,
-                                                  int c_lo, int c_hi, int t, int nthreads)
-{
-    if (t < 0)
-        return;
-    const int tx = t & 31, ty = t >> 5, nty = nthreads >> 5;
-    for (int c = c_lo + ty; c < c_hi; c += nty)
-    {
-        double pc[6];
-#pragma unroll
-        for (int k = 0; k < 6; k++)
-            pc[k] = Ls[(j0 + k) * LLD + c];
-        for (int r = c + tx; r < nc; r += 32)
-        {
-            const double s0 = Ls[(j0 + 0) * LLD + r] * pc[0] + Ls[(j0 + 1) * LLD + r] * pc[1] +
-                              Ls[(j0 + 2) * LLD + r] * pc[2];
-            const double s1 = Ls[(j0 + 3) * LLD + r] * pc[3] + Ls[(j0 + 4) * LLD + r] * pc[4] +
-                              Ls[(j0 + 5) * LLD + r] * pc[5];
-            Ls[c * LLD + r] -= s0 + s1;
-        }
-    }
-}
-
 // Trailing update on the matrix cores: columns [c0, NC) of the LDS matrix -= P P^T with P the
 // 6-column panel at j0, in 16x16 tiles dealt to `nw` waves (widx = index of this wave, < 0: not a
 // member).  K = 6 is two v_mfma_f64_16x16x4 steps (k = 4,5 in the second, upper lanes zero).
@@ -458,10 +434,7 @@ __device__ __forceinline__ void dev_potrf(const double* __restrict__ F, long ld,
         const int jn = j0 + 6;
         if (jn >= nc)
             break;
-        if (blockDim.x >= 768)
-            panel_update_next(Ls, nc, j0); // next panel's columns, one element per thread
-        else
-            panel_update_cols(Ls, nc, j0, jn, min(jn + 6, nc), threadIdx.x, blockDim.x);
+        panel_update_next(Ls, nc, j0); // next panel's columns, one element per thread
         __syncthreads();
         if (threadIdx.x < 64)
         {
@@ -1154,11 +1127,6 @@ size_t chol_lds_potrf_bytes()
     return ((size_t)NC_MAX * LLD + NC_MAX + (NC_MAX >> 4) * (16 * 17) + 8) * sizeof(double);
 }
 int chol_max_pivot_cols() { return NC_MAX; }
-size_t chol_lds_trsm_bytes(int nc_max)
-{
-    const size_t ncp = (size_t)((nc_max + 15) & ~15);
-    return (ncp * (size_t)PSTB + 8) * sizeof(double);
-}
 size_t chol_lds_backward_bytes(int nc_max, long ld_max)
 {
     const size_t ncp = (size_t)((nc_max + 15) & ~15);

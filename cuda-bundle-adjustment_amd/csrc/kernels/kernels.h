@@ -135,7 +135,6 @@ void launch_chol_backward_stage(hipStream_t s, const CholPlanDev& p, double* d_f
 void set_debug_stamps(long long* d_buf); // diagnostic s_memtime stamps (nullptr = off)
 size_t chol_lds_factor_bytes(int nc_max);
 size_t chol_lds_backward_bytes(int nc_max, long ld_max);
-size_t chol_lds_trsm_bytes(int nc_max);
 int chol_max_pivot_cols(); // widest pivot block the kernels support (scalars)
 
 } // namespace cugo_k

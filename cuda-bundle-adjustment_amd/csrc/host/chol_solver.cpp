@@ -13,7 +13,8 @@ void cugo_chol::upload(hipStream_t s)
 {
     const CholPlan& P = plan;
     d_ncb.upload(P.ncb, s), d_nb.upload(P.nb, s), d_off.upload(P.off, s), d_col0.upload(P.col0, s);
-    d_woff.upload(P.woff, s), d_l21off.upload(P.l21off, s);
+    d_woff.upload(P.woff, s), d_l21off.upload(P.l21off, s), d_ldf.upload(P.ldf, s);
+    d_alias_of.upload(P.alias_of, s);
     d_rows_ptr.upload(P.rows_ptr, s), d_rows.upload(P.rows, s);
     d_child_ptr.upload(P.child_ptr, s), d_child.upload(P.child, s);
     d_rel_ptr.upload(P.rel_ptr, s), d_rel.upload(P.rel, s);
@@ -44,6 +45,7 @@ void cugo_chol::upload(hipStream_t s)
     D.junk = d_junk.data();
     D.woff = d_woff.data(), D.winv = d_winv.data(), D.nc_max = P.nc_max;
     D.l21off = d_l21off.data(), D.l21 = d_l21.data();
+    D.ldf = d_ldf.data(), D.alias_of = d_alias_of.data();
     lds_factor = cugo_k::chol_lds_factor_bytes(P.nc_max);
     lds_backward = cugo_k::chol_lds_backward_bytes(P.nc_max, P.ld_max);
 }

@@ -26,6 +26,8 @@ CholOptions CholOptions::from_env()
         o.zero_frac = std::atof(s);
     if (const char* s = std::getenv("CUGO_TARGET_TASKS"))
         o.target_tasks = std::max(1, std::atoi(s));
+    if (const char* s = std::getenv("CUGO_ALIAS_CHAINS"))
+        o.alias_chains = std::atoi(s) != 0;
     if (const char* s = std::getenv("CUGO_MIN_SUBTREE_TASKS"))
         o.min_subtree_tasks = std::max(0, std::atoi(s));
     if (const char* s = std::getenv("CUGO_MAX_FRONT_COLS"))
@@ -565,6 +567,46 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
         }
     }
 
+    // ---- 5b. storage: single-child chains share memory --------------------------------------
+    // A front whose only child has exactly the front's rows as its boundary (the pieces of a wide
+    // supernode, and most single-child links of the etree) would receive that child's update
+    // block by a plain copy.  It is stored IN the child's update block instead (same leading
+    // dimension, rhs row included): no extend-add for it, and the memory is not allocated twice.
+    P.ldf.assign(ns, 0), P.alias_of.assign(ns, -1);
+    P.n_aliased = 0;
+    {
+        int64_t o = 0;
+        const bool enable = opt.alias_chains;
+        for (int s = 0; s < ns; s++) // postorder: children first
+        {
+            int c = -1;
+            if (enable && P.child_ptr[s + 1] - P.child_ptr[s] == 1)
+            {
+                c = P.child[P.child_ptr[s]];
+                const int nbr = P.nb[c] - P.ncb[c];
+                bool same = nbr == P.nb[s];
+                for (int i = 0; same && i < nbr; i++)
+                    same = P.rel[P.rel_ptr[c] + i] == i;
+                if (!same)
+                    c = -1;
+            }
+            if (c >= 0)
+            {
+                P.alias_of[s] = c;
+                P.ldf[s] = P.ldf[c];
+                P.off[s] = P.off[c] + 6LL * P.ncb[c] * P.ldf[c] + 6LL * P.ncb[c];
+                P.n_aliased++;
+            }
+            else
+            {
+                P.ldf[s] = 6LL * P.nb[s] + 1;
+                P.off[s] = o;
+                o += P.ldf[s] * 6LL * P.nb[s];
+            }
+        }
+        P.front_doubles = o;
+    }
+
     // ---- 6. assembly map of the Hsc blocks ---------------------------------------------
     const int B = rowptr[n];
     P.blk_front.resize(B), P.blk_row.resize(B), P.blk_col.resize(B), P.blk_trans.resize(B);
@@ -712,7 +754,7 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
                     P.up_potrf_flops += nc * nc * nc / 3.0;
                     P.up_trsm_flops += nc * nc * (nr + 1);
                     P.up_syrk_flops += 2.0 * nc * (nr * (nr + 1) / 2 + nr);
-                    for (int k = P.child_ptr[f]; k < P.child_ptr[f + 1]; k++)
+                    for (int k = P.child_ptr[f]; k < P.child_ptr[f + 1] && P.alias_of[f] < 0; k++)
                     {
                         const double cr = 6.0 * (P.nb[P.child[k]] - P.ncb[P.child[k]]);
                         P.up_ea_bytes += 24.0 * (cr * (cr + 1) / 2 + cr); // read U, read+write parent
@@ -720,7 +762,7 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
                 }
                 // extend-add work items: a workgroup has 16 waves and a unit is one 64-row chunk
                 // of one block column, so an item takes as many block columns as fill 16 waves
-                if (P.child_ptr[f + 1] > P.child_ptr[f])
+                if (P.child_ptr[f + 1] > P.child_ptr[f] && P.alias_of[f] < 0)
                 {
                     const int chunks = (6 * nb + 1 + 63) / 64;
                     const int cols = std::max(1, std::min(8, 16 / chunks));

@@ -13,6 +13,7 @@ struct CholOptions
     int max_super_cols = 8;  // relaxed supernodes: at most this many block columns
     double zero_frac = 0.35; // relaxed supernodes: tolerated share of explicit zero blocks
     int target_tasks = 1024; // subtree-to-workgroup granularity of stage 0
+    bool alias_chains = true; // single-child fronts with identical rows live in the child's update block
     int min_subtree_tasks = 64; // fewer bottom subtrees than this: no subtree stage (a handful of
                                 // workgroups walking whole subtrees serially is slower than the batched kernels)
     int max_front_cols = 16; // hard cap on pivot block columns of a front (LDS-resident L11)
@@ -33,6 +34,11 @@ struct CholPlan
     std::vector<int32_t> ncb, nb, col0;
     std::vector<int64_t> off;
     int64_t front_doubles = 0;
+    // leading dimension of each front and, for a front stored inside the update block of its only
+    // child (identical row structure: the extend-add would be a plain copy), that child; else -1
+    std::vector<int64_t> ldf;
+    std::vector<int32_t> alias_of;
+    int n_aliased = 0;
     std::vector<int64_t> woff; // per front: offset of W = L11^-1 (pad16(6*ncb)^2 doubles)
     int64_t winv_doubles = 0;
     // per front of an upper stage: offset of its L21 (+ forward-solved rhs row) in the compact

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(CBS) void k_assemble_blocks(CholPlanDev p, double* 
     const int k = (int)(idx / 36), t = (int)(idx % 36);
     const int r = t % 6, c = t / 6;
     const int f = p.blk_front[k];
-    const long ld = 6L * p.nb[f] + 1;
+    const long ld = p.ldf[f];
     double* F = fronts + p.off[f];
     const int rb = p.blk_row[k], cb = p.blk_col[k];
     double v = Hsc[idx];
@@ -76,9 +76,9 @@ __global__ __launch_bounds__(CBS) void k_assemble_rhs(CholPlanDev p, double* __r
         return;
     const int jb = j / 6, comp = j % 6;
     const int f = p.col_front[jb];
-    const long ld = 6L * p.nb[f] + 1;
+    const long ld = p.ldf[f];
     const long lc = 6L * (jb - p.col0[f]) + comp;
-    fronts[p.off[f] + lc * ld + (ld - 1)] = bsc[6L * p.perm[jb] + comp];
+    fronts[p.off[f] + lc * ld + 6L * p.nb[f]] = bsc[6L * p.perm[jb] + comp]; // rhs row = row 6*nb
 }
 
 // Diagnostic phase stamps: only in a build with -DCUGO_STAMPS (make STAMPS=1) and run with
@@ -121,7 +121,8 @@ __device__ __forceinline__ void wave_lds_sync()
 // lane <-> row, the 6 columns are 6 independent read-modify-writes in flight per lane.
 __device__ __forceinline__ void ea_chunk(const double* __restrict__ U, long ldc, int nru, int nbr,
                                          const int32_t* __restrict__ rel, double* __restrict__ Fp,
-                                         long ldp, int jb, int ch, int lane, double* __restrict__ sink)
+                                         long ldp, long rhs_row, int jb, int ch, int lane,
+                                         double* __restrict__ sink)
 {
     const int i = 6 * jb + 64 * ch + lane;
     const bool ok = i < nru;
@@ -129,7 +130,7 @@ __device__ __forceinline__ void ea_chunk(const double* __restrict__ U, long ldc,
     const int ib = ic / 6;
     const long pjb = 6L * rel[jb];
     const int rr = rel[min(ib, nbr - 1)];
-    const long pi = (ic == nru - 1) ? ldp - 1 : 6L * rr + (ic - 6 * ib); // last row = rhs row
+    const long pi = (ic == nru - 1) ? rhs_row : 6L * rr + (ic - 6 * ib); // last row = rhs row
     double* dst[6];
     double u[6], v[6];
 #pragma unroll
@@ -157,7 +158,7 @@ __device__ __forceinline__ void dev_extend_add(const CholPlanDev& p, double* __r
                                int cb1)
 {
     __shared__ int s_child[EA_BATCH][3]; // child front, first / past-last matching update block column
-    const long ldp = 6L * p.nb[f] + 1;
+    const long ldp = p.ldf[f], rhs_row = 6L * p.nb[f];
     double* Fp = fronts + p.off[f];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
     double* sink = p.junk + ((blockIdx.x & 63) << 10) + threadIdx.x;
@@ -191,7 +192,7 @@ __device__ __forceinline__ void dev_extend_add(const CholPlanDev& p, double* __r
             if (jhi <= jlo)
                 continue; // uniform over the workgroup
             const int ncb = p.ncb[c], nbr = p.nb[c] - ncb;
-            const long ldc = 6L * p.nb[c] + 1;
+            const long ldc = p.ldf[c];
             const double* U = fronts + p.off[c] + (6L * ncb) * ldc + 6L * ncb; // (0,0) of update
             const int32_t* rel = p.rel + p.rel_ptr[c];
             const int nru = 6 * nbr + 1;
@@ -200,7 +201,7 @@ __device__ __forceinline__ void dev_extend_add(const CholPlanDev& p, double* __r
             {
                 const int nch = (nru - 6 * jb + 63) >> 6;
                 for (; u < nch; u += nwv)
-                    ea_chunk(U, ldc, nru, nbr, rel, Fp, ldp, jb, u, lane, sink);
+                    ea_chunk(U, ldc, nru, nbr, rel, Fp, ldp, rhs_row, jb, u, lane, sink);
                 u -= nch;
             }
             __syncthreads(); // the next child may touch the same parent entries
@@ -912,7 +913,7 @@ __device__ __forceinline__ void dev_backward(const CholPlanDev& p, const double*
                              double* __restrict__ xout)
 {
     const int ncb = p.ncb[f], nb = p.nb[f];
-    const long ld = 6L * nb + 1;
+    const long ld = p.ldf[f];
     const int ncs = 6 * ncb, nrs = 6 * (nb - ncb), ncp = pad16(ncs);
     // L21 and the forward-solved rhs row: compact buffer (upper stages) or the front itself
     const long l21o = p.l21off[f];
@@ -1001,7 +1002,7 @@ __global__ __launch_bounds__(BIG) void k_subtree_factor(CholPlanDev p, double* _
     {
         const int f = p.task_fronts[fi];
         const int ncb = p.ncb[f], nb = p.nb[f];
-        const long ld = 6L * nb + 1;
+        const long ld = p.ldf[f];
         const int ncs = 6 * ncb, nrs = 6 * (nb - ncb), nt = nrs + 1;
         double* F = fronts + p.off[f];
         const int ncp = pad16(ncs);
@@ -1010,7 +1011,8 @@ __global__ __launch_bounds__(BIG) void k_subtree_factor(CholPlanDev p, double* _
         double* Vs = dinv + NC_MAX;
         double* Bt = Vs + (NC_MAX >> 4) * (16 * 17);
         double* Wg = p.winv + p.woff[f];
-        dev_extend_add(p, fronts, f, 0, nb);
+        if (p.alias_of[f] < 0) // a front stored in its only child's update block needs no extend-add
+            dev_extend_add(p, fronts, f, 0, nb);
         dev_potrf(F, ld, ncs, Ls, dinv, fail);
         __syncthreads();
         dev_inv_diag16(Ls, dinv, ncp, Vs);
@@ -1064,7 +1066,7 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
     double* Ls = lds;
     double* dinv = lds + NC_MAX * LLD;
     double* Vs = dinv + NC_MAX;
-    dev_potrf(fronts + p.off[f], 6L * p.nb[f] + 1, ncs, Ls, dinv, fail);
+    dev_potrf(fronts + p.off[f], p.ldf[f], ncs, Ls, dinv, fail);
     __syncthreads();
     stamp(0, 5);
     // one wave per diagonal block (16 lanes each): V_J = inverse of the 16x16 diagonal block
@@ -1085,7 +1087,7 @@ __global__ __launch_bounds__(BIG) void k_up_trsyrk(CholPlanDev p, double* __rest
     const int32_t* it = wl + 3 * blockIdx.x;
     const int f = it[0];
     const int ncs = 6 * p.ncb[f], nrs = 6 * (p.nb[f] - p.ncb[f]);
-    dev_trsyrk_tile(fronts + p.off[f], 6L * p.nb[f] + 1, ncs, nrs + 1, nrs, it[1], it[2],
+    dev_trsyrk_tile(fronts + p.off[f], p.ldf[f], ncs, nrs + 1, nrs, it[1], it[2],
                     p.winv + p.woff[f], p.l21 + p.l21off[f], nrs + 1, lds, p.junk);
     stamp(4, 7);
     stamp_value(4, 6, 1000L * ncs + nrs);

@@ -87,8 +87,11 @@ struct CholPlanDev
     int n_fronts;
     // per front
     const int32_t* ncb;        // pivot block columns
-    const int32_t* nb;         // total block rows (pivot + boundary); scalar ld = 6*nb + 1
+    const int32_t* nb;         // total block rows (pivot + boundary); the rhs row is row 6*nb
     const int64_t* off;        // offset (doubles) of the front matrix in `fronts`
+    const int64_t* ldf;        // leading dimension: 6*nb + 1, or the child's when the front lives in
+                               // the update block of its only child (single-child chains)
+    const int32_t* alias_of;   // that child, or -1
     const int64_t* woff;       // offset (doubles) of W = L11^-1 (pad16(6*ncb)^2, column-major) in winv
     double* winv;
     const int64_t* l21off;     // offset of the front's L21 (+ rhs row) in l21, or -1: in the front itself

@@ -155,7 +155,9 @@ def test_schur_complement_and_backsubst_vs_oracle(ctx, oracle_lib):
 
 
 # CUGO_MIN_SUBTREE_TASKS=0 forces the subtree stage (k_subtree_factor) that small graphs skip
-@pytest.mark.parametrize("env", [{}, {"CUGO_MIN_SUBTREE_TASKS": "0"},
+# CUGO_ALIAS_CHAINS=0 turns off the storage sharing of single-child chains (every front then gets
+# its extend-add)
+@pytest.mark.parametrize("env", [{}, {"CUGO_MIN_SUBTREE_TASKS": "0"}, {"CUGO_ALIAS_CHAINS": "0"},
                                  {"CUGO_ND_LEAF": "4", "CUGO_MAX_SUPER_COLS": "3", "CUGO_TARGET_TASKS": "4",
                                   "CUGO_MIN_SUBTREE_TASKS": "0"},
                                  {"CUGO_ND_LEAF": "1000", "CUGO_MAX_SUPER_COLS": "1", "CUGO_TARGET_TASKS": "100000"},

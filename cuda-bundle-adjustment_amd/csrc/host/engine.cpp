@@ -619,9 +619,10 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
         // build pass (ref: cuda_graph_optimisation.cpp:64-67)
         auto tb = Clock::now();
         m.timed("build", [&] {
+            // chi2 of the build pass is only consumed in the first iteration (see below)
             cugo_k::launch_build(s, m.ev, m.d_poses[m.cur].data(), m.d_lms[m.cur].data(), m.rk,
                                  m.d_Hpp.data(), m.bp(), m.d_Hll.data(), m.bl(), m.d_Hpl.data(),
-                                 m.rs(), m.d_scal.data());
+                                 m.rs(), iteration == 0 ? m.d_scal.data() : nullptr);
         });
         sync_prof(PROF_BUILD_SYSTEM, tb);
         if (iteration == 0)

@@ -735,15 +735,48 @@ __device__ __forceinline__ void hplT_x(const double* __restrict__ H, const doubl
     }
 }
 
+// pose update + scale partials of one 256-pose block (ref: updatePosesKernel .cu:1444)
+__device__ __forceinline__ void dev_update_poses(int blk, int nP, double lambda,
+                                                 const double* __restrict__ xp,
+                                                 const double* __restrict__ bp,
+                                                 const double* __restrict__ poses_in,
+                                                 double* __restrict__ poses_out,
+                                                 double* __restrict__ partials, double* sm)
+{
+    const int p = blk * BS + threadIdx.x;
+    double sc = 0;
+    if (p < nP)
+    {
+        double dx[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+        {
+            dx[i] = xp[6 * (size_t)p + i];
+            sc += dx[i] * (lambda * dx[i] + bp[6 * (size_t)p + i]);
+        }
+        pose_exp_update(dx, poses_in + 7 * (size_t)p, poses_out + 7 * (size_t)p);
+    }
+    sc = block_sum(sc, sm);
+    if (threadIdx.x == 0)
+        partials[blk] = sc;
+}
+
 __global__ __launch_bounds__(BS) void k_backsubst_landmarks(
     EV ev, double lambda, const double* __restrict__ invHll, const double* __restrict__ bl,
     const double* __restrict__ Hpl, const double* __restrict__ xp, double* __restrict__ xl,
     const double* __restrict__ lms_in, double* __restrict__ lms_out,
-    double* __restrict__ partials)
+    double* __restrict__ partials, int nbl, double lambda_pose, const double* __restrict__ bp,
+    const double* __restrict__ poses_in, double* __restrict__ poses_out)
 {
     __shared__ double sm[BS / 64];
     __shared__ double2 hs[BS * 9 + 1];
     __shared__ double cs[3][BS];
+    if ((int)blockIdx.x >= nbl)
+    { // pose update + its scale partials ride in the same launch (ref: updatePosesKernel .cu:1444)
+        dev_update_poses(blockIdx.x - nbl, ev.P, lambda_pose, xp, bp, poses_in, poses_out,
+                         partials + nbl, sm);
+        return;
+    }
     const int t = threadIdx.x;
     const int ebase = blockIdx.x * BS;
     const int e = ebase + t;
@@ -818,33 +851,6 @@ __global__ __launch_bounds__(BS) void k_backsubst_landmarks(
         lms_out[3 * (size_t)e] = lms_in[3 * (size_t)e];
         lms_out[3 * (size_t)e + 1] = lms_in[3 * (size_t)e + 1];
         lms_out[3 * (size_t)e + 2] = lms_in[3 * (size_t)e + 2];
-    }
-    sc = block_sum(sc, sm);
-    if (threadIdx.x == 0)
-        partials[blockIdx.x] = sc;
-}
-
-// pose update + scale partials (ref: updatePosesKernel .cu:1444)
-__global__ __launch_bounds__(BS) void k_update_poses(int nP, double lambda,
-                                                     const double* __restrict__ xp,
-                                                     const double* __restrict__ bp,
-                                                     const double* __restrict__ poses_in,
-                                                     double* __restrict__ poses_out,
-                                                     double* __restrict__ partials)
-{
-    __shared__ double sm[BS / 64];
-    const int p = blockIdx.x * BS + threadIdx.x;
-    double sc = 0;
-    if (p < nP)
-    {
-        double dx[6];
-#pragma unroll
-        for (int i = 0; i < 6; i++)
-        {
-            dx[i] = xp[6 * (size_t)p + i];
-            sc += dx[i] * (lambda * dx[i] + bp[6 * (size_t)p + i]);
-        }
-        pose_exp_update(dx, poses_in + 7 * (size_t)p, poses_out + 7 * (size_t)p);
     }
     sc = block_sum(sc, sm);
     if (threadIdx.x == 0)
@@ -944,12 +950,10 @@ void launch_backsubst_update(hipStream_t s, const cugo_edges& e, double lambda, 
 {
     const EV ev = make_ev(e);
     const int nbl = div_up(ev.E > ev.L ? ev.E : ev.L, BS), nbp = div_up(ev.P, BS);
-    if (nbl > 0)
-        CUGO_LAUNCH(k_backsubst_landmarks, dim3(nbl), dim3(BS), 0, s, ev, lambda, d_invHll,
-                           d_bl, d_Hpl, d_xp, d_xl, d_lms_in, d_lms_out, rs.d_partials);
-    if (nbp > 0)
-        CUGO_LAUNCH(k_update_poses, dim3(nbp), dim3(BS), 0, s, ev.P, lambda_pose, d_xp, d_bp,
-                           d_poses_in, d_poses_out, rs.d_partials + nbl);
+    if (nbl + nbp > 0)
+        CUGO_LAUNCH(k_backsubst_landmarks, dim3(nbl + nbp), dim3(BS), 0, s, ev, lambda, d_invHll,
+                           d_bl, d_Hpl, d_xp, d_xl, d_lms_in, d_lms_out, rs.d_partials, nbl,
+                           lambda_pose, d_bp, d_poses_in, d_poses_out);
     CUGO_LAUNCH(k_sum_partials, dim3(1), dim3(BS), 0, s, rs.d_partials, nbl + nbp, d_scale);
 }
 

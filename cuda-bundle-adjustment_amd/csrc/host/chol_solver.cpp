@@ -93,10 +93,27 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
     }
     for (int st = plan.n_stages - 1; st >= 0; st--)
     {
-        const int t0 = plan.stage_task_ptr[st], t1 = plan.stage_task_ptr[st + 1];
-        cugo_k::launch_chol_backward_stage(s, dev, d_fronts.data(), t0, t1 - t0, lds_backward,
-                                           d_xnew.data(), d_x);
-        if (dbg && st == plan.n_stages - 1)
+        const int t1 = plan.stage_task_ptr[st + 1];
+        // a run of single-front upper levels (the pieces of a wide separator at the top of the
+        // tree) is walked by one workgroup in one launch
+        int lo = st;
+        auto single_upper = [&](int q) {
+            return q >= 0 && plan.stage_task_ptr[q + 1] - plan.stage_task_ptr[q] == 1 &&
+                   !(plan.has_subtree_stage && q == 0);
+        };
+        if (single_upper(st))
+            while (single_upper(lo - 1))
+                lo--;
+        const int t0 = plan.stage_task_ptr[lo];
+        if (lo < st)
+            cugo_k::launch_chol_backward_stage(s, dev, d_fronts.data(), t0, 1, lds_backward, d_xnew.data(),
+                                               d_x, st - lo + 1);
+        else
+            cugo_k::launch_chol_backward_stage(s, dev, d_fronts.data(), t0, t1 - t0, lds_backward,
+                                               d_xnew.data(), d_x, 1);
+        const int st_top = st;
+        st = lo;
+        if (dbg && st_top == plan.n_stages - 1)
         { // keep the top stage's backward stamps (kernel 3) in slots 48.. before stage 0 overwrites them
             CUGO_HIP(hipStreamSynchronize(s));
             CUGO_HIP(hipMemcpy(d_stamps + 48, d_stamps + 24, 8 * sizeof(long long), hipMemcpyDeviceToDevice));

@@ -1096,12 +1096,14 @@ __global__ __launch_bounds__(BIG) void k_up_trsyrk(CholPlanDev p, double* __rest
 __global__ __launch_bounds__(BIG) void k_backward_stage(CholPlanDev p,
                                                         const double* __restrict__ fronts,
                                                         int task0, double* __restrict__ xnew,
-                                                        double* __restrict__ xout)
+                                                        double* __restrict__ xout, int span)
 {
     extern __shared__ double lds[];
     stamp(3, 0);
+    // span > 1 (one workgroup): a run of consecutive single-front levels walked top-down in one
+    // launch — each front only needs its ancestors, which this workgroup has just solved
     const int task = task0 + blockIdx.x;
-    for (int fi = p.task_ptr[task + 1] - 1; fi >= p.task_ptr[task]; fi--)
+    for (int fi = p.task_ptr[task + span] - 1; fi >= p.task_ptr[task]; fi--)
         dev_backward(p, fronts, p.task_fronts[fi], lds, xnew, xout);
     stamp(3, 7);
 }
@@ -1190,13 +1192,13 @@ void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fron
 }
 
 void launch_chol_backward_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,
-                                int ntasks, size_t lds_bytes, double* d_xnew, double* d_x)
+                                int ntasks, size_t lds_bytes, double* d_xnew, double* d_x, int span)
 {
     if (ntasks <= 0)
         return;
     ensure_lds(reinterpret_cast<const void*>(k_backward_stage), lds_bytes);
     CUGO_LAUNCH(k_backward_stage, dim3(ntasks), dim3(BIG), lds_bytes, s, p, d_fronts, task0,
-                       d_xnew, d_x);
+                       d_xnew, d_x, span);
 }
 
 } // namespace cugo_k

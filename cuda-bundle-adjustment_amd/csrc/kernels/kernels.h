@@ -132,8 +132,10 @@ void launch_chol_subtree_stage(hipStream_t s, const CholPlanDev& p, double* d_fr
 void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,
                              int ntasks, const int32_t* d_wl, int eap0, int neap, int ea0, int nea,
                              int sy0, int nsy, size_t lds_bytes, int32_t* d_fail);
+// span > 1 (with ntasks == 1): `span` consecutive single-front levels, tasks task0..task0+span-1,
+// solved top-down by one workgroup in one launch
 void launch_chol_backward_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,
-                                int ntasks, size_t lds_bytes, double* d_xnew, double* d_x);
+                                int ntasks, size_t lds_bytes, double* d_xnew, double* d_x, int span);
 // LDS bytes of the factor kernels (L11 + one 64-row tile) and of the backward kernel
 void set_debug_stamps(long long* d_buf); // diagnostic s_memtime stamps (nullptr = off)
 size_t chol_lds_factor_bytes(int nc_max);

@@ -320,6 +320,60 @@ def test_outlier_rejection_matches_oracle(oracle_lib):
     g.close()
 
 
+def dense_ring_problem(n_poses, n_landmarks, seed):
+    """cameras on a ring looking at a small cloud at the origin: EVERY landmark is seen by EVERY
+    pose (> 256 edges per landmark, a dense Schur complement)"""
+    import synth
+    rng = np.random.default_rng(seed)
+    cam = np.array([718.856, 718.856, 607.1928, 185.2157, 386.1448])
+    lm_true = rng.uniform(-1.0, 1.0, (n_landmarks, 3))
+    poses, meas, ep, el = [], [], [], []
+    for i in range(n_poses):
+        a = 2 * np.pi * i / n_poses
+        C = np.array([12.0 * np.cos(a), 0.4 * np.sin(3 * a), 12.0 * np.sin(a)])
+        z = -C / np.linalg.norm(C)
+        x = np.cross(np.array([0.0, 1.0, 0.0]), z)
+        x /= np.linalg.norm(x)
+        y = np.cross(z, x)
+        R = np.stack([x, y, z])  # rows = camera axes in world coordinates
+        t = -R @ C
+        poses.append(np.concatenate([synth._R_to_quat(R), t]))
+        Xc = lm_true @ R.T + t
+        u = cam[0] * Xc[:, 0] / Xc[:, 2] + cam[2]
+        v = cam[1] * Xc[:, 1] / Xc[:, 2] + cam[3]
+        ur = u - cam[4] / Xc[:, 2]
+        meas.append(np.stack([u, v, ur], 1) + rng.normal(0, 0.5, (n_landmarks, 3)))
+        ep.append(np.full(n_landmarks, i)), el.append(np.arange(n_landmarks))
+    pose = np.array(poses)
+    E = n_poses * n_landmarks
+    d = dict(pose=pose.copy(), lm=lm_true + rng.normal(0, 0.02, lm_true.shape),
+             pose_fixed=np.zeros(n_poses, np.uint8), lm_fixed=np.zeros(n_landmarks, np.uint8),
+             e_pose=np.concatenate(ep).astype(np.int32), e_lm=np.concatenate(el).astype(np.int32),
+             e_stereo=(np.arange(E) % 3 == 0).astype(np.uint8), e_meas=np.concatenate(meas),
+             e_omega=np.full(E, 1.0), e_cam=np.tile(cam, (E, 1)))
+    d["pose_fixed"][0] = 1
+    for i in range(1, n_poses):  # perturb the free poses a little
+        dq = synth.quat_from_rotvec(rng.normal(0, 0.002, 3))
+        d["pose"][i, :4] = synth.quat_mul(dq, pose[i, :4])
+        d["pose"][i, 4:] = synth.quat_to_R(dq) @ pose[i, 4:] + rng.normal(0, 0.01, 3)
+    d["e_meas"][d["e_stereo"] == 0, 2] = 0.0
+    return d
+
+
+def test_landmarks_with_more_than_256_edges_and_dense_schur(oracle_lib):
+    """every landmark is observed by 300 poses: the per-landmark sums leave their 256-edge block
+    (owner-lane slow paths of k_build_edges / k_backsubst_landmarks), Hsc is completely dense and
+    the elimination tree is one long chain of fronts"""
+    d = dense_ring_problem(300, 12, seed=3)
+    prob = oracle_lib.Problem(d["pose"], d["pose_fixed"], d["lm"], d["lm_fixed"], d["e_pose"], d["e_lm"],
+                              d["e_stereo"], d["e_meas"], d["e_omega"], d["e_cam"])
+    out = run_graph(d, 6)
+    ref = prob.optimize(6)
+    assert_trajectories_match(out["stats"], ref, 1e-10)
+    assert rmse(out["pose"], prob.pose) < 1e-9 and rmse(out["lm"], prob.lm) < 1e-9
+    assert out["stats"][-1]["chi2"] <= out["stats"][0]["chi2"]
+
+
 def test_global_information_and_camera_options(oracle_lib):
     d, prob = synth_problem(oracle_lib, 120, 1500, 6200, seed=5, lc=0)
     d["e_omega"][:] = 0.75

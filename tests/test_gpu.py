@@ -374,6 +374,23 @@ def test_landmarks_with_more_than_256_edges_and_dense_schur(oracle_lib):
     assert out["stats"][-1]["chi2"] <= out["stats"][0]["chi2"]
 
 
+@pytest.mark.parametrize("which", ["all_landmarks_fixed", "all_poses_fixed"])
+def test_degenerate_fixed_sets(oracle_lib, which):
+    """pose-only BA (no free landmark: the Schur complement is just Hpp) and structure-only BA
+    (no free pose: an empty pose system, landmarks solved by their 3x3 blocks)"""
+    d, _ = synth_problem(oracle_lib, 30, 400, 1600, seed=5, lc=0)
+    if which == "all_landmarks_fixed":
+        d["lm_fixed"] = np.ones(400, np.uint8)
+    else:
+        d["pose_fixed"] = np.ones(30, np.uint8)
+    prob = oracle_lib.Problem(d["pose"], d["pose_fixed"], d["lm"], d["lm_fixed"], d["e_pose"], d["e_lm"],
+                              d["e_stereo"], d["e_meas"], d["e_omega"], d["e_cam"])
+    out = run_graph(d, 5)
+    ref = prob.optimize(5)
+    assert_trajectories_match(out["stats"], ref, 1e-10)
+    assert rmse(out["pose"], prob.pose) < 1e-10 and rmse(out["lm"], prob.lm) < 1e-10
+
+
 def test_global_information_and_camera_options(oracle_lib):
     d, prob = synth_problem(oracle_lib, 120, 1500, 6200, seed=5, lc=0)
     d["e_omega"][:] = 0.75

@@ -9,8 +9,8 @@ namespace cugo_host
 
 struct CholOptions
 {
-    int nd_leaf = 24;        // nested dissection stops below this many block nodes
-    int max_super_cols = 8;  // relaxed supernodes: at most this many block columns
+    int nd_leaf = 96;        // nested dissection stops below this many block nodes (swept on MI355X: tools/sweep_ordering.sh)
+    int max_super_cols = 16; // relaxed supernodes: at most this many block columns
     double zero_frac = 0.35; // relaxed supernodes: tolerated share of explicit zero blocks
     int target_tasks = 1024; // subtree-to-workgroup granularity of stage 0
     bool alias_chains = true; // single-child fronts with identical rows live in the child's update block

@@ -22,7 +22,8 @@ def main():
     pat = sys.argv[2] if len(sys.argv) > 2 else ""
     tmp = tempfile.mkdtemp(prefix="isa_")
     inc = os.path.join(ROOT, "cuda-bundle-adjustment_amd")
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-pass-failed",
+    contract = "fast" if os.path.basename(src).startswith("chol_") else "off"  # as in the Makefile
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=" + contract, "-Wno-pass-failed",
            "-I", os.path.join(inc, "include"), "-I", os.path.join(ROOT, "include"),
            "--offload-device-only", "-S", src, "-o", os.path.join(tmp, "out.s")]
     subprocess.check_call(cmd, cwd=os.path.dirname(src))

@@ -283,14 +283,23 @@ __device__ __forceinline__ bool panel_factor_wave(double* __restrict__ Ls, int n
 #pragma unroll
     for (int j = 0; j < 6; j++)
     {
-        double d = D[j][j];
-        if (!(d > PIVOT_TOL))
+        const double d = D[j][j];
+        // a pivot <= tol (or NaN) only raises the flag: whatever flows on (NaN from rsq of a
+        // negative number included) is discarded with the rejected LM trial
+        bad = bad || !(d > PIVOT_TOL);
+        // sqrt(d) and 1/sqrt(d) together from one v_rsq_f64 seed (2^-24) and two coupled Newton
+        // steps (the scheme of the IEEE sqrt expansion, without its range scaling and special-case
+        // handling: d is a pivot in (1e-14, huge)): 11 instructions instead of ~28 for sqrt + 1/d
+        double sq, inv;
         {
-            bad = true;
-            d = 1.0; // keep finite numbers flowing; the LM step is rejected anyway
+            const double y = __builtin_amdgcn_rsq(d);
+            double g = d * y, h = 0.5 * y;
+            const double r0 = fma(-h, g, 0.5);
+            g = fma(g, r0, g), h = fma(h, r0, h);
+            const double dg = fma(-g, g, d), rh = fma(-h, g, 0.5);
+            sq = fma(dg, h, g);
+            inv = 2.0 * fma(h, rh, h);
         }
-        const double sq = sqrt(d);
-        const double inv = sq * (1.0 / d); // sqrt and reciprocal run side by side
         iv[j] = inv;
         D[j][j] = sq;
 #pragma unroll

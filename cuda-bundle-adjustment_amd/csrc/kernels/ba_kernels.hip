@@ -76,6 +76,13 @@ __device__ __forceinline__ double block_sum(double v, double* sm)
     return r;
 }
 
+// a wave's own LDS writes become visible to its other lanes (no workgroup barrier needed)
+__device__ __forceinline__ void wave_sync_lds()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
 struct Robust2
 {
     Robust m, s; // mono / stereo edge sets
@@ -223,14 +230,19 @@ __global__ __launch_bounds__(BS) void k_build_edges(EV ev, const double* __restr
                                                     double* __restrict__ Hpl,
                                                     double* __restrict__ Hll,
                                                     double* __restrict__ bl,
+                                                    double* __restrict__ rec,
                                                     double* __restrict__ partials)
 {
     __shared__ double sm[BS / 64];
     __shared__ double cs[9][BS];
+    __shared__ double rs_[BS * 9]; // per-edge records, 9-double lane stride: conflict-free both ways
     const int e = blockIdx.x * BS + threadIdx.x;
     double chi = 0;
     LmContrib lc = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     int l = -1;
+    // record for the pose pass (k_build_poses): Xc, e, w and {camera index, stereo bit}; w = 0 for
+    // an inactive slot.  The pose pass then needs ONE 64-byte line per edge instead of ~8 gathers.
+    double r8[8] = {0, 0, 1, 0, 0, 0, 0, 0};
     if (e < ev.E)
     {
         const uint8_t fl = ev.flags[e];
@@ -247,6 +259,10 @@ __global__ __launch_bounds__(BS) void k_build_edges(EV ev, const double* __restr
             edge_residual(pose, lms + 3 * (size_t)in.il, in.mu, in.mv, in.mr, in.stereo, in.omega,
                           in.cam, in.stereo ? rk.s : rk.m, g);
             chi = g.chi;
+            r8[0] = g.Xc[0], r8[1] = g.Xc[1], r8[2] = g.Xc[2];
+            r8[3] = g.e[0], r8[4] = g.e[1], r8[5] = g.e[2], r8[6] = g.w;
+            r8[7] = __longlong_as_double((long long)(ev.n_cams > 1 ? (int)ev.cam[e] : 0) |
+                                         ((long long)(in.stereo ? 1 : 0) << 16));
             double JL[3][3];
             jac_landmark(g.Xc, pose, in.cam, in.stereo, JL);
             lc = lm_contrib(JL, g, in.stereo);
@@ -275,10 +291,24 @@ __global__ __launch_bounds__(BS) void k_build_edges(EV ev, const double* __restr
         const int t = threadIdx.x;
         cs[0][t] = lc.h00, cs[1][t] = lc.h01, cs[2][t] = lc.h02, cs[3][t] = lc.h11, cs[4][t] = lc.h12;
         cs[5][t] = lc.h22, cs[6][t] = lc.b0, cs[7][t] = lc.b1, cs[8][t] = lc.b2;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            rs_[9 * t + k] = r8[k];
     }
-    chi = block_sum(chi, sm); // contains the barrier that publishes cs[]
+    chi = block_sum(chi, sm); // contains the barrier that publishes cs[] and rs_[]
     if (threadIdx.x == 0)
         partials[blockIdx.x] = chi;
+    { // records of this block's 256 slots -> global, fully coalesced (512 B per wave instruction)
+        const long base = 8L * blockIdx.x * BS;
+        const long limit = 8L * ev.E;
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+        {
+            const int f = i * BS + threadIdx.x; // flat double index within the block's records
+            if (base + f < limit)
+                rec[base + f] = rs_[9 * (f >> 3) + (f & 7)];
+        }
+    }
     if (l >= 0 && l < ev.L && ev.lm_ptr[l] == e)
     { // owner of landmark l
         const int e1 = ev.lm_ptr[l + 1];
@@ -323,26 +353,30 @@ __global__ __launch_bounds__(BS) void k_build_edges(EV ev, const double* __restr
     }
 }
 
-// 27 accumulators of one workgroup -> 27 sums, fixed order (thread-major then 8x32 tree)
+// NV accumulators of one workgroup -> NV sums, fixed order.  Row v of the LDS buffer holds the BS
+// per-thread values of accumulator v (row stride RS = BS + 8 doubles: rows start 16 banks apart);
+// thread (v, g), g < 8, sums the 32 values g, g+8, g+16, ... of its row — the 8 lanes of a row
+// read consecutive addresses, so the walk is (almost) conflict-free, where a contiguous 32-value
+// slice per thread puts all 64 lanes of a wave on one bank — then thread v adds the 8 partials.
+constexpr int RS = BS + 8;
 template <int NV>
-__device__ __forceinline__ void block_reduce_vec(const double (&acc)[NV], double* sm /*NV*BS*/,
+__device__ __forceinline__ void block_reduce_vec(const double (&acc)[NV], double* sm /*NV*RS*/,
                                                  double* out /*NV, LDS*/)
 {
     const int t = threadIdx.x;
 #pragma unroll
     for (int v = 0; v < NV; v++)
-        sm[v * BS + t] = acc[v];
+        sm[v * RS + t] = acc[v];
     __syncthreads();
-    // stage 1: (v, g) sums 32 consecutive threads; NV*8 <= BS required
-    if (t < NV * 8)
+    if (t < NV * 8) // NV*8 <= BS required
     {
         const int v = t >> 3, g = t & 7;
-        const double* p = sm + v * BS + g * 32;
+        const double* p = sm + v * RS + g;
         double s = 0;
 #pragma unroll 8
-        for (int i = 0; i < 32; i++)
-            s += p[i];
-        sm[v * BS + g * 32] = s; // only this thread reads that 32-slot range: no hazard
+        for (int i = 0; i < BS / 8; i++)
+            s += p[8 * i];
+        sm[v * RS + g] = s; // slots g, g+8, ... of a row are read by this thread only: no hazard
     }
     __syncthreads();
     if (t < NV)
@@ -350,7 +384,7 @@ __device__ __forceinline__ void block_reduce_vec(const double (&acc)[NV], double
         double s = 0;
 #pragma unroll
         for (int g = 0; g < 8; g++)
-            s += sm[t * BS + g * 32];
+            s += sm[t * RS + g];
         out[t] = s;
     }
     __syncthreads();
@@ -360,57 +394,76 @@ __device__ __forceinline__ void block_reduce_vec(const double (&acc)[NV], double
 __device__ __forceinline__ constexpr int tri6(int r, int c) { return r * 6 - r * (r - 1) / 2 + (c - r); }
 
 // ---------------------------------------------------------------- build: poses ---------
-// Hpp[p] = sum w JP^T JP, bp[p] = sum w JP^T e; one workgroup per pose
-__global__ __launch_bounds__(BS) void k_build_poses(EV ev, const double* __restrict__ poses,
-                                                    const double* __restrict__ lms, Robust2 rk,
+// Hpp[p] = sum w JP^T JP, bp[p] = sum w JP^T e; one workgroup per pose, one lane per edge.
+// The edge geometry comes from the 64-byte records k_build_edges left behind (Xc, e, w, camera
+// index, stereo bit): each wave fetches the records of its 64 edges with 4 load instructions
+// (4 lanes x 16 B per record: one cache line per edge instead of ~8 scattered lines for the
+// planar measurement / index / landmark gathers), parks them in LDS and every lane reads its own.
+__global__ __launch_bounds__(BS) void k_build_poses(EV ev, const double* __restrict__ rec,
                                                     double* __restrict__ Hpp,
                                                     double* __restrict__ bp)
 {
     extern __shared__ double smem[];
-    double* red = smem;            // 27*BS
-    double* out = smem + 27 * BS;  // 27
+    double* red = smem;            // 27*RS
+    double* out = smem + 27 * RS;  // 27 (+5 pad)
+    // per wave: 64 records x 9 doubles, inside the reduction area (not in use before the barrier below)
+    double* stage = smem + (threadIdx.x >> 6) * (64 * 9);
     const int p = blockIdx.x;
-    double pose[7];
-#pragma unroll
-    for (int i = 0; i < 7; i++)
-        pose[i] = poses[7 * (size_t)p + i];
+    const int lane = threadIdx.x & 63;
     double acc[27];
 #pragma unroll
     for (int i = 0; i < 27; i++)
         acc[i] = 0;
     const int i0 = ev.pose_ptr[p], i1 = ev.pose_ptr[p + 1];
-    for (int i = i0 + threadIdx.x; i < i1; i += BS)
-    {
-        const int e = ev.pose_edge[i];
-        const uint8_t fl = ev.flags[e];
-        if (fl & CUGO_EDGE_INACTIVE)
-            continue;
-        const EdgeIn in = load_edge(ev, e, fl);
-        EdgeGeom g;
-        edge_residual(pose, lms + 3 * (size_t)in.il, in.mu, in.mv, in.mr, in.stereo, in.omega,
-                      in.cam, in.stereo ? rk.s : rk.m, g);
-        double JP[3][6];
-        jac_pose(g.Xc, in.cam, in.stereo, JP);
-        int k = 0;
+    const double2* rec2 = reinterpret_cast<const double2*>(rec);
+    for (int ibase = i0 + (threadIdx.x & ~63); ibase < i1; ibase += BS)
+    { // wave-uniform loop: this wave's 64 list entries [ibase, ibase + 64)
+        const int i = ibase + lane;
+        const int e = ev.pose_edge[min(i, i1 - 1)];
 #pragma unroll
-        for (int r = 0; r < 6; r++)
-#pragma unroll
-            for (int c = r; c < 6; c++)
-            {
-                double s = JP[0][r] * JP[0][c] + JP[1][r] * JP[1][c];
-                if (in.stereo)
-                    s += JP[2][r] * JP[2][c];
-                acc[k++] += g.w * s;
-            }
-#pragma unroll
-        for (int r = 0; r < 6; r++)
-        {
-            double s = JP[0][r] * g.e[0] + JP[1][r] * g.e[1];
-            if (in.stereo)
-                s += JP[2][r] * g.e[2];
-            acc[21 + r] += g.w * s;
+        for (int q = 0; q < 4; q++)
+        { // 16 records per instruction: lanes 4j..4j+3 read the 4 quarters of record 16q + j
+            const int j = 16 * q + (lane >> 2), part = lane & 3;
+            const int ej = __shfl(e, j, 64);
+            const double2 v = rec2[4 * (size_t)ej + part];
+            stage[9 * j + 2 * part] = v.x;
+            stage[9 * j + 2 * part + 1] = v.y;
         }
+        wave_sync_lds();
+        if (i < i1)
+        {
+            const double* r = stage + 9 * lane;
+            const double Xc[3] = {r[0], r[1], r[2]};
+            const double ee[3] = {r[3], r[4], r[5]};
+            const double w = r[6];
+            const long long meta = __double_as_longlong(r[7]);
+            const bool stereo = ((meta >> 16) & 1) != 0;
+            const double* cam = ev.cams + 5 * (int)(meta & 0xFFFF);
+            double JP[3][6];
+            jac_pose(Xc, cam, stereo, JP);
+            int k = 0;
+#pragma unroll
+            for (int rr = 0; rr < 6; rr++)
+#pragma unroll
+                for (int c = rr; c < 6; c++)
+                {
+                    double sacc = JP[0][rr] * JP[0][c] + JP[1][rr] * JP[1][c];
+                    if (stereo)
+                        sacc += JP[2][rr] * JP[2][c];
+                    acc[k++] += w * sacc;
+                }
+#pragma unroll
+            for (int rr = 0; rr < 6; rr++)
+            {
+                double sacc = JP[0][rr] * ee[0] + JP[1][rr] * ee[1];
+                if (stereo)
+                    sacc += JP[2][rr] * ee[2];
+                acc[21 + rr] += w * sacc;
+            }
+        }
+        wave_sync_lds(); // the slot is refilled by the next round
     }
+    __syncthreads(); // every wave is done with its staging slot: the area becomes the reduction buffer
     block_reduce_vec<27>(acc, red, out);
     const int t = threadIdx.x;
     if (t < 36)
@@ -635,11 +688,6 @@ __global__ __launch_bounds__(HD_BS) void k_hsc_diag(EV ev, const int32_t* __rest
 // accumulates its own element over the chunk: no cross-lane reduction, summation in list order
 // (bit-reproducible).  The next chunk's loads are in flight while the current one is consumed.
 constexpr int OD_CH = 14; // products per chunk: two 7-product groups per load round
-__device__ __forceinline__ void wave_sync_lds()
-{
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-}
 __global__ __launch_bounds__(BS) void k_hsc_offdiag(int nblocks,
                                                     const int32_t* __restrict__ off_ptr,
                                                     const int32_t* __restrict__ off_ei,
@@ -868,9 +916,15 @@ static LaunchHook* g_hook = nullptr;
 void set_launch_hook(LaunchHook* h) { g_hook = h; }
 LaunchHook* launch_hook() { return g_hook; }
 
+// scratch = [block partials | per-edge records of the build pass (8 doubles per slot)]
+static size_t scratch_partials(int n_edges, int n_poses, int n_landmarks)
+{
+    const size_t n = (size_t)div_up(n_edges, BS) + div_up(n_poses, BS) + div_up(n_landmarks, BS) + 4096;
+    return (n + 31) & ~size_t(31); // the records start 256-byte aligned
+}
 size_t reduce_scratch_doubles(int n_edges, int n_poses, int n_landmarks)
 {
-    return (size_t)div_up(n_edges, BS) + div_up(n_poses, BS) + div_up(n_landmarks, BS) + 4096;
+    return scratch_partials(n_edges, n_poses, n_landmarks) + 8 * ((size_t)n_edges + BS);
 }
 
 void launch_errors(hipStream_t s, const cugo_edges& e, const double* d_poses, const double* d_lms,
@@ -901,14 +955,15 @@ void launch_build(hipStream_t s, const cugo_edges& e, const double* d_poses, con
     const EV ev = make_ev(e);
     const Robust2 r{{rk.type, rk.delta}, {rk.type_stereo, rk.delta_stereo}};
     const int nb = div_up(ev.E > ev.L ? ev.E : ev.L, BS); // also covers the edgeless landmarks
+    double* d_rec = rs.d_partials + scratch_partials(ev.E, ev.P, ev.L);
     if (nb > 0)
         CUGO_LAUNCH(k_build_edges, dim3(nb), dim3(BS), 0, s, ev, d_poses, d_lms, r, d_Hpl, d_Hll,
-                           d_bl, rs.d_partials);
+                           d_bl, d_rec, rs.d_partials);
     if (d_chi)
         CUGO_LAUNCH(k_sum_partials, dim3(1), dim3(BS), 0, s, rs.d_partials, nb, d_chi);
     if (ev.P > 0)
-        CUGO_LAUNCH(k_build_poses, dim3(ev.P), dim3(BS), (27 * BS + 32) * sizeof(double), s,
-                           ev, d_poses, d_lms, r, d_Hpp, d_bp);
+        CUGO_LAUNCH(k_build_poses, dim3(ev.P), dim3(BS),
+                           (27 * RS + 32) * sizeof(double), s, ev, d_rec, d_Hpp, d_bp);
 }
 
 void launch_max_diagonal(hipStream_t s, const double* d_Hpp, int nP, const double* d_Hll, int nL,

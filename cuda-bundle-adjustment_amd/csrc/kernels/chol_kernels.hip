@@ -87,14 +87,15 @@ __global__ __launch_bounds__(CBS) void k_assemble_rhs(CholPlanDev p, double* __r
 // (a run-time null check would cost a dependent global load per call).
 #ifdef CUGO_STAMPS
 __device__ long long* g_stamps = nullptr;
+__device__ int g_stamp_block[8] = {0, 0, 0, 0, 1, 0, 0, 0}; // per kernel: the workgroup that stamps
 __device__ __forceinline__ void stamp(int kernel, int slot)
 {
-    if (g_stamps && blockIdx.x == 0 && threadIdx.x == 0)
+    if (g_stamps && (int)blockIdx.x == g_stamp_block[kernel] && threadIdx.x == 0)
         g_stamps[kernel * 8 + slot] = clock64();
 }
 __device__ __forceinline__ void stamp_value(int kernel, int slot, long long v)
 {
-    if (g_stamps && blockIdx.x == 0 && threadIdx.x == 0)
+    if (g_stamps && (int)blockIdx.x == g_stamp_block[kernel] && threadIdx.x == 0)
         g_stamps[kernel * 8 + slot] = v;
 }
 #else
@@ -211,6 +212,14 @@ __device__ __forceinline__ void dev_extend_add(const CholPlanDev& p, double* __r
 }
 
 __device__ __forceinline__ int pad16(int nc) { return (nc + 15) & ~15; }
+
+// load base[idx] with a 32-bit BYTE offset: `uniform 64-bit base + zero-extended 32-bit offset` is
+// the addressing mode of global_load (saddr + voffset) — one VALU instruction per address instead
+// of a 64-bit multiply-add pair.  idx * 8 must fit 32 bits (a front / a W block always does).
+__device__ __forceinline__ double ldg32(const double* __restrict__ base, unsigned idx)
+{
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + (idx << 3));
+}
 
 // lower triangle of F11 -> LDS (upper part zero), padded to a multiple of 16 with an identity
 // block (W = L11^-1 is built from 16-column blocks).  The LDS copy always has leading dimension
@@ -785,7 +794,11 @@ __device__ __forceinline__ void dev_trsyrk_tile(double* __restrict__ F, long ld,
     constexpr int KC = KC_SYRK;
     double* sink = junk + ((blockIdx.x & 63) << 10) + threadIdx.x; // private slot of this lane
     const int ncp = pad16(ncs), nblk = ncp >> 4;
-    const int tt = threadIdx.x, lane = tt & 63, w = tt >> 6, ln = lane & 15, lk = lane >> 4;
+    const int tt = threadIdx.x, lane = tt & 63, ln = lane & 15, lk = lane >> 4;
+    // the wave index as a scalar: everything derived from it (roles, block assignment, K-block
+    // counts, column indices) then lives in SGPRs and branches on it are scalar branches — an
+    // exec-mask region per conditional load costs ~14 instructions, the load itself one
+    const int w = __builtin_amdgcn_readfirstlane(tt >> 6);
     const int rg = w & 3, g = w >> 2; // trsm role: row group, column-block group
     const int wc = w & 3, wr = w >> 2; // syrk role: column / row sub-tile
     const bool solo = tj < 0, diag = tj == ti, two = !solo && !diag;
@@ -798,26 +811,40 @@ __device__ __forceinline__ void dev_trsyrk_tile(double* __restrict__ F, long ld,
     stamp(4, 1);
     // ---- all global loads first: W operands, the B tile(s), the U entries to update
     double a[6][4];
+    const unsigned uncp = (unsigned)ncp;
 #pragma unroll
     for (int u = 0; u < 6; u++)
     {
-        const int cb = u < nA ? cbA : cbB, kb = u < nA ? u : u - nA;
 #pragma unroll
         for (int kk = 0; kk < 4; kk++)
-            a[u][kk] = (u < nU) ? Wg[(unsigned)((16 * kb + lk + 4 * kk) * ncp + 16 * cb + ln)] : 0.0;
+            a[u][kk] = 0.0;
+        if (u < nU) // scalar
+        {
+            const int cb = u < nA ? cbA : cbB, kb = u < nA ? u : u - nA;
+            const unsigned off = (unsigned)(16 * kb + lk) * uncp + (unsigned)(16 * cb + ln);
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++)
+                a[u][kk] = ldg32(Wg, off + (unsigned)(4 * kk) * uncp);
+        }
     }
     {
-        const int r = tt & 63, kq = tt >> 6;
+        const int r = lane, kq = w;
         const int gi = 64 * ti + r, gj = 64 * tj + r;
         const double* B = F + ncs; // (row i, col k) = B[k*ld + i]; 32-bit offsets from the uniform base
         const unsigned uld = (unsigned)ld;
+        // rows past the end are clamped (a valid address, no branch) and zeroed afterwards
+        const unsigned gic = (unsigned)min(gi, nt - 1), gjc = (unsigned)min(max(gj, 0), nt - 1);
+        const bool iok = gi < nt, jok = two && gj < nt;
         double vi[6], vj[6];
 #pragma unroll
         for (int u = 0; u < 6; u++)
         {
-            const int k = kq + 16 * u;
-            vi[u] = (k < ncs && gi < nt) ? B[(unsigned)k * uld + (unsigned)gi] : 0.0;
-            vj[u] = (two && k < ncs && gj < nt) ? B[(unsigned)k * uld + (unsigned)gj] : 0.0;
+            const int k = kq + 16 * u; // scalar
+            const unsigned kc = (unsigned)min(k, ncs - 1);
+            const double bi = ldg32(B, kc * uld + gic);
+            const double bj = two ? ldg32(B, kc * uld + gjc) : 0.0; // `two` is uniform
+            vi[u] = (k < ncs && iok) ? bi : 0.0;
+            vj[u] = (k < ncs && jok) ? bj : 0.0;
         }
         double uold[4];
 #pragma unroll
@@ -1099,7 +1126,7 @@ __global__ __launch_bounds__(BIG) void k_up_trsyrk(CholPlanDev p, double* __rest
     dev_trsyrk_tile(fronts + p.off[f], p.ldf[f], ncs, nrs + 1, nrs, it[1], it[2],
                     p.winv + p.woff[f], p.l21 + p.l21off[f], nrs + 1, lds, p.junk);
     stamp(4, 7);
-    stamp_value(4, 6, 1000L * ncs + nrs);
+    stamp_value(4, 6, 1000000L * (it[1] * 10 + it[2] + 1) + 1000L * ncs + nrs);
 }
 
 __global__ __launch_bounds__(BIG) void k_backward_stage(CholPlanDev p,

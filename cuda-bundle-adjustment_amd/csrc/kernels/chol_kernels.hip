@@ -239,7 +239,7 @@ __device__ __forceinline__ void dev_load_l11(const double* __restrict__ F, long 
         for (int q = 0; q < 3; q++)
         {
             const int c = ty + 32 * u, r = tx + 32 * q;
-            v[u][q] = F[(unsigned)min(c, nc - 1) * uld + (unsigned)min(r, nc - 1)];
+            v[u][q] = ldg32(F, (unsigned)min(c, nc - 1) * uld + (unsigned)min(r, nc - 1));
         }
 #pragma unroll
     for (int u = 0; u < 3; u++)

@@ -680,6 +680,9 @@ __device__ __forceinline__ void dev_trsm_w(double* __restrict__ F, long ld, int 
 constexpr int PST = 80;  // LDS panel stride (doubles) per k
 constexpr int KC_SYRK = 96; // K extent staged per barrier pair (= the widest pivot block)
 constexpr int syrk_lds() { return 2 * KC_SYRK * PST; } // doubles
+// fused trsm+syrk tile kernel: two panels at stride TPST plus the lower block triangle of W
+constexpr int TPST = 72;
+constexpr int trsyrk_lds() { return 2 * KC_SYRK * TPST + 21 * 256; } // doubles
 
 __device__ __forceinline__ void dev_syrk_tiles(double* __restrict__ F, long ld, int ncs, int nt, int nrs,
                                int first_tile, int ntiles_total, int ntj, double* __restrict__ lds,
@@ -792,6 +795,7 @@ __device__ __forceinline__ void dev_trsyrk_tile(double* __restrict__ F, long ld,
                                                 double* __restrict__ lds, double* __restrict__ junk)
 {
     constexpr int KC = KC_SYRK;
+    constexpr int PST = TPST; // panel stride of this kernel (leaves LDS room for W)
     double* sink = junk + ((blockIdx.x & 63) << 10) + threadIdx.x; // private slot of this lane
     const int ncp = pad16(ncs), nblk = ncp >> 4;
     const int tt = threadIdx.x, lane = tt & 63, ln = lane & 15, lk = lane >> 4;
@@ -804,28 +808,30 @@ __device__ __forceinline__ void dev_trsyrk_tile(double* __restrict__ F, long ld,
     const bool solo = tj < 0, diag = tj == ti, two = !solo && !diag;
     double* Pi = lds;
     double* Pj = lds + KC * PST;
+    double* Wl = lds + 2 * KC * PST; // lower block triangle of W, block (I,K) at (I(I+1)/2 + K)*256, [k][m]
     double* U = F + (long)ncs * ld + ncs;
     int cbA, cbB;
     deal_col_blocks(nblk, g, cbA, cbB);
     const int nA = cbA + 1, nU = nA + cbB + 1;
     stamp(4, 1);
-    // ---- all global loads first: W operands, the B tile(s), the U entries to update
-    double a[6][4];
-    const unsigned uncp = (unsigned)ncp;
+    // ---- all global loads first: W (once per workgroup, into LDS: every wave re-loading its own
+    // operands costs 4x the cache-line traffic and the load phase is bound by the per-CU line
+    // rate), the B tile(s), the U entries to update
+    const int nwblk = nblk * (nblk + 1) / 2;
+    double wv[6];
+    int wdst[6];
 #pragma unroll
     for (int u = 0; u < 6; u++)
     {
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++)
-            a[u][kk] = 0.0;
-        if (u < nU) // scalar
-        {
-            const int cb = u < nA ? cbA : cbB, kb = u < nA ? u : u - nA;
-            const unsigned off = (unsigned)(16 * kb + lk) * uncp + (unsigned)(16 * cb + ln);
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++)
-                a[u][kk] = ldg32(Wg, off + (unsigned)(4 * kk) * uncp);
-        }
+        const int f = tt + u * 1024; // element of the staged triangle: block f>>8, k = (f>>4)&15, m = f&15
+        const int blk = min(f >> 8, nwblk - 1);
+        int I = 0;
+        while ((I + 1) * (I + 2) / 2 <= blk)
+            I++;
+        const int K = blk - I * (I + 1) / 2;
+        const int k = (f >> 4) & 15, m = f & 15;
+        wdst[u] = (f >> 8) < nwblk ? f : -1;
+        wv[u] = ldg32(Wg, (unsigned)(16 * K + k) * (unsigned)ncp + (unsigned)(16 * I + m));
     }
     {
         const int r = lane, kq = w;
@@ -866,6 +872,10 @@ __device__ __forceinline__ void dev_trsyrk_tile(double* __restrict__ F, long ld,
                     Pj[k * PST + r] = vj[u];
             }
         }
+#pragma unroll
+        for (int u = 0; u < 6; u++)
+            if (wdst[u] >= 0)
+                Wl[wdst[u]] = wv[u];
         stamp(4, 2);
         __syncthreads();
         stamp(4, 3);
@@ -878,14 +888,16 @@ __device__ __forceinline__ void dev_trsyrk_tile(double* __restrict__ F, long ld,
             {
                 if (u < nU)
                 {
-                    const int kb = u < nA ? u : u - nA;
+                    const int cb = u < nA ? cbA : cbB, kb = u < nA ? u : u - nA;
+                    const double* Wb = Wl + (cb * (cb + 1) / 2 + kb) * 256 + lk * 16 + ln; // W[16cb+m][16kb+k]
 #pragma unroll
                     for (int kk = 0; kk < 4; kk++)
                     {
                         const int ko = (16 * kb + lk + 4 * kk) * PST + 16 * rg + ln;
-                        ai = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][kk], Pi[ko], ai, 0, 0, 0);
+                        const double av = Wb[64 * kk];
+                        ai = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Pi[ko], ai, 0, 0, 0);
                         if (two)
-                            aj = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][kk], Pj[ko], aj, 0, 0, 0);
+                            aj = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Pj[ko], aj, 0, 0, 0);
                     }
                     if (u == nA - 1)
                         xi[0] = ai, xj[0] = aj, ai = double4_t{0, 0, 0, 0}, aj = double4_t{0, 0, 0, 0};
@@ -1221,8 +1233,8 @@ void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fron
                 task0, ntasks, d_wl + 3L * ea0, d_fail);
     if (nsy > 0)
     {
-        ensure_lds(reinterpret_cast<const void*>(k_up_trsyrk), syrk_lds() * sizeof(double));
-        CUGO_LAUNCH(k_up_trsyrk, dim3(nsy), dim3(BIG), syrk_lds() * sizeof(double), s, p, d_fronts,
+        ensure_lds(reinterpret_cast<const void*>(k_up_trsyrk), trsyrk_lds() * sizeof(double));
+        CUGO_LAUNCH(k_up_trsyrk, dim3(nsy), dim3(BIG), trsyrk_lds() * sizeof(double), s, p, d_fronts,
                            d_wl + 3L * sy0);
     }
 }

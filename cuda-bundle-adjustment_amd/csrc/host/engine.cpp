@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <numeric>
+#include <thread>
 
 #include "../kernels/kernels.h"
 #include "chol_solver.h"
@@ -360,34 +361,52 @@ void Engine::initialize(FlatGraph&& g)
         m.slot_threshold.assign(E, 0.0);
     m.Etot = Etot;
     m.last_err_buf = 0;
-    for (int i = 0; i < E; i++)
-    {
-        if (slot_src[i] < 0)
-        { // padding: inactive edge of the previous slot's landmark
-            m.h_e_pose[i] = 0;
-            m.h_e_lm[i] = m.h_e_lm[i - 1];
-            m.h_flags[i] = CUGO_EDGE_INACTIVE;
-            meas[i] = meas[(size_t)E + i] = meas[2 * (size_t)E + i] = 0.0;
+    auto fill_slots = [&](int ia, int ib) {
+        for (int i = ia; i < ib; i++)
+        {
+            if (slot_src[i] < 0)
+            { // padding: inactive edge of the landmark of the nearest real slot before it
+                int j = i - 1;
+                while (slot_src[j] < 0)
+                    j--;
+                m.h_e_pose[i] = 0;
+                m.h_e_lm[i] = g.e_lm[order[slot_src[j]]];
+                m.h_flags[i] = CUGO_EDGE_INACTIVE;
+                meas[i] = meas[(size_t)E + i] = meas[2 * (size_t)E + i] = 0.0;
+                if (m.n_omega > 1)
+                    omega[i] = 0.0;
+                if (m.n_cams > 1)
+                    cam[i] = 0;
+                continue;
+            }
+            const int e = order[slot_src[i]];
+            m.slot_edge[i] = e;
+            if (any_threshold)
+                m.slot_threshold[i] = g.e_outlier_threshold[e];
+            m.h_e_pose[i] = g.e_pose[e];
+            m.h_e_lm[i] = g.e_lm[e];
+            m.h_flags[i] = g.e_flags[e];
+            meas[i] = g.e_meas[3 * (size_t)e];
+            meas[(size_t)E + i] = g.e_meas[3 * (size_t)e + 1];
+            meas[2 * (size_t)E + i] = g.e_meas[3 * (size_t)e + 2];
             if (m.n_omega > 1)
-                omega[i] = 0.0;
+                omega[i] = g.e_omega[e];
             if (m.n_cams > 1)
-                cam[i] = 0;
-            continue;
+                cam[i] = g.e_cam[e];
         }
-        const int e = order[slot_src[i]];
-        m.slot_edge[i] = e;
-        if (any_threshold)
-            m.slot_threshold[i] = g.e_outlier_threshold[e];
-        m.h_e_pose[i] = g.e_pose[e];
-        m.h_e_lm[i] = g.e_lm[e];
-        m.h_flags[i] = g.e_flags[e];
-        meas[i] = g.e_meas[3 * (size_t)e];
-        meas[(size_t)E + i] = g.e_meas[3 * (size_t)e + 1];
-        meas[2 * (size_t)E + i] = g.e_meas[3 * (size_t)e + 2];
-        if (m.n_omega > 1)
-            omega[i] = g.e_omega[e];
-        if (m.n_cams > 1)
-            cam[i] = g.e_cam[e];
+    };
+    { // independent per slot: split over a few host threads for big graphs
+        const unsigned nth = E < 100000 ? 1u : std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+        if (nth == 1)
+            fill_slots(0, E);
+        else
+        {
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < nth; t++)
+                pool.emplace_back(fill_slots, (int)((long)E * t / nth), (int)((long)E * (t + 1) / nth));
+            for (auto& th : pool)
+                th.join();
+        }
     }
     // ---- pose-major view (stable counting sort => ascending landmark inside a pose) ----
     m.h_pose_ptr.assign(m.Pall + 1, 0);

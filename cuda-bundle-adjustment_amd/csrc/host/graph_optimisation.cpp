@@ -3,7 +3,11 @@
 // (initialize), src/optimisable_graph.hpp:84-154, 474-572 (index / flag / activeness rules).
 #include "../../include/cuda_graph_optimisation.h"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <stdexcept>
 
 #include "engine.h"
@@ -116,15 +120,29 @@ void CudaGraphOptimisationImpl::initialize()
         vs->gatherEstimates(vs->isMarginilised() ? g.lms.data() : g.poses.data());
 
     // ---- edges: every edge with at least one free endpoint is active -------------------
+    // Walking 561k edge objects through virtual getters is the bulk of initialize(); the walk of
+    // each edge set is split over worker threads.  Every thread writes its contiguous chunk
+    // straight into the final arrays (sized for all edges up front, so the first touch of the
+    // pages is parallel too); chunks with skipped edges are compacted afterwards, in order, so
+    // the flattened order is exactly the container order.
     size_t cap = 0;
     for (BaseEdgeSet* es : edgeSets)
         cap += es->nedges();
-    g.e_pose.reserve(cap), g.e_lm.reserve(cap), g.e_flags.reserve(cap);
-    g.e_meas.reserve(3 * cap), g.e_omega.reserve(cap), g.e_cam.reserve(cap);
-    flatEdges_.clear(), flatEdgeSets_.clear();
-    flatEdges_.reserve(cap), flatEdgeSets_.reserve(cap);
-    bool omega_uniform = true, rk_set[2] = {false, false}, any_threshold = false;
+    g.e_pose.resize(cap), g.e_lm.resize(cap), g.e_flags.resize(cap);
+    g.e_meas.resize(3 * cap), g.e_omega.resize(cap), g.e_cam.resize(cap);
+    g.e_outlier_threshold.resize(cap);
+    flatEdges_.resize(cap), flatEdgeSets_.resize(cap);
+    bool omega_uniform = true, any_threshold = false;
     cugo_robust rk{CUGO_RK_NONE, 1.0, CUGO_RK_NONE, 1.0};
+    struct Chunk
+    {
+        size_t begin = 0, count = 0;  // slot range written: [begin, begin + count)
+        std::vector<double> cams;     // distinct cameras of this chunk (5 each), first-seen order
+        bool uniform = true;
+        bool too_many_cams = false;
+    };
+    const unsigned hw = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    size_t out = 0; // slots filled so far (compacted)
     for (BaseEdgeSet* es : edgeSets)
     {
         const int dim = es->dim();
@@ -133,64 +151,148 @@ void CudaGraphOptimisationImpl::initialize()
         const uint8_t stereo_bit = dim == 3 ? CUGO_EDGE_STEREO : 0;
         const RobustKernel& k = es->getRobustKernel();
         if (dim == 3)
-            rk.type_stereo = rk_code(k.type()), rk.delta_stereo = k.delta(), rk_set[1] = true;
+            rk.type_stereo = rk_code(k.type()), rk.delta_stereo = k.delta();
         else
-            rk.type = rk_code(k.type()), rk.delta = k.delta(), rk_set[0] = true;
-        size_t nactive = 0;
+            rk.type = rk_code(k.type()), rk.delta = k.delta();
         const double set_threshold = es->getOutlierThreshold();
         any_threshold = any_threshold || set_threshold > 0.0;
         es->setOutlierCount(0);
         const double set_info = es->getInformation();
         const Camera set_cam = es->getCamera();
-        for (BaseEdge* e : es->get())
+        const EdgeContainer& ec = es->get();
+        const size_t n = ec.size();
+        const unsigned nthreads = n < 20000 ? 1u : hw;
+        std::vector<Chunk> chunks(nthreads);
+        const bool perInfo = options.perEdgeInformation, perCam = options.perEdgeCamera;
+        const size_t base = out; // this set's edges go to slots [base, base + n) before compaction
+        auto work = [&](unsigned t) {
+            Chunk& c = chunks[t];
+            const size_t i0 = n * t / nthreads, i1 = n * (t + 1) / nthreads;
+            c.begin = base + i0;
+            size_t o = c.begin;
+            auto it = ec.begin() + i0;
+            uint16_t last_cam = 0;
+            for (size_t i = i0; i < i1; ++i, ++it)
+            {
+                BaseEdge* e = *it;
+                if (!e->isActive())
+                    continue;
+                BaseVertex* vp = e->getVertex(0);
+                BaseVertex* vl = e->getVertex(1);
+                const bool fp = vp->isFixed(), fl = vl->isFixed();
+                if (fp && fl)
+                    continue;
+                flatEdges_[o] = e, flatEdgeSets_[o] = es;
+                g.e_outlier_threshold[o] = set_threshold;
+                g.e_pose[o] = vp->getIndex();
+                g.e_lm[o] = vl->getIndex();
+                g.e_flags[o] = (uint8_t)((fl ? CUGO_EDGE_FIXED_L : 0) | (fp ? CUGO_EDGE_FIXED_P : 0) | stereo_bit);
+                const double* mz = static_cast<const double*>(e->getMeasurement());
+                g.e_meas[3 * o] = mz[0];
+                g.e_meas[3 * o + 1] = mz[1];
+                g.e_meas[3 * o + 2] = dim == 3 ? mz[2] : 0.0;
+                const double w = perInfo ? (double)e->getInformation() : set_info;
+                if (o > c.begin && w != g.e_omega[c.begin])
+                    c.uniform = false;
+                g.e_omega[o] = w;
+                const Camera& cm = perCam ? e->getCamera() : set_cam;
+                const double cv[5] = {cm.fx, cm.fy, cm.cx, cm.cy, cm.bf};
+                // deduplicate cameras: last-hit fast path, then a short linear scan
+                int ci = -1;
+                const size_t ncam = c.cams.size() / 5;
+                if (ncam > 0 && std::memcmp(&c.cams[5 * (size_t)last_cam], cv, sizeof cv) == 0)
+                    ci = last_cam;
+                else
+                    for (size_t k2 = 0; k2 < ncam; k2++)
+                        if (std::memcmp(&c.cams[5 * k2], cv, sizeof cv) == 0)
+                        {
+                            ci = (int)k2;
+                            break;
+                        }
+                if (ci < 0)
+                {
+                    if (ncam >= 65535)
+                    {
+                        c.too_many_cams = true;
+                        ci = 0;
+                    }
+                    else
+                    {
+                        ci = (int)ncam;
+                        c.cams.insert(c.cams.end(), cv, cv + 5);
+                    }
+                }
+                last_cam = (uint16_t)ci;
+                g.e_cam[o] = (uint16_t)ci; // chunk-local index, remapped below
+                o++;
+            }
+            c.count = o - c.begin;
+        };
+        if (nthreads == 1)
+            work(0);
+        else
         {
-            if (!e->isActive())
-                continue;
-            BaseVertex* vp = e->getVertex(0);
-            BaseVertex* vl = e->getVertex(1);
-            const bool fp = vp->isFixed(), fl = vl->isFixed();
-            if (fp && fl)
-                continue;
-            nactive++;
-            flatEdges_.push_back(e), flatEdgeSets_.push_back(es);
-            g.e_outlier_threshold.push_back(set_threshold);
-            g.e_pose.push_back(vp->getIndex());
-            g.e_lm.push_back(vl->getIndex());
-            g.e_flags.push_back((uint8_t)((fl ? CUGO_EDGE_FIXED_L : 0) | (fp ? CUGO_EDGE_FIXED_P : 0) | stereo_bit));
-            const double* mz = static_cast<const double*>(e->getMeasurement());
-            g.e_meas.push_back(mz[0]);
-            g.e_meas.push_back(mz[1]);
-            g.e_meas.push_back(dim == 3 ? mz[2] : 0.0);
-            const double w = options.perEdgeInformation ? (double)e->getInformation() : set_info;
-            if (!g.e_omega.empty() && w != g.e_omega[0])
-                omega_uniform = false;
-            g.e_omega.push_back(w);
-            const Camera& c = options.perEdgeCamera ? e->getCamera() : set_cam;
-            const double cv[5] = {c.fx, c.fy, c.cx, c.cy, c.bf};
-            // deduplicate cameras: last-hit fast path, then a short linear scan
-            int ci = -1;
-            const size_t ncam = g.cams.size() / 5;
-            if (!g.e_cam.empty() && std::memcmp(&g.cams[5 * (size_t)g.e_cam.back()], cv, sizeof cv) == 0)
-                ci = g.e_cam.back();
-            else
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < nthreads; t++)
+                pool.emplace_back(work, t);
+            for (auto& th : pool)
+                th.join();
+        }
+        size_t nactive = 0;
+        for (Chunk& c : chunks)
+        {
+            if (c.too_many_cams)
+                throw std::runtime_error("cugo: more than 65535 distinct cameras");
+            // merge this chunk's cameras into the global table (first-seen order is kept)
+            std::vector<uint16_t> remap(c.cams.size() / 5);
+            bool identity = true;
+            for (size_t q = 0; q < remap.size(); q++)
+            {
+                int ci = -1;
+                const size_t ncam = g.cams.size() / 5;
                 for (size_t k2 = 0; k2 < ncam; k2++)
-                    if (std::memcmp(&g.cams[5 * k2], cv, sizeof cv) == 0)
+                    if (std::memcmp(&g.cams[5 * k2], &c.cams[5 * q], 5 * sizeof(double)) == 0)
                     {
                         ci = (int)k2;
                         break;
                     }
-            if (ci < 0)
-            {
-                if (ncam >= 65535)
-                    throw std::runtime_error("cugo: more than 65535 distinct cameras");
-                ci = (int)ncam;
-                g.cams.insert(g.cams.end(), cv, cv + 5);
+                if (ci < 0)
+                {
+                    if (ncam >= 65535)
+                        throw std::runtime_error("cugo: more than 65535 distinct cameras");
+                    ci = (int)ncam;
+                    g.cams.insert(g.cams.end(), c.cams.begin() + 5 * q, c.cams.begin() + 5 * q + 5);
+                }
+                remap[q] = (uint16_t)ci;
+                identity = identity && ci == (int)q;
             }
-            g.e_cam.push_back((uint16_t)ci);
+            if (c.count > 0 && (!c.uniform || (out > 0 && g.e_omega[c.begin] != g.e_omega[0])))
+                omega_uniform = false;
+            if (!identity)
+                for (size_t i = c.begin; i < c.begin + c.count; i++)
+                    g.e_cam[i] = remap[g.e_cam[i]];
+            if (c.begin != out && c.count > 0)
+            { // edges were skipped in an earlier chunk: close the gap
+                std::memmove(&g.e_pose[out], &g.e_pose[c.begin], c.count * sizeof(int32_t));
+                std::memmove(&g.e_lm[out], &g.e_lm[c.begin], c.count * sizeof(int32_t));
+                std::memmove(&g.e_flags[out], &g.e_flags[c.begin], c.count);
+                std::memmove(&g.e_meas[3 * out], &g.e_meas[3 * c.begin], 3 * c.count * sizeof(double));
+                std::memmove(&g.e_omega[out], &g.e_omega[c.begin], c.count * sizeof(double));
+                std::memmove(&g.e_cam[out], &g.e_cam[c.begin], c.count * sizeof(uint16_t));
+                std::memmove(&g.e_outlier_threshold[out], &g.e_outlier_threshold[c.begin], c.count * sizeof(double));
+                std::memmove(&flatEdges_[out], &flatEdges_[c.begin], c.count * sizeof(BaseEdge*));
+                std::memmove(&flatEdgeSets_[out], &flatEdgeSets_[c.begin], c.count * sizeof(BaseEdgeSet*));
+            }
+            out += c.count;
+            nactive += c.count;
         }
+        // the next set starts right behind the compacted edges of this one
         es->setActiveEdgeCount(nactive);
         es->setDirtyState(false);
     }
+    g.e_pose.resize(out), g.e_lm.resize(out), g.e_flags.resize(out), g.e_meas.resize(3 * out);
+    g.e_omega.resize(out), g.e_cam.resize(out), g.e_outlier_threshold.resize(out);
+    flatEdges_.resize(out), flatEdgeSets_.resize(out);
     if (omega_uniform && !g.e_omega.empty())
         g.e_omega.resize(1);
     if (!any_threshold)
@@ -201,7 +303,6 @@ void CudaGraphOptimisationImpl::initialize()
         g.cams.assign(z, z + 5);
     }
     g.rk = rk;
-    (void)rk_set;
 
     engine_->initialize(std::move(g));
     stats_.clear();

@@ -14,8 +14,11 @@ struct CholOptions
     double zero_frac = 0.35; // relaxed supernodes: tolerated share of explicit zero blocks
     int target_tasks = 1024; // subtree-to-workgroup granularity of stage 0
     bool alias_chains = true; // single-child fronts with identical rows live in the child's update block
-    int min_subtree_tasks = 64; // fewer bottom subtrees than this: no subtree stage (a handful of
-                                // workgroups walking whole subtrees serially is slower than the batched kernels)
+    // bottom subtrees walked by one workgroup each (k_subtree_factor) only if there are at least
+    // this many of them.  Measured on MI355X the batched per-level kernels win at every size tried
+    // (1.3k poses: 13 subtrees; 10k poses: ~900 fronts, 56.4 vs 57.7 ms), so it is off by default;
+    // CUGO_MIN_SUBTREE_TASKS=0 turns it on (kept under test).
+    int min_subtree_tasks = 1 << 30;
     int max_front_cols = 16; // hard cap on pivot block columns of a front (LDS-resident L11)
     static CholOptions from_env();
 };

@@ -35,6 +35,11 @@ constexpr double PIVOT_TOL = 1e-14;
 constexpr int TR = 64; // trsm / syrk tile edge
 constexpr int NC_MAX = 96; // widest pivot block (scalars): L11 lives in LDS
 constexpr int LLD = NC_MAX + 1; // leading dimension of the LDS copy of L11
+// Panel width of the in-LDS Cholesky (must divide 6).  The redundant in-register factorisation of
+// the PW x PW diagonal block grows with PW^3 while the per-panel barrier / look-ahead / LDS
+// round-trip overhead is paid 6/PW times per pose block: measured, 6 beats 3 (32 vs 38 us per
+// 96-column front); 12 would not fit the 128-VGPR budget of a 1024-thread workgroup.
+constexpr int PW = 6;
 
 using cugo_k::CholPlanDev;
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -262,7 +267,7 @@ __device__ __forceinline__ bool panel_factor_wave(double* __restrict__ Ls, int n
                                                   double* __restrict__ dinv)
 {
     const int lane = threadIdx.x & 63;
-    const int r0 = j0 + 6 + lane, r1 = j0 + 70 + lane;
+    const int r0 = j0 + PW + lane, r1 = j0 + PW + 64 + lane;
     // rows past the end are clamped to the last padded row for the loads (valid LDS, results
     // unused) and masked as a group for the stores: no branch per access
     const bool ok0 = r0 < nc, ok1 = r1 < nc;
@@ -271,26 +276,26 @@ __device__ __forceinline__ bool panel_factor_wave(double* __restrict__ Ls, int n
     const double* A1 = Ls + j0 * LLD + min(r1, NC_MAX - 1);
     if (j0 == 0)
         stamp(2, 0);
-    double D[6][6], a0[6], a1[6];
+    double D[PW][PW], a0[PW], a1[PW];
 #pragma unroll
-    for (int c = 0; c < 6; c++)
+    for (int c = 0; c < PW; c++)
     {
 #pragma unroll
-        for (int r = 0; r < 6; r++)
+        for (int r = 0; r < PW; r++)
             D[r][c] = (r >= c) ? P[c * LLD + r] : 0.0;
         a0[c] = A0[c * LLD];
         a1[c] = A1[c * LLD];
     }
     bool bad = false;
-    double iv[6];
+    double iv[PW];
     if (j0 == 0)
     {
         // make the loads complete before the stamp: consume one value
-        asm volatile("" ::"v"(D[5][5]), "v"(a1[5]));
+        asm volatile("" ::"v"(D[PW - 1][PW - 1]), "v"(a1[PW - 1]));
         stamp(2, 1);
     }
 #pragma unroll
-    for (int j = 0; j < 6; j++)
+    for (int j = 0; j < PW; j++)
     {
         const double d = D[j][j];
         // a pivot <= tol (or NaN) only raises the flag: whatever flows on (NaN from rsq of a
@@ -312,17 +317,17 @@ __device__ __forceinline__ bool panel_factor_wave(double* __restrict__ Ls, int n
         iv[j] = inv;
         D[j][j] = sq;
 #pragma unroll
-        for (int i = 0; i < 6; i++)
+        for (int i = 0; i < PW; i++)
             if (i > j)
                 D[i][j] *= inv;
         a0[j] *= inv;
         a1[j] *= inv;
 #pragma unroll
-        for (int c = 0; c < 6; c++)
+        for (int c = 0; c < PW; c++)
             if (c > j)
             {
 #pragma unroll
-                for (int i = 0; i < 6; i++)
+                for (int i = 0; i < PW; i++)
                     if (i >= c)
                         D[i][c] -= D[i][j] * D[c][j];
                 a0[c] -= a0[j] * D[c][j];
@@ -331,31 +336,31 @@ __device__ __forceinline__ bool panel_factor_wave(double* __restrict__ Ls, int n
     }
     if (j0 == 0)
     {
-        asm volatile("" ::"v"(D[5][5]), "v"(a1[5]), "v"(a0[5]));
+        asm volatile("" ::"v"(D[PW - 1][PW - 1]), "v"(a1[PW - 1]), "v"(a0[PW - 1]));
         stamp(2, 2);
     }
     if (ok0)
     {
         double* W0 = Ls + j0 * LLD + r0;
 #pragma unroll
-        for (int c = 0; c < 6; c++)
+        for (int c = 0; c < PW; c++)
             W0[c * LLD] = a0[c];
     }
     if (ok1)
     {
         double* W1 = Ls + j0 * LLD + r1;
 #pragma unroll
-        for (int c = 0; c < 6; c++)
+        for (int c = 0; c < PW; c++)
             W1[c * LLD] = a1[c];
     }
     if (lane == 0)
     {
 #pragma unroll
-        for (int c = 0; c < 6; c++)
+        for (int c = 0; c < PW; c++)
         {
             dinv[j0 + c] = iv[c];
 #pragma unroll
-            for (int r = 0; r < 6; r++)
+            for (int r = 0; r < PW; r++)
                 if (r >= c)
                     P[c * LLD + r] = D[r][c];
         }
@@ -379,8 +384,11 @@ __device__ __forceinline__ void panel_update_mfma(double* __restrict__ Ls, int n
     const int lane = threadIdx.x & 63, ln = lane & 15, lk = lane >> 4;
     const int nt = (nc - c0 + 15) >> 4;
     const int ntiles = nt * (nt + 1) / 2;
-    const double* P0 = Ls + (j0 + lk) * LLD;               // k = lk
-    const double* P1 = Ls + (j0 + 4 + (lk & 1)) * LLD;     // k = 4 + lk (lk < 2)
+    // K = PW columns of the panel: lane group lk supplies k = lk (and k = 4 + lk in a second MFMA
+    // when PW > 4); lanes whose k is beyond the panel contribute zeros
+    const double* P0 = Ls + (j0 + min(lk, PW - 1)) * LLD;
+    const double* P1 = Ls + (j0 + min(4 + lk, PW - 1)) * LLD;
+    const bool k0ok = lk < PW, k1ok = 4 + lk < PW;
     for (int t = widx; t < ntiles; t += nw)
     {
         int tj = 0, rem = t; // unrank: tile column tj has nt - tj tiles
@@ -391,15 +399,16 @@ __device__ __forceinline__ void panel_update_mfma(double* __restrict__ Ls, int n
         }
         const int R = c0 + 16 * (tj + rem), C = c0 + 16 * tj;
         const int ra = min(R + ln, NC_MAX - 1), cb = min(C + ln, NC_MAX - 1);
-        const double a0 = -P0[ra], b0 = P0[cb];
-        const double a1 = lk < 2 ? -P1[ra] : 0.0, b1 = lk < 2 ? P1[cb] : 0.0;
+        const double a0 = k0ok ? -P0[ra] : 0.0, b0 = P0[cb];
+        const double a1 = k1ok ? -P1[ra] : 0.0, b1 = P1[cb];
         double4_t acc;
         double* Cc = Ls + cb * LLD;
 #pragma unroll
         for (int q = 0; q < 4; q++)
             acc[q] = Cc[min(R + lk + 4 * q, NC_MAX - 1)];
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
+        if (PW > 4)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
         if (C + ln < NC_MAX)
         {
 #pragma unroll
@@ -410,29 +419,33 @@ __device__ __forceinline__ void panel_update_mfma(double* __restrict__ Ls, int n
     }
 }
 
-// the 6 columns right after panel j0 (the next panel), one matrix element per thread:
-// column = tid >> 7, row = j0 + 6 + (tid & 127)   (needs blockDim >= 768, nc <= 128)
+// the PW columns right after panel j0 (the next panel), one matrix element per thread:
+// column = tid >> 7, row = j0 + PW + (tid & 127)   (needs blockDim >= 128 * PW, nc <= 128)
 __device__ __forceinline__ void panel_update_next(double* __restrict__ Ls, int nc, int j0)
 {
     const int cc = threadIdx.x >> 7, rr = threadIdx.x & 127;
-    const int c = j0 + 6 + cc, r = j0 + 6 + rr;
-    if (cc < 6 && c < nc && r < nc && r >= c)
-    {
-        const double s0 = Ls[(j0 + 0) * LLD + r] * Ls[(j0 + 0) * LLD + c] +
-                          Ls[(j0 + 1) * LLD + r] * Ls[(j0 + 1) * LLD + c] +
-                          Ls[(j0 + 2) * LLD + r] * Ls[(j0 + 2) * LLD + c];
-        const double s1 = Ls[(j0 + 3) * LLD + r] * Ls[(j0 + 3) * LLD + c] +
-                          Ls[(j0 + 4) * LLD + r] * Ls[(j0 + 4) * LLD + c] +
-                          Ls[(j0 + 5) * LLD + r] * Ls[(j0 + 5) * LLD + c];
+    const int c = j0 + PW + cc, r = j0 + PW + rr;
+    if (cc < PW && c < nc && r < nc && r >= c)
+    { // two partial sums: a dependent fp64 FMA costs ~40 cycles
+        double s0 = 0, s1 = 0;
+#pragma unroll
+        for (int k = 0; k < PW; k++)
+        {
+            const double p = Ls[(j0 + k) * LLD + r] * Ls[(j0 + k) * LLD + c];
+            if (k & 1)
+                s1 += p;
+            else
+                s0 += p;
+        }
         Ls[c * LLD + r] -= s0 + s1;
     }
 }
 
-// L11 = chol(F11) in LDS (Ls: nc x nc, leading dimension nc+1), 6-column panels with
-// LOOK-AHEAD: once panel p is factored, all threads first update only the 6 columns of panel
+// L11 = chol(F11) in LDS (Ls: nc x nc, leading dimension LLD), PW-column panels with
+// LOOK-AHEAD: once panel p is factored, all threads first update only the PW columns of panel
 // p+1; then wave 0 factors panel p+1 in registers while the other waves apply panel p to the
-// remaining columns.  Two barriers per panel, and the sequential part (panel factorisation)
-// overlaps the parallel part (trailing update).
+// remaining columns on the matrix cores.  Two barriers per panel, and the sequential part (panel
+// factorisation) overlaps the parallel part (trailing update).
 // On return Ls holds L11 (lower) and dinv the reciprocal diagonal.  L11 is NOT written back to
 // F: every later consumer (trsm, backward substitution) works with W = L11^-1 (dev_winv).
 __device__ __forceinline__ void dev_potrf(const double* __restrict__ F, long ld, int nc, double* __restrict__ Ls,
@@ -448,9 +461,9 @@ __device__ __forceinline__ void dev_potrf(const double* __restrict__ F, long ld,
             *fail = 1;
     __syncthreads();
     stamp(0, 3);
-    for (int j0 = 0; j0 < nc; j0 += 6)
+    for (int j0 = 0; j0 < nc; j0 += PW)
     {
-        const int jn = j0 + 6;
+        const int jn = j0 + PW;
         if (jn >= nc)
             break;
         panel_update_next(Ls, nc, j0); // next panel's columns, one element per thread
@@ -461,7 +474,7 @@ __device__ __forceinline__ void dev_potrf(const double* __restrict__ F, long ld,
                 *fail = 1;
         }
         else
-            panel_update_mfma(Ls, nc, j0, jn + 6, (int)(threadIdx.x >> 6) - 1, (int)(blockDim.x >> 6) - 1); // the rest, meanwhile
+            panel_update_mfma(Ls, nc, j0, jn + PW, (int)(threadIdx.x >> 6) - 1, (int)(blockDim.x >> 6) - 1); // the rest, meanwhile
         __syncthreads();
     }
     stamp(0, 4);

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <numeric>
 #include <thread>
 
@@ -500,67 +501,82 @@ void Engine::build_structure()
             for (int k = m.cov_ptr[l]; k < m.cov_ptr[l + 1]; k++)
                 pc_lm[pos[m.cov_pose[k]]++] = l;
     }
+    // The three passes below are independent per pose row: contiguous row ranges, balanced by
+    // their number of co-visibility entries, go to a few host threads (SLAM calls BA with a new
+    // topology every time, so this "cold" work is paid on every call there).
+    const unsigned nth = m.cov_pose.size() < 200000 ? 1u : std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    std::vector<int> row_split(nth + 1, P);
+    row_split[0] = 0;
+    for (unsigned t = 1; t < nth; t++)
+    {
+        const int32_t target = (int32_t)((int64_t)pc_ptr[P] * t / nth);
+        row_split[t] = (int)(std::lower_bound(pc_ptr.begin(), pc_ptr.end(), target) - pc_ptr.begin());
+        row_split[t] = std::min(std::max(row_split[t], row_split[t - 1]), P);
+    }
+    auto parallel_rows = [&](const std::function<void(unsigned, int, int)>& fn) {
+        if (nth == 1)
+            return fn(0, 0, P);
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < nth; t++)
+            pool.emplace_back(fn, t, row_split[t], row_split[t + 1]);
+        for (auto& th : pool)
+            th.join();
+    };
     // rows: diagonal first, then ascending columns (ref: sparse_block_matrix.cpp:80-155; O(M)
     // with a marker array instead of the reference's dense P x P byte map)
     m.hsc_rowptr.assign(P + 1, 0);
-    m.hsc_colind.clear();
-    std::vector<int32_t> mark(P, -1);
-    double products = 0;
-    for (int p = 0; p < P; p++)
-    {
-        const size_t start = m.hsc_colind.size();
-        m.hsc_colind.push_back(p);
-        mark[p] = p;
-        for (int i = pc_ptr[p]; i < pc_ptr[p + 1]; i++)
+    std::vector<std::vector<int32_t>> cols_t(nth);
+    std::vector<double> products_t(nth, 0.0);
+    parallel_rows([&](unsigned t, int p0, int p1) {
+        std::vector<int32_t> mark(P, -1);
+        std::vector<int32_t>& cols = cols_t[t];
+        double products = 0;
+        for (int p = p0; p < p1; p++)
         {
-            const int l = pc_lm[i];
-            for (int k = m.cov_ptr[l]; k < m.cov_ptr[l + 1]; k++)
+            const size_t start = cols.size();
+            cols.push_back(p);
+            mark[p] = p;
+            for (int i = pc_ptr[p]; i < pc_ptr[p + 1]; i++)
             {
-                const int q = m.cov_pose[k];
-                if (q >= p)
-                    products += 1;
-                if (q > p && mark[q] != p)
+                const int l = pc_lm[i];
+                for (int k = m.cov_ptr[l]; k < m.cov_ptr[l + 1]; k++)
                 {
-                    mark[q] = p;
-                    m.hsc_colind.push_back(q);
+                    const int q = m.cov_pose[k];
+                    if (q >= p)
+                        products += 1;
+                    if (q > p && mark[q] != p)
+                    {
+                        mark[q] = p;
+                        cols.push_back(q);
+                    }
                 }
             }
+            std::sort(cols.begin() + start + 1, cols.end());
+            m.hsc_rowptr[p + 1] = (int32_t)(cols.size() - start); // row length; prefix sum below
         }
-        std::sort(m.hsc_colind.begin() + start + 1, m.hsc_colind.end());
-        m.hsc_rowptr[p + 1] = (int32_t)m.hsc_colind.size();
+        products_t[t] = products;
+    });
+    double products = 0;
+    m.hsc_colind.clear();
+    for (unsigned t = 0; t < nth; t++)
+    {
+        products += products_t[t];
+        m.hsc_colind.insert(m.hsc_colind.end(), cols_t[t].begin(), cols_t[t].end());
     }
+    for (int p = 0; p < P; p++)
+        m.hsc_rowptr[p + 1] += m.hsc_rowptr[p];
     const int B = (int)m.hsc_colind.size();
     // contribution lists of the off-diagonal blocks from the LOCAL edges, built row by row
     // (pose-major): pos[q] gives the slot of column q in the current row, so every product is
     // placed with O(1) work; inside a block the contributions are in ascending landmark order.
+    // A row only touches the counters / slots of its own blocks: rows are independent.
     auto free_free = [&](int e) {
         return (m.h_flags[e] & (CUGO_EDGE_FIXED_L | CUGO_EDGE_FIXED_P | CUGO_EDGE_INACTIVE)) == 0;
     };
     std::vector<int32_t> off_cnt(B + 1, 0);
-    std::vector<int32_t> pos(P, -1);
-    for (int p = 0; p < P; p++)
-    {
-        const int r0 = m.hsc_rowptr[p], r1 = m.hsc_rowptr[p + 1];
-        for (int k = r0; k < r1; k++)
-            pos[m.hsc_colind[k]] = k;
-        for (int i = m.h_pose_ptr[p]; i < m.h_pose_ptr[p + 1]; i++)
-        {
-            const int a = m.h_pose_edge[i];
-            if (!free_free(a))
-                continue;
-            const int e1 = m.h_lm_ptr[m.h_e_lm[a] + 1];
-            for (int b = a + 1; b < e1; b++)
-                if (free_free(b))
-                    off_cnt[pos[m.h_e_pose[b]] + 1]++;
-        }
-    }
-    for (int k = 0; k < B; k++)
-        off_cnt[k + 1] += off_cnt[k];
-    const size_t Moff = (size_t)off_cnt[B];
-    std::vector<int32_t> off_ei(Moff), off_ej(Moff);
-    {
-        std::vector<int32_t> fill(off_cnt.begin(), off_cnt.end() - 1);
-        for (int p = 0; p < P; p++)
+    parallel_rows([&](unsigned, int p0, int p1) {
+        std::vector<int32_t> pos(P, -1);
+        for (int p = p0; p < p1; p++)
         {
             const int r0 = m.hsc_rowptr[p], r1 = m.hsc_rowptr[p + 1];
             for (int k = r0; k < r1; k++)
@@ -573,13 +589,39 @@ void Engine::build_structure()
                 const int e1 = m.h_lm_ptr[m.h_e_lm[a] + 1];
                 for (int b = a + 1; b < e1; b++)
                     if (free_free(b))
-                    {
-                        const int q = fill[pos[m.h_e_pose[b]]]++;
-                        off_ei[q] = a;
-                        off_ej[q] = b;
-                    }
+                        off_cnt[pos[m.h_e_pose[b]] + 1]++;
             }
         }
+    });
+    for (int k = 0; k < B; k++)
+        off_cnt[k + 1] += off_cnt[k];
+    const size_t Moff = (size_t)off_cnt[B];
+    std::vector<int32_t> off_ei(Moff), off_ej(Moff);
+    {
+        std::vector<int32_t> fill(off_cnt.begin(), off_cnt.end() - 1);
+        parallel_rows([&](unsigned, int p0, int p1) {
+            std::vector<int32_t> pos(P, -1);
+            for (int p = p0; p < p1; p++)
+            {
+                const int r0 = m.hsc_rowptr[p], r1 = m.hsc_rowptr[p + 1];
+                for (int k = r0; k < r1; k++)
+                    pos[m.hsc_colind[k]] = k;
+                for (int i = m.h_pose_ptr[p]; i < m.h_pose_ptr[p + 1]; i++)
+                {
+                    const int a = m.h_pose_edge[i];
+                    if (!free_free(a))
+                        continue;
+                    const int e1 = m.h_lm_ptr[m.h_e_lm[a] + 1];
+                    for (int b = a + 1; b < e1; b++)
+                        if (free_free(b))
+                        {
+                            const int q = fill[pos[m.h_e_pose[b]]]++;
+                            off_ei[q] = a;
+                            off_ej[q] = b;
+                        }
+                }
+            }
+        });
     }
     m.d_hsc_rowptr.upload(m.hsc_rowptr, s), m.d_hsc_colind.upload(m.hsc_colind, s);
     m.d_off_ptr.upload(off_cnt, s), m.d_off_ei.upload(off_ei, s), m.d_off_ej.upload(off_ej, s);

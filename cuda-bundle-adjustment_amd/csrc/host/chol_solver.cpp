@@ -14,7 +14,7 @@ void cugo_chol::upload(hipStream_t s)
     const CholPlan& P = plan;
     d_ncb.upload(P.ncb, s), d_nb.upload(P.nb, s), d_off.upload(P.off, s), d_col0.upload(P.col0, s);
     d_woff.upload(P.woff, s), d_l21off.upload(P.l21off, s), d_ldf.upload(P.ldf, s);
-    d_alias_of.upload(P.alias_of, s);
+    d_alias_of.upload(P.alias_of, s), d_bw_np.upload(P.bw_np, s);
     d_rows_ptr.upload(P.rows_ptr, s), d_rows.upload(P.rows, s);
     d_child_ptr.upload(P.child_ptr, s), d_child.upload(P.child, s);
     d_rel_ptr.upload(P.rel_ptr, s), d_rel.upload(P.rel, s);
@@ -45,7 +45,7 @@ void cugo_chol::upload(hipStream_t s)
     D.junk = d_junk.data();
     D.woff = d_woff.data(), D.winv = d_winv.data(), D.nc_max = P.nc_max;
     D.l21off = d_l21off.data(), D.l21 = d_l21.data();
-    D.ldf = d_ldf.data(), D.alias_of = d_alias_of.data();
+    D.ldf = d_ldf.data(), D.alias_of = d_alias_of.data(), D.bw_np = d_bw_np.data();
     lds_factor = cugo_k::chol_lds_factor_bytes(P.nc_max);
     lds_backward = cugo_k::chol_lds_backward_bytes(P.nc_max, P.ld_max);
 }
@@ -93,26 +93,12 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
     }
     for (int st = plan.n_stages - 1; st >= 0; st--)
     {
-        const int t1 = plan.stage_task_ptr[st + 1];
-        // a run of single-front upper levels (the pieces of a wide separator at the top of the
-        // tree) is walked by one workgroup in one launch
-        int lo = st;
-        auto single_upper = [&](int q) {
-            return q >= 0 && plan.stage_task_ptr[q + 1] - plan.stage_task_ptr[q] == 1 &&
-                   !(plan.has_subtree_stage && q == 0);
-        };
-        if (single_upper(st))
-            while (single_upper(lo - 1))
-                lo--;
-        const int t0 = plan.stage_task_ptr[lo];
-        if (lo < st)
-            cugo_k::launch_chol_backward_stage(s, dev, d_fronts.data(), t0, 1, lds_backward, d_xnew.data(),
-                                               d_x, st - lo + 1);
-        else
-            cugo_k::launch_chol_backward_stage(s, dev, d_fronts.data(), t0, t1 - t0, lds_backward,
-                                               d_xnew.data(), d_x, 1);
+        const int t0 = plan.stage_task_ptr[st], t1 = plan.stage_task_ptr[st + 1];
+        // the level's fronts, plus the ahead-of-time mat-vecs of their children as extra workgroups
+        cugo_k::launch_chol_backward_stage(s, dev, d_fronts.data(), t0, t1 - t0, lds_backward, d_xnew.data(),
+                                           d_x, d_wl.data() + 3L * plan.bwg_ptr[st],
+                                           plan.bwg_ptr[st + 1] - plan.bwg_ptr[st]);
         const int st_top = st;
-        st = lo;
         if (dbg && st_top == plan.n_stages - 1)
         { // keep the top stage's backward stamps (kernel 3) in slots 48.. before stage 0 overwrites them
             CUGO_HIP(hipStreamSynchronize(s));

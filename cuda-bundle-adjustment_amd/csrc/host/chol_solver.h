@@ -17,7 +17,7 @@ struct cugo_chol
         d_rel_ptr, d_rel, d_task_ptr, d_task_fronts, d_blk_front, d_blk_row, d_blk_col, d_perm,
         d_col_front, d_wl;
     cugo_host::DevBuf<int64_t> d_off, d_woff, d_l21off, d_ldf;
-    cugo_host::DevBuf<int32_t> d_alias_of;
+    cugo_host::DevBuf<int32_t> d_alias_of, d_bw_np;
     cugo_host::DevBuf<uint8_t> d_blk_trans;
     cugo_host::DevBuf<double> d_fronts, d_xnew, d_junk, d_winv, d_l21;
 

@@ -737,10 +737,11 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
     P.nc_max = 6;
     for (int s = 0; s < ns; s++)
         P.nc_max = std::max(P.nc_max, 6 * P.ncb[s]);
-    P.ea_ptr.assign(1, 0), P.eab_ptr.assign(1, 0), P.syrk_ptr.assign(1, 0);
+    P.ea_ptr.assign(1, 0), P.eab_ptr.assign(1, 0), P.syrk_ptr.assign(1, 0), P.bwg_ptr.assign(1, 0);
+    P.bw_np.assign(ns, -1);
     P.l21off.assign(ns, -1);
     P.l21_doubles = 0;
-    std::vector<int32_t> ea, eab, sy;
+    std::vector<int32_t> ea, eab, sy, bwg;
     for (int st = 0; st < P.n_stages; st++)
     {
         const bool subtree = P.has_subtree_stage && st == 0;
@@ -792,20 +793,44 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
                 }
                 P.l21off[f] = P.l21_doubles;
                 P.l21_doubles += (int64_t)6 * ncb * nbelow;
+                // backward mat-vec items of this front's CHILDREN (upper-stage ones): rows beyond
+                // the part owned by this front, 16 pivot columns per workgroup
+                for (int k = P.child_ptr[f]; k < P.child_ptr[f + 1]; k++)
+                {
+                    const int c = P.child[k];
+                    if (lower[c])
+                        continue;
+                    const int nbr = P.nb[c] - P.ncb[c];
+                    int npb = 0;
+                    while (npb < nbr && P.rel[P.rel_ptr[c] + npb] < ncb)
+                        npb++;
+                    if (nbr - npb >= 8) // worth a workgroup only if a fair share is left
+                    {
+                        P.bw_np[c] = npb;
+                        for (int j0 = 0; j0 < 6 * P.ncb[c]; j0 += 16)
+                        {
+                            bwg.push_back(c), bwg.push_back(j0), bwg.push_back(0);
+                        }
+                    }
+                }
             }
         P.ea_ptr.push_back((int)ea.size() / 3);
         P.eab_ptr.push_back((int)eab.size() / 3);
         P.syrk_ptr.push_back((int)sy.size() / 3);
+        P.bwg_ptr.push_back((int)bwg.size() / 3);
     }
-    // one array: [ea | eab | trsyrk]; the ptr arrays index items within their own section
+    // one array: [ea | eab | trsyrk | backward mat-vec]; the ptr arrays index items within their own section
     P.wl.clear();
     P.wl.insert(P.wl.end(), ea.begin(), ea.end());
     P.wl.insert(P.wl.end(), eab.begin(), eab.end());
     P.wl.insert(P.wl.end(), sy.begin(), sy.end());
+    P.wl.insert(P.wl.end(), bwg.begin(), bwg.end());
     for (auto& v : P.eab_ptr)
         v += (int)ea.size() / 3;
     for (auto& v : P.syrk_ptr)
         v += (int)(ea.size() + eab.size()) / 3;
+    for (auto& v : P.bwg_ptr)
+        v += (int)(ea.size() + eab.size() + sy.size()) / 3;
 }
 
 } // namespace cugo_host

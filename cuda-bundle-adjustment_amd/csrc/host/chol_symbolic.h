@@ -61,7 +61,12 @@ struct CholPlan
     //   trsm        : scalar rows [a, b) below the pivot block (relative to row 6*ncb)
     //   syrk        : 64x64 tile (row tile a, col tile b), a >= b
     std::vector<int32_t> wl;
-    std::vector<int32_t> ea_ptr, eab_ptr, syrk_ptr; // [n_stages+1] item ranges per stage
+    std::vector<int32_t> ea_ptr, eab_ptr, syrk_ptr, bwg_ptr; // [n_stages+1] item ranges per stage
+    // backward pass: boundary block rows of a front that lie in its PARENT's pivot columns (they come
+    // first).  The mat-vec over the remaining rows — ancestors above the parent, solved earlier —
+    // is done one launch ahead by extra workgroups riding with the parent's level (items bwg:
+    // front, first column, -); -1: the front does its whole mat-vec itself
+    std::vector<int32_t> bw_np;
     // ea = extend-add of the pivot block columns (before potrf), eab = of the boundary columns
     // (same launch as trsm)
     int nc_max = 6; // widest pivot block in scalars (LDS sizing)

@@ -987,7 +987,12 @@ __device__ __forceinline__ void dev_backward(const CholPlanDev& p, const double*
     const int32_t* rows = p.rows + p.rows_ptr[f];
     stamp(3, 1);
     stamp_value(3, 6, 1000L * ncs + nrs);
-    for (int i = threadIdx.x; i < nrs; i += blockDim.x)
+    // rows of the mat-vec still to do here: all of them, or — when the ancestor part was done one
+    // launch ahead (k_backward_stage, extra workgroups; the partial result waits in xnew at this
+    // front's own positions) — only the leading rows that belong to the parent
+    const int npb = p.bw_np[f];
+    const int nr_here = npb >= 0 ? 6 * npb : nrs;
+    for (int i = threadIdx.x; i < nr_here; i += blockDim.x)
     {
         const int ib = i / 6;
         xr[i] = xnew[6L * rows[ib] + (i - 6 * ib)];
@@ -997,13 +1002,13 @@ __device__ __forceinline__ void dev_backward(const CholPlanDev& p, const double*
     __syncthreads();
     stamp(3, 2);
     const int g = threadIdx.x >> 4, l16 = threadIdx.x & 15, ng = blockDim.x >> 4;
-    // v_j = y_j - sum_i L21[i,j] x_R[i]
+    // v_j = y_j - sum_i L21[i,j] x_R[i]: 16 lanes per column, lanes stride the rows
     for (int j = g; j < ncs; j += ng)
     {
         const double* col = L + (long)j * ldl;
-        const double y = col[nrs];
+        const double y = npb >= 0 ? xnew[6L * c0 + j] : col[nrs];
         double s = 0;
-        for (int i = l16; i < nrs; i += 128)
+        for (int i = l16; i < nr_here; i += 128)
         { // eight independent loads in flight per lane
             double a[8];
 #pragma unroll
@@ -1011,7 +1016,7 @@ __device__ __forceinline__ void dev_backward(const CholPlanDev& p, const double*
                 a[u] = col[min(i + 16 * u, nrs - 1)];
 #pragma unroll
             for (int u = 0; u < 8; u++)
-                s += (i + 16 * u < nrs) ? a[u] * xr[i + 16 * u] : 0.0;
+                s += (i + 16 * u < nr_here) ? a[u] * xr[i + 16 * u] : 0.0;
         }
 #pragma unroll
         for (int off = 8; off > 0; off >>= 1)
@@ -1154,17 +1159,67 @@ __global__ __launch_bounds__(BIG) void k_up_trsyrk(CholPlanDev p, double* __rest
     stamp_value(4, 6, 1000000L * (it[1] * 10 + it[2] + 1) + 1000L * ncs + nrs);
 }
 
+// the ancestor part of a front's backward mat-vec, one launch ahead of the front itself:
+// v_j = y_j - sum_{i >= 6*npb} L21[i,j] x_R[i] for the 16 columns j0.. (one wave per column, its
+// 64 lanes stride the rows), parked in xnew at the front's own positions
+__device__ __forceinline__ void dev_backward_ahead(const CholPlanDev& p, int f, int j0, double* __restrict__ lds,
+                                                   double* __restrict__ xnew)
+{
+    const int ncb = p.ncb[f], nb = p.nb[f];
+    const int ncs = 6 * ncb, nrs = 6 * (nb - ncb);
+    const int r0 = 6 * p.bw_np[f]; // first row of the ancestor part
+    const double* L = p.l21 + p.l21off[f];
+    const long ldl = nrs + 1;
+    const int c0 = p.col0[f];
+    const int32_t* rows = p.rows + p.rows_ptr[f];
+    double* xr = lds;
+    for (int i = r0 + threadIdx.x; i < nrs; i += blockDim.x)
+    {
+        const int ib = i / 6;
+        xr[i] = xnew[6L * rows[ib] + (i - 6 * ib)];
+    }
+    __syncthreads();
+    const int j = j0 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (j < ncs)
+    {
+        const double* col = L + (long)j * ldl;
+        const double y = col[nrs];
+        double s = 0;
+        for (int i = r0 + lane; i < nrs; i += 512)
+        { // eight independent loads in flight per lane
+            double a[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                a[u] = col[min(i + 64 * u, nrs - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                s += (i + 64 * u < nrs) ? a[u] * xr[i + 64 * u] : 0.0;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+            s += __shfl_xor(s, off, 64);
+        if (lane == 0)
+            xnew[6L * c0 + j] = y - s;
+    }
+}
+
 __global__ __launch_bounds__(BIG) void k_backward_stage(CholPlanDev p,
                                                         const double* __restrict__ fronts,
-                                                        int task0, double* __restrict__ xnew,
-                                                        double* __restrict__ xout, int span)
+                                                        int task0, int ntasks,
+                                                        const int32_t* __restrict__ wl_gemv,
+                                                        double* __restrict__ xnew,
+                                                        double* __restrict__ xout)
 {
     extern __shared__ double lds[];
+    if ((int)blockIdx.x >= ntasks)
+    { // ahead-of-time mat-vec of a child of this level's fronts
+        const int32_t* it = wl_gemv + 3 * (blockIdx.x - ntasks);
+        dev_backward_ahead(p, it[0], it[1], lds, xnew);
+        return;
+    }
     stamp(3, 0);
-    // span > 1 (one workgroup): a run of consecutive single-front levels walked top-down in one
-    // launch — each front only needs its ancestors, which this workgroup has just solved
     const int task = task0 + blockIdx.x;
-    for (int fi = p.task_ptr[task + span] - 1; fi >= p.task_ptr[task]; fi--)
+    for (int fi = p.task_ptr[task + 1] - 1; fi >= p.task_ptr[task]; fi--)
         dev_backward(p, fronts, p.task_fronts[fi], lds, xnew, xout);
     stamp(3, 7);
 }
@@ -1253,13 +1308,14 @@ void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fron
 }
 
 void launch_chol_backward_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,
-                                int ntasks, size_t lds_bytes, double* d_xnew, double* d_x, int span)
+                                int ntasks, size_t lds_bytes, double* d_xnew, double* d_x,
+                                const int32_t* d_wl_gemv, int ngemv)
 {
     if (ntasks <= 0)
         return;
     ensure_lds(reinterpret_cast<const void*>(k_backward_stage), lds_bytes);
-    CUGO_LAUNCH(k_backward_stage, dim3(ntasks), dim3(BIG), lds_bytes, s, p, d_fronts, task0,
-                       d_xnew, d_x, span);
+    CUGO_LAUNCH(k_backward_stage, dim3(ntasks + ngemv), dim3(BIG), lds_bytes, s, p, d_fronts, task0,
+                       ntasks, d_wl_gemv, d_xnew, d_x);
 }
 
 } // namespace cugo_k

@@ -92,6 +92,8 @@ struct CholPlanDev
     const int64_t* ldf;        // leading dimension: 6*nb + 1, or the child's when the front lives in
                                // the update block of its only child (single-child chains)
     const int32_t* alias_of;   // that child, or -1
+    const int32_t* bw_np;      // backward: leading boundary block rows owned by the parent when the
+                               // rest of the front's mat-vec is done ahead of time, else -1
     const int64_t* woff;       // offset (doubles) of W = L11^-1 (pad16(6*ncb)^2, column-major) in winv
     double* winv;
     const int64_t* l21off;     // offset of the front's L21 (+ rhs row) in l21, or -1: in the front itself
@@ -132,10 +134,12 @@ void launch_chol_subtree_stage(hipStream_t s, const CholPlanDev& p, double* d_fr
 void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,
                              int ntasks, const int32_t* d_wl, int eap0, int neap, int ea0, int nea,
                              int sy0, int nsy, size_t lds_bytes, int32_t* d_fail);
-// span > 1 (with ntasks == 1): `span` consecutive single-front levels, tasks task0..task0+span-1,
-// solved top-down by one workgroup in one launch
+// backward substitution of one level: ntasks workgroups solve the level's fronts; ngemv more
+// workgroups (items d_wl_gemv: front, first column, -) do the ancestor part of the mat-vec of
+// the CHILDREN of these fronts, which the next launch then does not have to wait for
 void launch_chol_backward_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,
-                                int ntasks, size_t lds_bytes, double* d_xnew, double* d_x, int span);
+                                int ntasks, size_t lds_bytes, double* d_xnew, double* d_x,
+                                const int32_t* d_wl_gemv, int ngemv);
 // LDS bytes of the factor kernels (L11 + one 64-row tile) and of the backward kernel
 void set_debug_stamps(long long* d_buf); // diagnostic s_memtime stamps (nullptr = off)
 size_t chol_lds_factor_bytes(int nc_max);

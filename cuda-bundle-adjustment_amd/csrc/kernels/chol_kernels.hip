@@ -128,10 +128,11 @@ __device__ __forceinline__ void wave_lds_sync()
 __device__ __forceinline__ void ea_chunk(const double* __restrict__ U, long ldc, int nru, int nbr,
                                          const int32_t* __restrict__ rel, double* __restrict__ Fp,
                                          long ldp, long rhs_row, int jb, int ch, int lane,
-                                         double* __restrict__ sink)
+                                         double* __restrict__ sink, int rbeg, int rend)
 {
-    const int i = 6 * jb + 64 * ch + lane;
-    const bool ok = i < nru;
+    // rows [rbeg, rend) of the child's update block column jb (rbeg >= 6*jb, rend <= nru)
+    const int i = rbeg + 64 * ch + lane;
+    const bool ok = i < rend;
     const int ic = ok ? i : 6 * jb;
     const int ib = ic / 6;
     const long pjb = 6L * rel[jb];
@@ -159,11 +160,16 @@ __device__ __forceinline__ void ea_chunk(const double* __restrict__ U, long ldc,
 // Extend-add of the children of front f into its block columns [cb0, cb1).  Children are applied
 // one after the other in list order (fixed summation order => bit-reproducible); within a child
 // the (block column, 64-row chunk) units are dealt round-robin to the waves.
+// `part`: 0 = all rows; 1 = only the child rows that map into the parent's PIVOT rows (the parent's
+// F11: what its potrf needs); 2 = only the rows below them (F21 / F22).  Parts 1 and 2 touch
+// disjoint parent entries, so they may run in different workgroups of one launch.
 constexpr int EA_BATCH = 32;
 __device__ __forceinline__ void dev_extend_add(const CholPlanDev& p, double* __restrict__ fronts, int f, int cb0,
-                               int cb1)
+                               int cb1, int part)
 {
-    __shared__ int s_child[EA_BATCH][3]; // child front, first / past-last matching update block column
+    __shared__ int s_child[EA_BATCH][4]; // child front, first / past-last matching update block column,
+                                         // number of child rows (blocks) inside the parent's pivot block
+    const int ncbp = p.ncb[f];
     const long ldp = p.ldf[f], rhs_row = 6L * p.nb[f];
     double* Fp = fronts + p.off[f];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
@@ -180,16 +186,17 @@ __device__ __forceinline__ void dev_extend_add(const CholPlanDev& p, double* __r
             const int c = p.child[cbase + k];
             const int nbr = p.nb[c] - p.ncb[c];
             const int32_t* rel = p.rel + p.rel_ptr[c];
-            int jlo = 0, jhi = 0;
+            int jlo = 0, jhi = 0, nsp = 0;
             for (int base = 0; base < nbr; base += 64)
             {
                 const int i = base + lane;
                 const int rv = rel[min(i, nbr - 1)];
                 jlo += __popcll(__ballot(i < nbr && rv < cb0));
                 jhi += __popcll(__ballot(i < nbr && rv < cb1));
+                nsp += __popcll(__ballot(i < nbr && rv < ncbp));
             }
             if (lane == 0)
-                s_child[k][0] = c, s_child[k][1] = jlo, s_child[k][2] = jhi;
+                s_child[k][0] = c, s_child[k][1] = jlo, s_child[k][2] = jhi, s_child[k][3] = nsp;
         }
         __syncthreads();
         for (int k = 0; k < nchild; k++)
@@ -202,12 +209,15 @@ __device__ __forceinline__ void dev_extend_add(const CholPlanDev& p, double* __r
             const double* U = fronts + p.off[c] + (6L * ncb) * ldc + 6L * ncb; // (0,0) of update
             const int32_t* rel = p.rel + p.rel_ptr[c];
             const int nru = 6 * nbr + 1;
+            const int isplit = 6 * s_child[k][3]; // child rows below this index map into parent pivot rows
             int u = wv;
             for (int jb = jlo; jb < jhi; jb++)
             {
-                const int nch = (nru - 6 * jb + 63) >> 6;
+                const int rbeg = part == 2 ? max(6 * jb, isplit) : 6 * jb;
+                const int rend = part == 1 ? min(nru, isplit) : nru;
+                const int nch = rend > rbeg ? (rend - rbeg + 63) >> 6 : 0;
                 for (; u < nch; u += nwv)
-                    ea_chunk(U, ldc, nru, nbr, rel, Fp, ldp, rhs_row, jb, u, lane, sink);
+                    ea_chunk(U, ldc, nru, nbr, rel, Fp, ldp, rhs_row, jb, u, lane, sink, rbeg, rend);
                 u -= nch;
             }
             __syncthreads(); // the next child may touch the same parent entries
@@ -1078,7 +1088,7 @@ __global__ __launch_bounds__(BIG) void k_subtree_factor(CholPlanDev p, double* _
         double* Bt = Vs + (NC_MAX >> 4) * (16 * 17);
         double* Wg = p.winv + p.woff[f];
         if (p.alias_of[f] < 0) // a front stored in its only child's update block needs no extend-add
-            dev_extend_add(p, fronts, f, 0, nb);
+            dev_extend_add(p, fronts, f, 0, nb, 0);
         dev_potrf(F, ld, ncs, Ls, dinv, fail);
         __syncthreads();
         dev_inv_diag16(Ls, dinv, ncp, Vs);
@@ -1101,32 +1111,34 @@ __global__ __launch_bounds__(BIG) void k_subtree_factor(CholPlanDev p, double* _
 }
 
 // ---------------------------------------------------------------- upper stages ---------
-__global__ __launch_bounds__(BIG) void k_up_extend_add(CholPlanDev p, double* __restrict__ fronts,
-                                                       const int32_t* __restrict__ wl)
-{
-    stamp(5, 0);
-    const int32_t* it = wl + 3 * blockIdx.x;
-    dev_extend_add(p, fronts, it[0], it[1], it[2]);
-    stamp(5, 7);
-}
-
-// potrf of the stage's fronts and, in the same launch, the extend-add of their BOUNDARY columns
-// (blocks >= npotrf): independent data (F11 vs F22), one kernel boundary less
+// potrf of the stage's fronts and, in the same launch (blocks >= npotrf), the extend-add of
+// everything except the parents' F11 blocks: independent data, no separate extend-add launch
 __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restrict__ fronts,
                                                   int task0, int npotrf,
-                                                  const int32_t* __restrict__ wl_ea,
+                                                  const int32_t* __restrict__ wl_eap, int neap,
+                                                  const int32_t* __restrict__ wl_eab,
                                                   int32_t* __restrict__ fail)
 {
     extern __shared__ double lds[];
     if ((int)blockIdx.x >= npotrf)
-    {
-        const int32_t* it = wl_ea + 3 * (blockIdx.x - npotrf);
-        dev_extend_add(p, fronts, it[0], it[1], it[2]);
+    { // items of the pivot columns first, then of the boundary columns
+        const int b = blockIdx.x - npotrf;
+        const int32_t* it = b < neap ? wl_eap + 3 * b : wl_eab + 3 * (b - neap);
+        dev_extend_add(p, fronts, it[0], it[1], it[2], 2); // everything below the parents' F11
         return;
     }
     stamp(0, 0);
     const int f = p.task_fronts[p.task_ptr[task0 + blockIdx.x]];
     const int ncs = 6 * p.ncb[f];
+    // the part of the extend-add this factorisation depends on: the children's contributions to
+    // F11 (<= 96 x 96), gathered by this workgroup itself; the rest of the pivot columns and the
+    // boundary columns are gathered meanwhile by the extra workgroups above
+    if (p.alias_of[f] < 0 && p.child_ptr[f + 1] > p.child_ptr[f])
+    {
+        dev_extend_add(p, fronts, f, 0, p.ncb[f], 1);
+        __threadfence_block();
+        __syncthreads();
+    }
     const int ncp = pad16(ncs);
     stamp(0, 1);
     double* Ls = lds;
@@ -1293,12 +1305,9 @@ void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fron
     (void)lds_bytes;
     if (ntasks <= 0)
         return;
-    if (neap > 0) // children -> pivot columns
-        CUGO_LAUNCH(k_up_extend_add, dim3(neap), dim3(BIG), 0, s, p, d_fronts,
-                           d_wl + 3L * eap0);
     ensure_lds(reinterpret_cast<const void*>(k_up_potrf), chol_lds_potrf_bytes());
-    CUGO_LAUNCH(k_up_potrf, dim3(ntasks + nea), dim3(BIG), chol_lds_potrf_bytes(), s, p, d_fronts,
-                task0, ntasks, d_wl + 3L * ea0, d_fail);
+    CUGO_LAUNCH(k_up_potrf, dim3(ntasks + neap + nea), dim3(BIG), chol_lds_potrf_bytes(), s, p, d_fronts,
+                task0, ntasks, d_wl + 3L * eap0, neap, d_wl + 3L * ea0, d_fail);
     if (nsy > 0)
     {
         ensure_lds(reinterpret_cast<const void*>(k_up_trsyrk), trsyrk_lds() * sizeof(double));

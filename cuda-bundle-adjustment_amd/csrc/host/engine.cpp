@@ -16,6 +16,7 @@
 #include "../kernels/kernels.h"
 #include "chol_solver.h"
 #include "hip_util.h"
+#include "thread_pool.h"
 
 namespace cugo_host
 {
@@ -247,9 +248,27 @@ void Engine::set_shard(int rank, int world, cugo_exchange_fn fn, void* user)
     impl_->rank = rank, impl_->world = world, impl_->xfn = fn, impl_->xuser = user;
 }
 
+static constexpr unsigned kMaxHostThreads = 16;
+
+// CUGO_INIT_TIMING=1: per-section host times of initialize() on stderr (diagnosis only)
+struct InitLaps
+{
+    bool on = std::getenv("CUGO_INIT_TIMING") != nullptr;
+    Clock::time_point t = Clock::now();
+    void lap(const char* what)
+    {
+        if (!on)
+            return;
+        const auto n = Clock::now();
+        std::fprintf(stderr, "[cugo init] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
+
 void Engine::initialize(FlatGraph&& g)
 {
     const auto t0 = Clock::now();
+    InitLaps laps;
     Impl& m = *impl_;
     hipStream_t s = m.ctx.stream;
     m.Pall = g.Pall, m.Lall = g.Lall, m.P = g.P, m.L = g.L;
@@ -258,88 +277,131 @@ void Engine::initialize(FlatGraph&& g)
     E_global_ = Etot;
 
     // ---- landmark-major order: counting sort by landmark, then by pose inside ----------
+    // Threads own contiguous landmark ranges: each scans all edges (8 B per edge, from cache)
+    // and counts / places only the edges of its own landmarks, so no two threads write the same
+    // bin and the placement keeps the container order inside a landmark (stable).
     std::vector<int32_t> lm_cnt(m.Lall + 1, 0);
-    for (int e = 0; e < Etot; e++)
-        lm_cnt[g.e_lm[e] + 1]++;
-    for (int l = 0; l < m.Lall; l++)
-        lm_cnt[l + 1] += lm_cnt[l];
     std::vector<int32_t> order(Etot);
     {
-        std::vector<int32_t> pos(lm_cnt.begin(), lm_cnt.end() - 1);
-        for (int e = 0; e < Etot; e++)
-            order[pos[g.e_lm[e]]++] = e;
-        for (int l = 0; l < m.Lall; l++)
-        {
-            int32_t* b = order.data() + lm_cnt[l];
-            const int k = lm_cnt[l + 1] - lm_cnt[l];
-            for (int i = 1; i < k; i++)
-            { // insertion sort by pose index (k is small)
-                const int32_t v = b[i];
-                const int pv = g.e_pose[v];
-                int j = i - 1;
-                while (j >= 0 && g.e_pose[b[j]] > pv)
-                {
-                    b[j + 1] = b[j];
-                    j--;
-                }
-                b[j + 1] = v;
+        const int32_t* elm = g.e_lm.data();
+        parallel_chunks((size_t)m.Lall, 65536, [&](size_t la, size_t lb, unsigned) {
+            for (int e = 0; e < Etot; e++)
+            {
+                const size_t l = (size_t)elm[e];
+                if (l >= la && l < lb)
+                    lm_cnt[l + 1]++;
             }
-        }
+        });
+        for (int l = 0; l < m.Lall; l++)
+            lm_cnt[l + 1] += lm_cnt[l];
+        parallel_chunks((size_t)m.Lall, 65536, [&](size_t la, size_t lb, unsigned) {
+            if (la == lb)
+                return;
+            std::vector<int32_t> pos(lm_cnt.begin() + la, lm_cnt.begin() + lb);
+            for (int e = 0; e < Etot; e++)
+            {
+                const size_t l = (size_t)elm[e];
+                if (l >= la && l < lb)
+                    order[pos[l - la]++] = e;
+            }
+            for (size_t l = la; l < lb; l++)
+            {
+                int32_t* b = order.data() + lm_cnt[l];
+                const int k = lm_cnt[l + 1] - lm_cnt[l];
+                for (int i = 1; i < k; i++)
+                { // insertion sort by pose index (k is small)
+                    const int32_t v = b[i];
+                    const int pv = g.e_pose[v];
+                    int j = i - 1;
+                    while (j >= 0 && g.e_pose[b[j]] > pv)
+                    {
+                        b[j + 1] = b[j];
+                        j--;
+                    }
+                    b[j + 1] = v;
+                }
+            }
+        });
     }
+    laps.lap("engine: landmark sort");
     // ---- global co-visibility (all shards): free landmark -> free poses ----------------
-    m.cov_ptr.assign(m.L + 1, 0);
-    m.cov_pose.clear();
-    m.cov_pose.reserve(Etot);
-    for (int l = 0; l < m.L; l++)
     {
-        for (int i = lm_cnt[l]; i < lm_cnt[l + 1]; i++)
-        {
-            const int e = order[i];
-            if ((g.e_flags[e] & (CUGO_EDGE_FIXED_L | CUGO_EDGE_FIXED_P | CUGO_EDGE_INACTIVE)) == 0)
-                m.cov_pose.push_back(g.e_pose[e]);
-        }
-        m.cov_ptr[l + 1] = (int32_t)m.cov_pose.size();
+        auto is_ff = [&](int e) {
+            return (g.e_flags[e] & (CUGO_EDGE_FIXED_L | CUGO_EDGE_FIXED_P | CUGO_EDGE_INACTIVE)) == 0;
+        };
+        m.cov_ptr.assign(m.L + 1, 0);
+        parallel_chunks((size_t)m.L, 65536, [&](size_t la, size_t lb, unsigned) {
+            for (size_t l = la; l < lb; l++)
+            {
+                int c = 0;
+                for (int i = lm_cnt[l]; i < lm_cnt[l + 1]; i++)
+                    c += is_ff(order[i]);
+                m.cov_ptr[l + 1] = c;
+            }
+        });
+        for (int l = 0; l < m.L; l++)
+            m.cov_ptr[l + 1] += m.cov_ptr[l];
+        m.cov_pose.resize((size_t)m.cov_ptr[m.L]);
+        parallel_chunks((size_t)m.L, 65536, [&](size_t la, size_t lb, unsigned) {
+            for (size_t l = la; l < lb; l++)
+            {
+                int o = m.cov_ptr[l];
+                for (int i = lm_cnt[l]; i < lm_cnt[l + 1]; i++)
+                    if (is_ff(order[i]))
+                        m.cov_pose[o++] = g.e_pose[order[i]];
+            }
+        });
     }
+    laps.lap("engine: co-visibility");
     // ---- shard: contiguous landmark range balanced by edge count -----------------------
     int l0 = 0, l1 = m.Lall;
     shard_range(lm_cnt, m.rank, m.world, l0, l1);
     m.shard_l0 = l0, m.shard_l1 = l1;
-    const int e_begin = lm_cnt[l0], e_end = lm_cnt[l1];
     // Slot layout of this shard's edges: landmark-major, padded with inactive slots so that no
     // landmark with <= 256 edges straddles a 256-slot boundary (k_build_edges / the back-
     // substitution sum a landmark's edges inside one workgroup).  A padding slot belongs to
     // the landmark before it; slot_src[i] = index into `order`, or -1 for padding.
     constexpr int kBlock = 256;
     std::vector<int32_t> slot_src;
-    slot_src.reserve((size_t)(e_end - e_begin) + (e_end - e_begin) / 32 + kBlock);
     m.h_lm_ptr.assign(m.Lall + 1, 0);
     {
-        int last_l = -1; // last landmark that owns slots
+        // first the start slot of every landmark (sequential: a padding decision moves everything
+        // behind it), then the slots are filled per landmark range in parallel
+        std::vector<int32_t> start((size_t)(l1 - l0) + 1, 0);
+        int pos = 0, last_l = -1; // last_l: last landmark that owns slots
         for (int l = l0; l < l1; l++)
         {
             const int k = lm_cnt[l + 1] - lm_cnt[l];
-            int pos = (int)slot_src.size();
             if (k > 0 && k <= kBlock && pos % kBlock + k > kBlock && last_l >= 0)
             {
-                const int pad = kBlock - pos % kBlock;
-                slot_src.insert(slot_src.end(), pad, -1);
-                pos += pad;
+                pos += kBlock - pos % kBlock;
                 for (int q = last_l + 1; q <= l; q++)
                     m.h_lm_ptr[q] = pos; // the padding extends landmark last_l
             }
             m.h_lm_ptr[l] = pos;
-            for (int i = lm_cnt[l]; i < lm_cnt[l + 1]; i++)
-                slot_src.push_back(i);
+            start[l - l0] = pos;
+            pos += k;
             if (k > 0)
                 last_l = l;
         }
-        const int total = (int)slot_src.size();
+        const int total = pos;
+        slot_src.assign((size_t)total, -1);
+        parallel_chunks((size_t)(l1 - l0), 65536, [&](size_t a, size_t b, unsigned) {
+            for (size_t q = a; q < b; q++)
+            {
+                const int l = l0 + (int)q;
+                int32_t* dst = slot_src.data() + start[q];
+                for (int i = lm_cnt[l]; i < lm_cnt[l + 1]; i++)
+                    *dst++ = i;
+            }
+        });
         for (int l = l1; l <= m.Lall; l++)
             m.h_lm_ptr[l] = total;
         // lm_ptr[l] for l < l0 stays 0; fix up the entries between padded landmarks
         for (int l = l0 + 1; l <= l1; l++)
             m.h_lm_ptr[l] = std::max(m.h_lm_ptr[l], m.h_lm_ptr[l - 1]);
     }
+    laps.lap("engine: slot layout");
     const int E = (int)slot_src.size();
     m.E = E;
     m.h_e_pose.resize(E), m.h_e_lm.resize(E), m.h_flags.resize(E);
@@ -396,33 +458,40 @@ void Engine::initialize(FlatGraph&& g)
                 cam[i] = g.e_cam[e];
         }
     };
-    { // independent per slot: split over a few host threads for big graphs
-        const unsigned nth = E < 100000 ? 1u : std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
-        if (nth == 1)
-            fill_slots(0, E);
-        else
-        {
-            std::vector<std::thread> pool;
-            for (unsigned t = 0; t < nth; t++)
-                pool.emplace_back(fill_slots, (int)((long)E * t / nth), (int)((long)E * (t + 1) / nth));
-            for (auto& th : pool)
-                th.join();
-        }
-    }
+    // independent per slot: split over a few host threads for big graphs
+    parallel_chunks((size_t)E, 100000, [&](size_t a, size_t b, unsigned) { fill_slots((int)a, (int)b); });
+    laps.lap("engine: fill slots");
     // ---- pose-major view (stable counting sort => ascending landmark inside a pose) ----
+    // threads own pose ranges and scan all slots (as in the landmark sort above)
     m.h_pose_ptr.assign(m.Pall + 1, 0);
-    for (int i = 0; i < E; i++)
-        if (slot_src[i] >= 0)
-            m.h_pose_ptr[m.h_e_pose[i] + 1]++;
-    for (int p = 0; p < m.Pall; p++)
-        m.h_pose_ptr[p + 1] += m.h_pose_ptr[p];
     m.h_pose_edge.assign(std::max(E, 1), 0);
     {
-        std::vector<int32_t> pos(m.h_pose_ptr.begin(), m.h_pose_ptr.end() - 1);
-        for (int i = 0; i < E; i++)
-            if (slot_src[i] >= 0)
-                m.h_pose_edge[pos[m.h_e_pose[i]]++] = i;
+        const size_t serial_below = E < 100000 ? (size_t)m.Pall + 1 : 0;
+        const int32_t* ep = m.h_e_pose.data();
+        const int32_t* src = slot_src.data();
+        parallel_chunks((size_t)m.Pall, serial_below, [&](size_t pa, size_t pb, unsigned) {
+            for (int i = 0; i < E; i++)
+            {
+                const size_t q = (size_t)ep[i];
+                if (src[i] >= 0 && q >= pa && q < pb)
+                    m.h_pose_ptr[q + 1]++;
+            }
+        });
+        for (int q = 0; q < m.Pall; q++)
+            m.h_pose_ptr[q + 1] += m.h_pose_ptr[q];
+        parallel_chunks((size_t)m.Pall, serial_below, [&](size_t pa, size_t pb, unsigned) {
+            if (pa == pb)
+                return;
+            std::vector<int32_t> pos(m.h_pose_ptr.begin() + pa, m.h_pose_ptr.begin() + pb);
+            for (int i = 0; i < E; i++)
+            {
+                const size_t q = (size_t)ep[i];
+                if (src[i] >= 0 && q >= pa && q < pb)
+                    m.h_pose_edge[pos[q - pa]++] = i;
+            }
+        });
     }
+    laps.lap("engine: pose-major view");
     // ---- upload --------------------------------------------------------------------------
     m.d_e_pose.upload(m.h_e_pose, s), m.d_e_lm.upload(m.h_e_lm, s), m.d_flags.upload(m.h_flags, s);
     m.d_meas.upload(meas, s), m.d_omega.upload(omega, s), m.d_cams.upload(g.cams, s);
@@ -444,7 +513,9 @@ void Engine::initialize(FlatGraph&& g)
     m.d_scal.resize(16), m.d_fail.resize(4), m.h_scal.resize(16), m.h_fail.resize(4);
     m.d_x.zero(s);
     m.ctx.scratch.resize(cugo_k::reduce_scratch_doubles(E, m.P, m.L));
+    laps.lap("engine: enqueue uploads");
     CUGO_HIP(hipStreamSynchronize(s)); // host staging vectors go out of scope
+    laps.lap("engine: upload sync");
 
     cugo_edges& ev = m.ev;
     ev.n_edges = E, ev.n_poses_total = m.Pall, ev.n_landmarks_total = m.Lall;
@@ -461,12 +532,32 @@ void Engine::initialize(FlatGraph&& g)
     {
         uint64_t h = 1469598103934665603ull;
         auto mix = [&h](const void* p, size_t n) {
-            const uint64_t* w = static_cast<const uint64_t*>(p);
-            for (size_t i = 0; i < n / 8; i++)
-                h = (h ^ w[i]) * 1099511628211ull;
-            const unsigned char* c = static_cast<const unsigned char*>(p) + (n & ~size_t(7));
-            for (size_t i = 0; i < (n & 7); i++)
-                h = (h ^ c[i]) * 1099511628211ull;
+            // 64-bit FNV-style hash of fixed 1 MiB pieces (hashed in parallel), then of their digests
+            constexpr size_t piece = 1u << 20;
+            const size_t np = (n + piece - 1) / piece;
+            std::vector<uint64_t> dig(np);
+            const unsigned char* base = static_cast<const unsigned char*>(p);
+            parallel_chunks(np, 4, [&](size_t a, size_t b, unsigned) {
+                for (size_t q = a; q < b; q++)
+                {
+                    const unsigned char* c0 = base + q * piece;
+                    const size_t len = std::min(piece, n - q * piece);
+                    uint64_t d = 1469598103934665603ull ^ len;
+                    size_t i = 0;
+                    for (; i + 8 <= len; i += 8)
+                    {
+                        uint64_t w;
+                        std::memcpy(&w, c0 + i, 8);
+                        d = (d ^ w) * 1099511628211ull;
+                    }
+                    for (; i < len; i++)
+                        d = (d ^ c0[i]) * 1099511628211ull;
+                    dig[q] = d;
+                }
+            });
+            for (uint64_t d : dig)
+                h = (h ^ d) * 1099511628211ull;
+            h = (h ^ n) * 1099511628211ull;
         };
         const int dims[8] = {m.Pall, m.Lall, m.P, m.L, E, m.rank, m.world, Etot};
         mix(dims, sizeof dims);
@@ -478,6 +569,7 @@ void Engine::initialize(FlatGraph&& g)
             m.structure_dirty = true;
         m.structure_sig = h;
     }
+    laps.lap("engine: topology hash");
     prof_[PROF_INITIALIZE] += ms_since(t0);
 }
 
@@ -504,7 +596,7 @@ void Engine::build_structure()
     // The three passes below are independent per pose row: contiguous row ranges, balanced by
     // their number of co-visibility entries, go to a few host threads (SLAM calls BA with a new
     // topology every time, so this "cold" work is paid on every call there).
-    const unsigned nth = m.cov_pose.size() < 200000 ? 1u : std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    const unsigned nth = m.cov_pose.size() < 200000 ? 1u : std::max(1u, std::min(kMaxHostThreads, std::thread::hardware_concurrency()));
     std::vector<int> row_split(nth + 1, P);
     row_split[0] = 0;
     for (unsigned t = 1; t < nth; t++)
@@ -516,11 +608,18 @@ void Engine::build_structure()
     auto parallel_rows = [&](const std::function<void(unsigned, int, int)>& fn) {
         if (nth == 1)
             return fn(0, 0, P);
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < nth; t++)
-            pool.emplace_back(fn, t, row_split[t], row_split[t + 1]);
-        for (auto& th : pool)
-            th.join();
+        struct RowCtx
+        {
+            const std::function<void(unsigned, int, int)>* fn;
+            const std::vector<int>* split;
+        } rc{&fn, &row_split};
+        pool_run(
+            nth,
+            [](void* p, unsigned t) {
+                RowCtx& c = *static_cast<RowCtx*>(p);
+                (*c.fn)(t, (*c.split)[t], (*c.split)[t + 1]);
+            },
+            &rc);
     };
     // rows: diagonal first, then ascending columns (ref: sparse_block_matrix.cpp:80-155; O(M)
     // with a marker array instead of the reference's dense P x P byte map)

@@ -11,9 +11,22 @@
 #include <stdexcept>
 
 #include "engine.h"
+#include "thread_pool.h"
 
 namespace cugo
 {
+
+namespace detail
+{
+unsigned hostPoolThreads()
+{
+    return cugo_host::pool_threads();
+}
+void hostPoolRun(unsigned chunks, void (*fn)(void*, unsigned), void* ctx)
+{
+    cugo_host::pool_run(chunks, fn, ctx);
+}
+} // namespace detail
 
 using cugo_host::Engine;
 using cugo_host::FlatGraph;
@@ -83,6 +96,15 @@ void CudaGraphOptimisationImpl::initialize()
     if (vertexSets.empty() || edgeSets.empty())
         throw std::runtime_error("cugo: initialize() needs at least one vertex set and one edge set");
 
+    const bool timing = std::getenv("CUGO_INIT_TIMING") != nullptr;
+    auto lap_t = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing)
+            return;
+        const auto n = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[cugo init] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - lap_t).count());
+        lap_t = n;
+    };
     FlatGraph g;
     // ---- vertex indices: free first (ascending id), fixed after -------------------------
     int nPfree = 0, nLfree = 0, nP = 0, nL = 0;
@@ -119,6 +141,7 @@ void CudaGraphOptimisationImpl::initialize()
     for (BaseVertexSet* vs : vertexSets)
         vs->gatherEstimates(vs->isMarginilised() ? g.lms.data() : g.poses.data());
 
+    lap("graph: vertices");
     // ---- edges: every edge with at least one free endpoint is active -------------------
     // Walking 561k edge objects through virtual getters is the bulk of initialize(); the walk of
     // each edge set is split over worker threads.  Every thread writes its contiguous chunk
@@ -141,7 +164,8 @@ void CudaGraphOptimisationImpl::initialize()
         bool uniform = true;
         bool too_many_cams = false;
     };
-    const unsigned hw = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    const unsigned hw = cugo_host::pool_threads();
+    lap("graph: edge array alloc");
     size_t out = 0; // slots filled so far (compacted)
     for (BaseEdgeSet* es : edgeSets)
     {
@@ -228,16 +252,12 @@ void CudaGraphOptimisationImpl::initialize()
             }
             c.count = o - c.begin;
         };
-        if (nthreads == 1)
-            work(0);
-        else
+        struct WorkCtx
         {
-            std::vector<std::thread> pool;
-            for (unsigned t = 0; t < nthreads; t++)
-                pool.emplace_back(work, t);
-            for (auto& th : pool)
-                th.join();
-        }
+            decltype(work)* w;
+        } wctx{&work};
+        cugo_host::pool_run(
+            nthreads, [](void* p, unsigned t) { (*static_cast<WorkCtx*>(p)->w)(t); }, &wctx);
         size_t nactive = 0;
         for (Chunk& c : chunks)
         {
@@ -303,16 +323,28 @@ void CudaGraphOptimisationImpl::initialize()
         g.cams.assign(z, z + 5);
     }
     g.rk = rk;
+    lap("graph: edge flatten");
 
     engine_->initialize(std::move(g));
+    lap("graph: engine initialize");
     stats_.clear();
     trace_.clear();
 }
 
 void CudaGraphOptimisationImpl::optimize(int niterations)
 {
+    const bool timing = std::getenv("CUGO_INIT_TIMING") != nullptr;
+    auto lap_t = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing)
+            return;
+        const auto n = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[cugo optimize] %-24s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - lap_t).count());
+        lap_t = n;
+    };
     std::vector<cugo_host::IterRecord> rec;
     engine_->optimize(niterations, rec, verbose);
+    lap("engine optimize");
     for (const auto& r : rec)
     {
         stats_.addStat({r.iteration, r.chi2});
@@ -333,8 +365,10 @@ void CudaGraphOptimisationImpl::optimize(int niterations)
     // ref: finalize(): estimates go back into the user's vertex objects
     std::vector<double> poses, lms;
     engine_->download(poses, lms);
+    lap("outliers + download");
     for (BaseVertexSet* vs : vertexSets)
         vs->scatterEstimates(vs->isMarginilised() ? lms.data() : poses.data());
+    lap("scatter estimates");
 }
 
 const TimeProfile& CudaGraphOptimisationImpl::timeProfile()

@@ -126,6 +126,42 @@ public:
     virtual int countFree() const noexcept = 0;
 };
 
+namespace detail
+{
+// the library's persistent host thread pool (csrc/host/thread_pool.cpp)
+unsigned hostPoolThreads();
+void hostPoolRun(unsigned chunks, void (*fn)(void*, unsigned), void* ctx);
+} // namespace detail
+
+// Runs f(begin, end, chunk) over [0, n) split into contiguous chunks on the library's host
+// threads (one chunk, in the caller, for small n).  Returns the number of chunks (<= 16).  The
+// vertex/edge walks of initialize()/optimize() are memory-latency bound pointer chasing: they
+// scale with threads.
+template <typename F>
+inline unsigned parallelChunks(size_t n, F&& f)
+{
+    const unsigned nt = n < 32768 ? 1u : detail::hostPoolThreads();
+    if (nt <= 1)
+    {
+        f((size_t)0, n, 0u);
+        return 1;
+    }
+    struct Ctx
+    {
+        F* f;
+        size_t n;
+        unsigned nt;
+    } ctx{&f, n, nt};
+    detail::hostPoolRun(
+        nt,
+        [](void* p, unsigned c) {
+            Ctx& x = *static_cast<Ctx*>(p);
+            (*x.f)(x.n * c / x.nt, x.n * (c + 1) / x.nt, c);
+        },
+        &ctx);
+    return nt;
+}
+
 // ref: VertexSet<T, E> src/optimisable_graph.h:224-332
 template <typename T, typename E>
 class VertexSet : public BaseVertexSet
@@ -136,7 +172,11 @@ public:
 
     explicit VertexSet(bool marg) : marginilised(marg) {}
 
-    void addVertex(T* vertex) { vertexMap.emplace(vertex->getId(), vertex); }
+    void addVertex(T* vertex)
+    {
+        vertexMap.emplace(vertex->getId(), vertex);
+        byIdStale = true;
+    }
     T* getVertex(const int id) const { return vertexMap.at(id); }
     bool removeVertex(BaseVertex* v, BaseEdgeSet* edgeSet) override;
     size_t size() const noexcept override { return vertexMap.size(); }
@@ -150,67 +190,117 @@ public:
         vertices.clear();
         activeSize = 0;
     }
-    void clearVertices() noexcept override { vertexMap.clear(); }
+    void clearVertices() noexcept override
+    {
+        vertexMap.clear();
+        byIdStale = true;
+    }
 
     int estimateDim() const noexcept override { return (int)(sizeof(E) / sizeof(double)); }
     int countFree() const noexcept override
     {
+        const std::vector<T*>& ids = idOrder();
+        std::vector<int> part(16, 0);
+        parallelChunks(ids.size(), [&](size_t a, size_t b, unsigned t) {
+            int c = 0;
+            for (size_t i = a; i < b; i++)
+                c += !ids[i]->isFixed();
+            part[t] = c;
+        });
         int c = 0;
-        for (const auto& kv : vertexMap)
-            c += !kv.second->isFixed();
+        for (int v : part)
+            c += v;
         return c;
     }
+    // free vertices first, fixed after, both in ascending id; chunks of the id order are
+    // partitioned independently once the per-chunk free/fixed counts are known
     void assignIndices(int firstFree, int firstFixed, int& nFree, int& nFixed) override
     {
-        const int total = (int)vertexMap.size();
-        const int nfree = countFree();
+        const std::vector<T*>& ids = idOrder();
+        const size_t total = ids.size();
+        std::vector<int> cfree(17, 0), cfix(17, 0);
+        const unsigned nt = parallelChunks(total, [&](size_t a, size_t b, unsigned t) {
+            int c = 0;
+            for (size_t i = a; i < b; i++)
+                c += !ids[i]->isFixed();
+            cfree[t + 1] = c;
+            cfix[t + 1] = (int)(b - a) - c;
+        });
+        for (unsigned t = 0; t < nt; t++)
+            cfree[t + 1] += cfree[t], cfix[t + 1] += cfix[t];
+        const int nfree = cfree[nt];
         vertices.assign(total, nullptr);
-        int f = 0, x = 0;
-        for (const auto& kv : vertexMap)
-        {
-            T* v = kv.second;
-            if (!v->isFixed())
+        parallelChunks(total, [&](size_t a, size_t b, unsigned t) {
+            int f = cfree[t], x = cfix[t];
+            for (size_t i = a; i < b; i++)
             {
-                v->setIndex(firstFree + f);
-                vertices[f++] = v;
+                T* v = ids[i];
+                if (!v->isFixed())
+                {
+                    v->setIndex(firstFree + f);
+                    vertices[f++] = v;
+                }
+                else
+                {
+                    v->setIndex(firstFixed + x);
+                    vertices[nfree + x++] = v;
+                }
             }
-            else
-            {
-                v->setIndex(firstFixed + x);
-                vertices[nfree + x++] = v;
-            }
-        }
+        });
         activeSize = nfree;
         nFree = nfree;
-        nFixed = x;
+        nFixed = (int)total - nfree;
     }
     void gatherEstimates(double* out) const override
     {
         static_assert(std::is_trivially_copyable<E>::value, "estimate must be POD");
         const int d = (int)(sizeof(E) / sizeof(double));
-        for (const T* v : vertices)
-        {
-            const E& e = v->getEstimate();
-            const double* src = reinterpret_cast<const double*>(&e);
-            std::copy(src, src + d, out + (size_t)v->getIndex() * d);
-        }
+        parallelChunks(vertices.size(), [&](size_t a, size_t b, unsigned) {
+            for (size_t i = a; i < b; i++)
+            {
+                const T* v = vertices[i];
+                const E& e = v->getEstimate();
+                const double* src = reinterpret_cast<const double*>(&e);
+                std::copy(src, src + d, out + (size_t)v->getIndex() * d);
+            }
+        });
     }
     void scatterEstimates(const double* in) override
     {
         const int d = (int)(sizeof(E) / sizeof(double));
-        for (T* v : vertices)
-        {
-            E e;
-            std::copy(in + (size_t)v->getIndex() * d, in + (size_t)(v->getIndex() + 1) * d,
-                      reinterpret_cast<double*>(&e));
-            v->setEstimate(e);
-        }
+        parallelChunks(vertices.size(), [&](size_t a, size_t b, unsigned) {
+            for (size_t i = a; i < b; i++)
+            {
+                T* v = vertices[i];
+                E e;
+                std::copy(in + (size_t)v->getIndex() * d, in + (size_t)(v->getIndex() + 1) * d,
+                          reinterpret_cast<double*>(&e));
+                v->setEstimate(e);
+            }
+        });
     }
 
 protected:
+    // the vertices in ascending id as a flat array: walking the std::map (one cache miss per
+    // node) is paid once after the set changed, not on every initialize()
+    const std::vector<T*>& idOrder() const
+    {
+        if (byIdStale)
+        {
+            byId.clear();
+            byId.reserve(vertexMap.size());
+            for (const auto& kv : vertexMap)
+                byId.push_back(kv.second);
+            byIdStale = false;
+        }
+        return byId;
+    }
+
     std::map<int, VertexType*> vertexMap; // ascending id
     bool marginilised;
     std::vector<VertexType*> vertices;
+    mutable std::vector<VertexType*> byId;
+    mutable bool byIdStale = true;
     int activeSize = 0;
 };
 
@@ -390,6 +480,7 @@ bool VertexSet<T, E>::removeVertex(BaseVertex* v, BaseEdgeSet* edgeSet)
     for (BaseEdge* e : es)
         edgeSet->removeEdge(e);
     vertexMap.erase(it);
+    byIdStale = true;
     return true;
 }
 

@@ -68,6 +68,12 @@ struct Engine::Impl : cugo_k::LaunchHook
     // host copies (sorted, local shard)
     std::vector<int32_t> h_e_pose, h_e_lm, h_lm_ptr, h_pose_ptr, h_pose_edge;
     std::vector<int32_t> slot_edge;     // slot -> edge index of the FlatGraph (-1: padding)
+    // staging of initialize(), kept between calls: a fresh 40 MB of vectors costs more in page
+    // faults than the work done on them
+    FlatGraph staging;
+    std::vector<int32_t> st_lm_cnt, st_order, st_slot_src;
+    std::vector<double> st_meas, st_omega;
+    std::vector<uint16_t> st_cam;
     std::vector<double> slot_threshold; // slot -> outlier threshold (empty: rejection disabled)
     int last_err_buf = 0;               // estimate buffer of the last error pass
     int Etot = 0;
@@ -265,7 +271,12 @@ struct InitLaps
     }
 };
 
-void Engine::initialize(FlatGraph&& g)
+FlatGraph& Engine::staging()
+{
+    return impl_->staging;
+}
+
+void Engine::initialize(FlatGraph& g)
 {
     const auto t0 = Clock::now();
     InitLaps laps;
@@ -280,30 +291,13 @@ void Engine::initialize(FlatGraph&& g)
     // Threads own contiguous landmark ranges: each scans all edges (8 B per edge, from cache)
     // and counts / places only the edges of its own landmarks, so no two threads write the same
     // bin and the placement keeps the container order inside a landmark (stable).
-    std::vector<int32_t> lm_cnt(m.Lall + 1, 0);
-    std::vector<int32_t> order(Etot);
+    std::vector<int32_t>& lm_cnt = m.st_lm_cnt;
+    std::vector<int32_t>& order = m.st_order;
+    lm_cnt.assign(m.Lall + 1, 0);
+    order.resize(Etot);
     {
         const int32_t* elm = g.e_lm.data();
-        parallel_chunks((size_t)m.Lall, 65536, [&](size_t la, size_t lb, unsigned) {
-            for (int e = 0; e < Etot; e++)
-            {
-                const size_t l = (size_t)elm[e];
-                if (l >= la && l < lb)
-                    lm_cnt[l + 1]++;
-            }
-        });
-        for (int l = 0; l < m.Lall; l++)
-            lm_cnt[l + 1] += lm_cnt[l];
-        parallel_chunks((size_t)m.Lall, 65536, [&](size_t la, size_t lb, unsigned) {
-            if (la == lb)
-                return;
-            std::vector<int32_t> pos(lm_cnt.begin() + la, lm_cnt.begin() + lb);
-            for (int e = 0; e < Etot; e++)
-            {
-                const size_t l = (size_t)elm[e];
-                if (l >= la && l < lb)
-                    order[pos[l - la]++] = e;
-            }
+        auto sort_by_pose = [&](size_t la, size_t lb) {
             for (size_t l = la; l < lb; l++)
             {
                 int32_t* b = order.data() + lm_cnt[l];
@@ -321,7 +315,82 @@ void Engine::initialize(FlatGraph&& g)
                     b[j + 1] = v;
                 }
             }
+        };
+        // Callers usually add the edges landmark by landmark (ORB-SLAM2 walks its map points):
+        // then the counting sort is the identity and only the counts are needed.
+        std::vector<uint8_t> chunk_sorted(kMaxHostThreads, 1);
+        parallel_chunks((size_t)Etot, 100000, [&](size_t a, size_t b, unsigned t) {
+            bool ok = true;
+            for (size_t e = std::max<size_t>(a, 1); e < b; e++)
+                ok = ok && elm[e - 1] <= elm[e];
+            chunk_sorted[t] = ok;
         });
+        bool sorted = true;
+        for (uint8_t c : chunk_sorted)
+            sorted = sorted && c;
+        if (sorted)
+        {
+            // a chunk's first and last landmark may continue in the neighbouring chunks: their
+            // counts are combined afterwards
+            struct Side
+            {
+                int32_t first = -1, nfirst = 0, last = -1, nlast = 0;
+            };
+            std::vector<Side> side(kMaxHostThreads);
+            parallel_chunks((size_t)Etot, 100000, [&](size_t a, size_t b, unsigned t) {
+                if (a == b)
+                    return;
+                Side sd;
+                sd.first = elm[a], sd.last = elm[b - 1];
+                for (size_t e = a; e < b; e++)
+                {
+                    const int32_t l = elm[e];
+                    if (l == sd.first)
+                        sd.nfirst++;
+                    else if (l == sd.last)
+                        sd.nlast++;
+                    else
+                        lm_cnt[l + 1]++;
+                    order[e] = (int32_t)e;
+                }
+                side[t] = sd;
+            });
+            for (const Side& sd : side)
+            {
+                if (sd.first >= 0)
+                    lm_cnt[sd.first + 1] += sd.nfirst;
+                if (sd.last >= 0 && sd.last != sd.first)
+                    lm_cnt[sd.last + 1] += sd.nlast;
+            }
+            for (int l = 0; l < m.Lall; l++)
+                lm_cnt[l + 1] += lm_cnt[l];
+            parallel_chunks((size_t)m.Lall, 65536, [&](size_t la, size_t lb, unsigned) { sort_by_pose(la, lb); });
+        }
+        else
+        {
+            parallel_chunks((size_t)m.Lall, 65536, [&](size_t la, size_t lb, unsigned) {
+                for (int e = 0; e < Etot; e++)
+                {
+                    const size_t l = (size_t)elm[e];
+                    if (l >= la && l < lb)
+                        lm_cnt[l + 1]++;
+                }
+            });
+            for (int l = 0; l < m.Lall; l++)
+                lm_cnt[l + 1] += lm_cnt[l];
+            parallel_chunks((size_t)m.Lall, 65536, [&](size_t la, size_t lb, unsigned) {
+                if (la == lb)
+                    return;
+                std::vector<int32_t> pos(lm_cnt.begin() + la, lm_cnt.begin() + lb);
+                for (int e = 0; e < Etot; e++)
+                {
+                    const size_t l = (size_t)elm[e];
+                    if (l >= la && l < lb)
+                        order[pos[l - la]++] = e;
+                }
+                sort_by_pose(la, lb);
+            });
+        }
     }
     laps.lap("engine: landmark sort");
     // ---- global co-visibility (all shards): free landmark -> free poses ----------------
@@ -362,7 +431,7 @@ void Engine::initialize(FlatGraph&& g)
     // substitution sum a landmark's edges inside one workgroup).  A padding slot belongs to
     // the landmark before it; slot_src[i] = index into `order`, or -1 for padding.
     constexpr int kBlock = 256;
-    std::vector<int32_t> slot_src;
+    std::vector<int32_t>& slot_src = m.st_slot_src;
     m.h_lm_ptr.assign(m.Lall + 1, 0);
     {
         // first the start slot of every landmark (sequential: a padding decision moves everything
@@ -405,8 +474,10 @@ void Engine::initialize(FlatGraph&& g)
     const int E = (int)slot_src.size();
     m.E = E;
     m.h_e_pose.resize(E), m.h_e_lm.resize(E), m.h_flags.resize(E);
-    std::vector<double> meas(3 * (size_t)E), omega;
-    std::vector<uint16_t> cam;
+    std::vector<double>&meas = m.st_meas, &omega = m.st_omega;
+    std::vector<uint16_t>& cam = m.st_cam;
+    meas.resize(3 * (size_t)E); // every slot is written by fill_slots
+    omega.clear(), cam.clear();
     m.n_omega = g.e_omega.size() > 1 ? E : 1;
     m.n_cams = (int)(g.cams.size() / 5);
     if (m.n_omega > 1)
@@ -462,33 +533,38 @@ void Engine::initialize(FlatGraph&& g)
     parallel_chunks((size_t)E, 100000, [&](size_t a, size_t b, unsigned) { fill_slots((int)a, (int)b); });
     laps.lap("engine: fill slots");
     // ---- pose-major view (stable counting sort => ascending landmark inside a pose) ----
-    // threads own pose ranges and scan all slots (as in the landmark sort above)
+    // threads own slot ranges: a histogram per thread, then offsets per (pose, thread) in thread
+    // order, so every thread places its own slots and the slot order inside a pose is kept
     m.h_pose_ptr.assign(m.Pall + 1, 0);
     m.h_pose_edge.assign(std::max(E, 1), 0);
     {
-        const size_t serial_below = E < 100000 ? (size_t)m.Pall + 1 : 0;
+        const size_t serial_below = (size_t)m.Pall * kMaxHostThreads > (size_t)E ? (size_t)E + 1 : 100000;
         const int32_t* ep = m.h_e_pose.data();
         const int32_t* src = slot_src.data();
-        parallel_chunks((size_t)m.Pall, serial_below, [&](size_t pa, size_t pb, unsigned) {
-            for (int i = 0; i < E; i++)
-            {
-                const size_t q = (size_t)ep[i];
-                if (src[i] >= 0 && q >= pa && q < pb)
-                    m.h_pose_ptr[q + 1]++;
-            }
+        std::vector<std::vector<int32_t>> hist(kMaxHostThreads);
+        const unsigned nt = parallel_chunks((size_t)E, serial_below, [&](size_t a, size_t b, unsigned t) {
+            std::vector<int32_t>& h = hist[t];
+            h.assign(m.Pall, 0);
+            for (size_t i = a; i < b; i++)
+                if (src[i] >= 0)
+                    h[ep[i]]++;
         });
         for (int q = 0; q < m.Pall; q++)
-            m.h_pose_ptr[q + 1] += m.h_pose_ptr[q];
-        parallel_chunks((size_t)m.Pall, serial_below, [&](size_t pa, size_t pb, unsigned) {
-            if (pa == pb)
-                return;
-            std::vector<int32_t> pos(m.h_pose_ptr.begin() + pa, m.h_pose_ptr.begin() + pb);
-            for (int i = 0; i < E; i++)
+        {
+            int32_t run = m.h_pose_ptr[q];
+            for (unsigned t = 0; t < nt; t++)
             {
-                const size_t q = (size_t)ep[i];
-                if (src[i] >= 0 && q >= pa && q < pb)
-                    m.h_pose_edge[pos[q - pa]++] = i;
+                const int32_t c = hist[t][q];
+                hist[t][q] = run; // first output position of thread t for pose q
+                run += c;
             }
+            m.h_pose_ptr[q + 1] = run;
+        }
+        parallel_chunks((size_t)E, serial_below, [&](size_t a, size_t b, unsigned t) {
+            std::vector<int32_t>& pos = hist[t];
+            for (size_t i = a; i < b; i++)
+                if (src[i] >= 0)
+                    m.h_pose_edge[pos[ep[i]]++] = (int32_t)i;
         });
     }
     laps.lap("engine: pose-major view");
@@ -532,8 +608,8 @@ void Engine::initialize(FlatGraph&& g)
     {
         uint64_t h = 1469598103934665603ull;
         auto mix = [&h](const void* p, size_t n) {
-            // 64-bit FNV-style hash of fixed 1 MiB pieces (hashed in parallel), then of their digests
-            constexpr size_t piece = 1u << 20;
+            // 64-bit FNV-style hash of fixed 64 KiB pieces (hashed in parallel), then of their digests
+            constexpr size_t piece = 1u << 16;
             const size_t np = (n + piece - 1) / piece;
             std::vector<uint64_t> dig(np);
             const unsigned char* base = static_cast<const unsigned char*>(p);

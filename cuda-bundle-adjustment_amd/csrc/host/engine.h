@@ -73,7 +73,9 @@ public:
 
     void set_shard(int rank, int world, cugo_exchange_fn fn, void* user);
     // ref: BlockSolver::initialize (block_solver.cpp:21-137)
-    void initialize(FlatGraph&& g);
+    void initialize(FlatGraph& g);
+    // a FlatGraph owned by the engine whose buffers survive between initialize() calls
+    FlatGraph& staging();
     // ref: optimize(); appends to records. verbose prints one line per iteration.
     void optimize(int niterations, std::vector<IterRecord>& records, bool verbose);
     // estimates back to host (ref: VertexSet::finalise, optimisable_graph.hpp:137-154)

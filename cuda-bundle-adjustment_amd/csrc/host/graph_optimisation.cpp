@@ -105,7 +105,8 @@ void CudaGraphOptimisationImpl::initialize()
         std::fprintf(stderr, "[cugo init] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - lap_t).count());
         lap_t = n;
     };
-    FlatGraph g;
+    FlatGraph& g = engine_->staging();
+    g.cams.clear();
     // ---- vertex indices: free first (ascending id), fixed after -------------------------
     int nPfree = 0, nLfree = 0, nP = 0, nL = 0;
     for (BaseVertexSet* vs : vertexSets)
@@ -198,6 +199,16 @@ void CudaGraphOptimisationImpl::initialize()
             uint16_t last_cam = 0;
             for (size_t i = i0; i < i1; ++i, ++it)
             {
+                // the walk is a chain of cache misses (edge object, then its two vertices):
+                // fetch the edge 16 ahead and the vertices of the edge 8 ahead
+                if (i + 16 < i1)
+                    __builtin_prefetch(*(it + 16));
+                if (i + 8 < i1)
+                {
+                    BaseEdge* e8 = *(it + 8);
+                    __builtin_prefetch(e8->getVertex(0));
+                    __builtin_prefetch(e8->getVertex(1));
+                }
                 BaseEdge* e = *it;
                 if (!e->isActive())
                     continue;
@@ -325,7 +336,7 @@ void CudaGraphOptimisationImpl::initialize()
     g.rk = rk;
     lap("graph: edge flatten");
 
-    engine_->initialize(std::move(g));
+    engine_->initialize(g);
     lap("graph: engine initialize");
     stats_.clear();
     trace_.clear();

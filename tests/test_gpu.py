@@ -410,6 +410,28 @@ def test_bitwise_reproducible(oracle_lib):
     assert np.array_equal(a["pose"], b["pose"]) and np.array_equal(a["lm"], b["lm"])
 
 
+@pytest.mark.parametrize("stereo", [0.0, 0.7])
+def test_edge_insertion_order_does_not_matter(oracle_lib, stereo):
+    """initialize() sorts the edges landmark-major (threaded above 100k edges; a shortcut when the
+    caller already added them landmark by landmark): any insertion order gives the same device
+    layout, hence bitwise the same run.  Mono-only input in landmark order takes the shortcut,
+    the shuffled copy and the mono|stereo split the general path."""
+    d = cugo.synth(300, 30000, 126000, seed=5, n_loop_closures=300, stereo_fraction=stereo)
+    assert bool(np.all(np.diff(d["e_lm"]) >= 0))  # the generator emits landmark-major edges
+    a = run_graph(d, 4)
+    perm = np.random.default_rng(1).permutation(len(d["e_pose"]))
+    sh = dict(d)
+    for k in ("e_pose", "e_lm", "e_stereo", "e_meas", "e_omega"):
+        sh[k] = np.ascontiguousarray(np.asarray(d[k])[perm])
+    if np.asarray(d["e_cam"]).reshape(-1, 5).shape[0] > 1:
+        sh["e_cam"] = np.ascontiguousarray(np.asarray(d["e_cam"]).reshape(-1, 5)[perm])
+    b = run_graph(sh, 4)
+    assert [x["chi2"] for x in a["stats"]] == [x["chi2"] for x in b["stats"]]
+    assert np.array_equal(a["pose"], b["pose"]) and np.array_equal(a["lm"], b["lm"])
+    prob = oracle_lib.Problem(*synth.problem_fields(d))
+    assert_trajectories_match(a["stats"], prob.optimize(4), 1e-10)
+
+
 def test_ids_fixed_vertices_and_reinitialize(oracle_lib):
     """non-contiguous ids, fixed poses and landmarks, the sample's warm-up protocol
     (initialize; optimize(1); initialize; optimize(n) — ref samples/sample_ba_from_file/main.cpp:168-188)"""

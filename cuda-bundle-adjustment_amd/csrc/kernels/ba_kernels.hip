@@ -76,6 +76,18 @@ __device__ __forceinline__ double block_sum(double v, double* sm)
     return r;
 }
 
+// Workgroups b and b+8 land on the same XCD (observed round-robin dispatch; speed only, never
+// correctness) and share its 4 MiB L2.  k_hsc_diag gives every XCD a CONTIGUOUS range of poses:
+// neighbouring poses read the same landmarks' 144-B blocks (adjacent slots, shared cache lines),
+// so a line fetched once serves the neighbours out of L2 (57 -> 47 us on the kitti_00 shape).
+// Launch 8*ceil(n/8) workgroups; returns the work item of this workgroup (>= n: none).
+__device__ __forceinline__ int xcd_contiguous_item(int n)
+{
+    const int per = (n + 7) >> 3;
+    return (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+}
+static inline int xcd_grid(int n) { return 8 * ((n + 7) / 8); }
+
 // a wave's own LDS writes become visible to its other lanes (no workgroup barrier needed)
 __device__ __forceinline__ void wave_sync_lds()
 {
@@ -588,7 +600,9 @@ __global__ __launch_bounds__(HD_BS) void k_hsc_diag(EV ev, const int32_t* __rest
     __shared__ double2 sT2[HD_W][HD_CH * 9 + 1]; // T blocks as loaded
     __shared__ double sU[HD_W][HD_CH * 21 + 3];  // per edge: 3 rows of [H[6m..6m+5], bl[m]]
     __shared__ double part[HD_W][28];
-    const int p = blockIdx.x;
+    const int p = xcd_contiguous_item(ev.P);
+    if (p >= ev.P)
+        return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     // output element of this lane: v < 21 -> (r, c) of the upper triangle, else rhs row r
     const int v = lane < 27 ? lane : 26;
@@ -698,6 +712,10 @@ __global__ __launch_bounds__(BS) void k_hsc_offdiag(int nblocks,
 {
     __shared__ double2 stage[BS / 64][2][OD_CH * 9 + 1];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // (blocks stay in dispatch order here: giving every XCD a contiguous range of Hsc blocks was
+    // measured slower, 123 vs 112 us — the operands shared by neighbouring blocks are then no
+    // longer fetched by several XCDs at about the same time, which is what makes the re-reads
+    // Infinity-Cache hits)
     const int k = blockIdx.x * (BS / 64) + w;
     if (k >= nblocks)
         return; // whole wave
@@ -992,7 +1010,7 @@ void launch_schur(hipStream_t s, const cugo_edges& e, const cugo_hsc_struct& hs,
         CUGO_LAUNCH(k_hsc_offdiag, dim3(div_up(hs.n_blocks, BS / 64)), dim3(BS), 0, s,
                            hs.n_blocks, hs.d_off_ptr, hs.d_off_ei, hs.d_off_ej, d_Hpl, d_T, d_Hsc);
     if (ev.P > 0)
-        CUGO_LAUNCH(k_hsc_diag, dim3(ev.P), dim3(HD_BS), 0, s, ev,
+        CUGO_LAUNCH(k_hsc_diag, dim3(xcd_grid(ev.P)), dim3(HD_BS), 0, s, ev,
                            hs.d_rowptr, damp_hsc_diag ? lambda : 0.0, d_Hpp, d_bp, d_bl, d_Hpl, d_T,
                            d_Hsc, d_bsc);
 }

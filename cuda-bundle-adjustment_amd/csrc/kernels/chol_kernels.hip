@@ -273,6 +273,7 @@ __device__ __forceinline__ void dev_load_l11(const double* __restrict__ F, long 
 // column to its own rows below the block (lane t: rows j0+6+t and j0+70+t; nc <= 96).
 // Right-looking inside the panel, so every value is touched by one FMA per column: the
 // dependent chain is 6 x (sqrt || 1/d, mul, mul, fma) ~ 6 x 220 cycles.  Writes dinv[j0..j0+5].
+template <bool HAS1>
 __device__ __forceinline__ bool panel_factor_wave(double* __restrict__ Ls, int nc, int j0,
                                                   double* __restrict__ dinv)
 {
@@ -280,7 +281,7 @@ __device__ __forceinline__ bool panel_factor_wave(double* __restrict__ Ls, int n
     const int r0 = j0 + PW + lane, r1 = j0 + PW + 64 + lane;
     // rows past the end are clamped to the last padded row for the loads (valid LDS, results
     // unused) and masked as a group for the stores: no branch per access
-    const bool ok0 = r0 < nc, ok1 = r1 < nc;
+    const bool ok0 = r0 < nc, ok1 = HAS1 && r1 < nc;
     double* P = Ls + j0 * LLD + j0;           // (j0, j0); column c at P + c*LLD (immediate offsets)
     const double* A0 = Ls + j0 * LLD + min(r0, NC_MAX - 1);
     const double* A1 = Ls + j0 * LLD + min(r1, NC_MAX - 1);
@@ -294,7 +295,7 @@ __device__ __forceinline__ bool panel_factor_wave(double* __restrict__ Ls, int n
         for (int r = 0; r < PW; r++)
             D[r][c] = (r >= c) ? P[c * LLD + r] : 0.0;
         a0[c] = A0[c * LLD];
-        a1[c] = A1[c * LLD];
+        a1[c] = HAS1 ? A1[c * LLD] : 0.0;
     }
     bool bad = false;
     double iv[PW];
@@ -319,10 +320,12 @@ __device__ __forceinline__ bool panel_factor_wave(double* __restrict__ Ls, int n
             const double y = __builtin_amdgcn_rsq(d);
             double g = d * y, h = 0.5 * y;
             const double r0 = fma(-h, g, 0.5);
+            // h2 = 2h is carried along so that 1/sqrt(d) needs no final doubling on the chain
+            const double h2 = fma(y, r0, y);
             g = fma(g, r0, g), h = fma(h, r0, h);
             const double dg = fma(-g, g, d), rh = fma(-h, g, 0.5);
             sq = fma(dg, h, g);
-            inv = 2.0 * fma(h, rh, h);
+            inv = fma(h2, rh, h2);
         }
         iv[j] = inv;
         D[j][j] = sq;
@@ -331,7 +334,8 @@ __device__ __forceinline__ bool panel_factor_wave(double* __restrict__ Ls, int n
             if (i > j)
                 D[i][j] *= inv;
         a0[j] *= inv;
-        a1[j] *= inv;
+        if (HAS1)
+            a1[j] *= inv;
 #pragma unroll
         for (int c = 0; c < PW; c++)
             if (c > j)
@@ -341,7 +345,8 @@ __device__ __forceinline__ bool panel_factor_wave(double* __restrict__ Ls, int n
                     if (i >= c)
                         D[i][c] -= D[i][j] * D[c][j];
                 a0[c] -= a0[j] * D[c][j];
-                a1[c] -= a1[j] * D[c][j];
+                if (HAS1)
+                    a1[c] -= a1[j] * D[c][j];
             }
     }
     if (j0 == 0)
@@ -349,19 +354,23 @@ __device__ __forceinline__ bool panel_factor_wave(double* __restrict__ Ls, int n
         asm volatile("" ::"v"(D[PW - 1][PW - 1]), "v"(a1[PW - 1]), "v"(a0[PW - 1]));
         stamp(2, 2);
     }
-    if (ok0)
+    // Branch-free stores: lanes without a row write into a sink (the Vs area behind dinv, unused
+    // until the panels are done; offsets up to 127 + 5*LLD stay inside it).  With the stores under
+    // `if (ok0)` the compiler sinks the loads and the whole update chain of a0/a1 into that
+    // branch, i.e. behind the factorisation of D instead of into its latency shadows.
     {
-        double* W0 = Ls + j0 * LLD + r0;
+        double* sink = dinv + NC_MAX + lane;
+        double* W0 = ok0 ? Ls + j0 * LLD + r0 : sink;
 #pragma unroll
         for (int c = 0; c < PW; c++)
             W0[c * LLD] = a0[c];
-    }
-    if (ok1)
-    {
-        double* W1 = Ls + j0 * LLD + r1;
+        if (HAS1)
+        {
+            double* W1 = ok1 ? Ls + j0 * LLD + r1 : sink + 64;
 #pragma unroll
-        for (int c = 0; c < PW; c++)
-            W1[c * LLD] = a1[c];
+            for (int c = 0; c < PW; c++)
+                W1[c * LLD] = a1[c];
+        }
     }
     if (lane == 0)
     {
@@ -467,7 +476,7 @@ __device__ __forceinline__ void dev_potrf(const double* __restrict__ F, long ld,
     __syncthreads();
     stamp(0, 2);
     if (threadIdx.x < 64)
-        if (panel_factor_wave(Ls, nc, 0, dinv))
+        if (nc > PW + 64 ? panel_factor_wave<true>(Ls, nc, 0, dinv) : panel_factor_wave<false>(Ls, nc, 0, dinv))
             *fail = 1;
     __syncthreads();
     stamp(0, 3);
@@ -480,7 +489,9 @@ __device__ __forceinline__ void dev_potrf(const double* __restrict__ F, long ld,
         __syncthreads();
         if (threadIdx.x < 64)
         {
-            if (panel_factor_wave(Ls, nc, jn, dinv))
+            // rows beyond the first 64 below the panel (second register row per lane) exist only
+            // in the first panels of a wide pivot block
+            if (jn + PW + 64 < nc ? panel_factor_wave<true>(Ls, nc, jn, dinv) : panel_factor_wave<false>(Ls, nc, jn, dinv))
                 *fail = 1;
         }
         else

@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--float32", action="store_true",
+                    help="fp32-internal mode (BASELINE config 5): float storage of the Hpl / T block streams")
     args = ap.parse_args()
 
     import torch
@@ -103,6 +105,8 @@ def main():
 
     def make_graph():
         g = cugo.graph_from_arrays(data)
+        if args.float32:
+            g.set_float32(True)
         if world > 1:
             g.set_shard(rank, world, exchange)
         t0 = time.perf_counter()
@@ -273,7 +277,8 @@ def main():
             "config": {"workload": "%s-shaped synthetic graph: %d poses / %d landmarks / %d edges, %d LM iterations"
                                    % (args.workload, P, L, nedges, args.iters),
                        "parallelism": "landmark-sharded x%d, replicated LL^T" % world if world > 1 else "single GPU",
-                       "lm_iterations_per_step": iters_total / args.steps},
+                       "lm_iterations_per_step": iters_total / args.steps,
+                       "block_storage": "float (Hpl, Hpl*invHll streams; BASELINE config 5)" if args.float32 else "double"},
             "ba_10iter_seconds": elapsed / args.steps,
             "init_ms": float(np.median(init_ms)),
             "cold_first_call": cold,

@@ -37,7 +37,8 @@ class Edges(C.Structure):
                 ("d_pose", C.c_void_p), ("d_lm", C.c_void_p), ("d_meas", C.c_void_p),
                 ("d_omega", C.c_void_p), ("n_omega", C.c_int), ("d_flags", C.c_void_p),
                 ("d_cam", C.c_void_p), ("d_cams", C.c_void_p), ("n_cams", C.c_int),
-                ("d_lm_ptr", C.c_void_p), ("d_pose_ptr", C.c_void_p), ("d_pose_edge", C.c_void_p)]
+                ("d_lm_ptr", C.c_void_p), ("d_pose_ptr", C.c_void_p), ("d_pose_edge", C.c_void_p),
+                ("block_f32", C.c_int)]
 
 
 class Robust(C.Structure):
@@ -240,6 +241,10 @@ class Graph:
         n = lib().cugo_graph_time_profile(self._g, buf, 2048, _p(ms, _f64p), 16)
         names = buf.value.decode().split("\n")[:n]
         return dict(zip(names, ms[:n].tolist()))
+
+    def set_float32(self, on):
+        """fp32-internal mode: float storage of the Hpl / T block streams (next initialize())"""
+        check(lib().cugo_graph_set_float32(self._g, int(on)))
 
     def set_kernel_timing(self, on):
         lib().cugo_graph_set_kernel_timing(self._g, int(on))

@@ -130,7 +130,7 @@ int cugo_compute_active_errors(cugo_ctx* ctx, const cugo_edges* ev, const double
 
 int cugo_construct_quadratic_form(cugo_ctx* ctx, const cugo_edges* ev, const double* d_poses,
                                   const double* d_lms, cugo_robust rk, double* d_Hpp, double* d_bp,
-                                  double* d_Hll, double* d_bl, double* d_Hpl, double* d_chi)
+                                  double* d_Hll, double* d_bl, void* d_Hpl, double* d_chi)
 {
     return guarded([&] {
         cugo_k::launch_build(ctx->stream, *ev, d_poses, d_lms, rk, d_Hpp, d_bp, d_Hll, d_bl, d_Hpl,
@@ -151,8 +151,8 @@ int cugo_max_diagonal(cugo_ctx* ctx, const double* d_Hpp, int nP, const double* 
 
 int cugo_compute_schur(cugo_ctx* ctx, const cugo_edges* ev, const cugo_hsc_struct* hs, double lambda,
                        int damp_hsc_diag, const double* d_Hpp, const double* d_bp,
-                       const double* d_Hll, const double* d_bl, const double* d_Hpl,
-                       double* d_invHll, double* d_T, double* d_bsc, double* d_Hsc)
+                       const double* d_Hll, const double* d_bl, const void* d_Hpl,
+                       double* d_invHll, void* d_T, double* d_bsc, double* d_Hsc)
 {
     return guarded([&] {
         cugo_k::launch_schur(ctx->stream, *ev, *hs, lambda, damp_hsc_diag, d_Hpp, d_bp, d_Hll, d_bl,
@@ -163,7 +163,7 @@ int cugo_compute_schur(cugo_ctx* ctx, const cugo_edges* ev, const cugo_hsc_struc
 
 int cugo_backsubst_update(cugo_ctx* ctx, const cugo_edges* ev, double lambda,
                           const double* d_invHll, const double* d_bl, const double* d_bp,
-                          const double* d_Hpl, const double* d_xp, double* d_xl,
+                          const void* d_Hpl, const double* d_xp, double* d_xl,
                           const double* d_poses_in, const double* d_lms_in, double* d_poses_out,
                           double* d_lms_out, double* d_scale)
 {
@@ -533,6 +533,11 @@ int cugo_graph_time_profile(cugo_graph* g, char* names, int buf_len, double* ms,
 int cugo_graph_set_verbose(cugo_graph* g, int v)
 {
     g->opt->setVerbose(v != 0);
+    return CUGO_OK;
+}
+int cugo_graph_set_float32(cugo_graph* g, int on)
+{
+    g->opt->setUseFloat32(on != 0);
     return CUGO_OK;
 }
 int cugo_graph_set_kernel_timing(cugo_graph* g, int on)

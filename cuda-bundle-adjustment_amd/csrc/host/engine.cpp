@@ -71,6 +71,7 @@ struct Engine::Impl : cugo_k::LaunchHook
     // staging of initialize(), kept between calls: a fresh 40 MB of vectors costs more in page
     // faults than the work done on them
     FlatGraph staging;
+    bool f32_blocks = false; // Hpl / T stored as float (fp32-internal mode)
     std::vector<int32_t> st_lm_cnt, st_order, st_slot_src;
     std::vector<double> st_meas, st_omega;
     std::vector<uint16_t> st_cam;
@@ -270,6 +271,11 @@ struct InitLaps
         t = n;
     }
 };
+
+void Engine::set_float32_blocks(bool on)
+{
+    impl_->f32_blocks = on;
+}
 
 FlatGraph& Engine::staging()
 {
@@ -583,7 +589,13 @@ void Engine::initialize(FlatGraph& g)
     m.cur = 0;
     m.d_Hpp.resize(36 * (size_t)m.P + 16), m.d_b.resize(6 * (size_t)m.P + 3 * (size_t)m.L + 16);
     m.d_Hll.resize(9 * (size_t)m.L + 16), m.d_invHll.resize(9 * (size_t)m.L + 16);
-    m.d_Hpl.resize(18 * (size_t)E + 16), m.d_T.resize(18 * (size_t)E + 16);
+    {
+        // block streams: 18 doubles per edge slot, or 18 floats (= 9 doubles of storage)
+        const char* env = std::getenv("CUGO_FLOAT32");
+        m.ev.block_f32 = (m.f32_blocks || (env && env[0] == '1')) ? 1 : 0;
+        const size_t per_edge = m.ev.block_f32 ? 9 : 18;
+        m.d_Hpl.resize(per_edge * (size_t)E + 16), m.d_T.resize(per_edge * (size_t)E + 16);
+    }
     m.d_x.resize(6 * (size_t)m.P + 3 * (size_t)m.L + 16);
     m.d_tmp.resize(36 * (size_t)m.P + 16);
     m.d_scal.resize(16), m.d_fail.resize(4), m.h_scal.resize(16), m.h_fail.resize(4);

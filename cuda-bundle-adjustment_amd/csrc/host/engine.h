@@ -73,6 +73,9 @@ public:
 
     void set_shard(int rank, int world, cugo_exchange_fn fn, void* user);
     // ref: BlockSolver::initialize (block_solver.cpp:21-137)
+    // float storage of the Hpl / T block streams (GraphOptimisationOptions::useFloat32); takes
+    // effect at the next initialize().  The environment variable CUGO_FLOAT32=1 forces it on.
+    void set_float32_blocks(bool on);
     void initialize(FlatGraph& g);
     // a FlatGraph owned by the engine whose buffers survive between initialize() calls
     FlatGraph& staging();

@@ -105,6 +105,7 @@ void CudaGraphOptimisationImpl::initialize()
         std::fprintf(stderr, "[cugo init] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - lap_t).count());
         lap_t = n;
     };
+    engine_->set_float32_blocks(options.useFloat32);
     FlatGraph& g = engine_->staging();
     g.cams.clear();
     // ---- vertex indices: free first (ascending id), fixed after -------------------------

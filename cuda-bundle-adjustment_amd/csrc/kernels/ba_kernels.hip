@@ -88,6 +88,38 @@ __device__ __forceinline__ int xcd_contiguous_item(int n)
 }
 static inline int xcd_grid(int n) { return 8 * ((n + 7) / 8); }
 
+// Element type S of the two per-edge block streams, Hpl [E][18] and T = Hpl invHll [E][18]:
+// double, or float in the fp32-internal mode (BASELINE config 5; cugo_edges.block_f32).  Those
+// two arrays are what the Schur kernels move, so float storage halves their traffic; every
+// value is widened on load and all arithmetic and every accumulator stays fp64.  The blocks are
+// moved as pairs of consecutive elements: 16-B accesses for double, 8-B for float, the same
+// lane <-> pair assignment in both.
+template <typename S>
+struct BlockPair;
+template <>
+struct BlockPair<double>
+{
+    using type = double2;
+};
+template <>
+struct BlockPair<float>
+{
+    using type = float2;
+};
+template <typename S>
+__device__ __forceinline__ double2 ld_pair(const S* __restrict__ base, size_t pair)
+{
+    const typename BlockPair<S>::type v = reinterpret_cast<const typename BlockPair<S>::type*>(base)[pair];
+    return make_double2((double)v.x, (double)v.y);
+}
+template <typename S>
+__device__ __forceinline__ void st_pair(S* __restrict__ base, size_t pair, double a, double b)
+{
+    typename BlockPair<S>::type v;
+    v.x = (S)a, v.y = (S)b;
+    reinterpret_cast<typename BlockPair<S>::type*>(base)[pair] = v;
+}
+
 // a wave's own LDS writes become visible to its other lanes (no workgroup barrier needed)
 __device__ __forceinline__ void wave_sync_lds()
 {
@@ -237,9 +269,10 @@ __device__ __forceinline__ LmContrib lm_contrib(const double JL[3][3], const Edg
                      g.w * t0, g.w * t1, g.w * t2};
 }
 
+template <typename S>
 __global__ __launch_bounds__(BS) void k_build_edges(EV ev, const double* __restrict__ poses,
                                                     const double* __restrict__ lms, Robust2 rk,
-                                                    double* __restrict__ Hpl,
+                                                    S* __restrict__ Hpl,
                                                     double* __restrict__ Hll,
                                                     double* __restrict__ bl,
                                                     double* __restrict__ rec,
@@ -294,10 +327,9 @@ __global__ __launch_bounds__(BS) void k_build_edges(EV ev, const double* __restr
                     }
             }
         }
-        double2* dst = reinterpret_cast<double2*>(Hpl + 18 * (size_t)e);
 #pragma unroll
         for (int i = 0; i < 9; i++)
-            dst[i] = make_double2(H[2 * i], H[2 * i + 1]);
+            st_pair(Hpl, 9 * (size_t)e + i, H[2 * i], H[2 * i + 1]);
     }
     {
         const int t = threadIdx.x;
@@ -525,11 +557,12 @@ __global__ __launch_bounds__(BS) void k_max_diag(const double* __restrict__ Hpp,
 // ---------------------------------------------------------------- Schur: edges ---------
 // invHll = (Hll + lambda I)^-1 (written by the landmark's first edge lane),
 // T[e] = Hpl[e] * invHll   (ref: computeBschureKernel .cu:1286-1314, lane per edge)
+template <typename S>
 __global__ __launch_bounds__(BS) void k_schur_edges(EV ev, double lambda,
                                                     const double* __restrict__ Hll,
-                                                    const double* __restrict__ Hpl,
+                                                    const S* __restrict__ Hpl,
                                                     double* __restrict__ invHll,
-                                                    double* __restrict__ T)
+                                                    S* __restrict__ T)
 {
     const int e = blockIdx.x * BS + threadIdx.x;
     if (e >= ev.E)
@@ -548,12 +581,11 @@ __global__ __launch_bounds__(BS) void k_schur_edges(EV ev, double lambda,
     const uint8_t fl = ev.flags[e];
     if (fl & (CUGO_EDGE_FIXED_L | CUGO_EDGE_FIXED_P | CUGO_EDGE_INACTIVE))
         return;
-    const double2* src = reinterpret_cast<const double2*>(Hpl + 18 * (size_t)e);
     double H[18];
 #pragma unroll
     for (int i = 0; i < 9; i++)
     {
-        const double2 v = src[i];
+        const double2 v = ld_pair(Hpl, 9 * (size_t)e + i);
         H[2 * i] = v.x, H[2 * i + 1] = v.y;
     }
     double Tt[18];
@@ -565,10 +597,9 @@ __global__ __launch_bounds__(BS) void k_schur_edges(EV ev, double lambda,
         Tt[6 + r] = a * iv.b01 + b * iv.b11 + c * iv.b12;
         Tt[12 + r] = a * iv.b02 + b * iv.b12 + c * iv.b22;
     }
-    double2* dst = reinterpret_cast<double2*>(T + 18 * (size_t)e);
 #pragma unroll
     for (int i = 0; i < 9; i++)
-        dst[i] = make_double2(Tt[2 * i], Tt[2 * i + 1]);
+        st_pair(T, 9 * (size_t)e + i, Tt[2 * i], Tt[2 * i + 1]);
 }
 
 // ---------------------------------------------------------------- Schur: diagonal ------
@@ -587,13 +618,14 @@ __device__ __forceinline__ void wave_sync_lds0()
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
 }
+template <typename S>
 __global__ __launch_bounds__(HD_BS) void k_hsc_diag(EV ev, const int32_t* __restrict__ rowptr,
                                                  double lambda_diag,
                                                  const double* __restrict__ Hpp,
                                                  const double* __restrict__ bp,
                                                  const double* __restrict__ bl,
-                                                 const double* __restrict__ Hpl,
-                                                 const double* __restrict__ T,
+                                                 const S* __restrict__ Hpl,
+                                                 const S* __restrict__ T,
                                                  double* __restrict__ Hsc,
                                                  double* __restrict__ bsc)
 {
@@ -621,8 +653,6 @@ __global__ __launch_bounds__(HD_BS) void k_hsc_diag(EV ev, const int32_t* __rest
         r = v - 21;
     const int pj = min(lane / 9, HD_CH - 1), part9 = lane - 9 * (lane / 9);
     const bool writer = lane < 9 * HD_CH;
-    const double2* T2 = reinterpret_cast<const double2*>(T);
-    const double2* H2 = reinterpret_cast<const double2*>(Hpl);
     const double* sT = reinterpret_cast<const double*>(sT2[w]);
     double* su = sU[w];
     const int i0 = ev.pose_ptr[p], i1 = ev.pose_ptr[p + 1];
@@ -642,7 +672,8 @@ __global__ __launch_bounds__(HD_BS) void k_hsc_diag(EV ev, const int32_t* __rest
         const bool act = i < i1 && !(fl & (CUGO_EDGE_FIXED_L | CUGO_EDGE_FIXED_P | CUGO_EDGE_INACTIVE));
         // fixed-landmark edges have l >= L: no bl entry (and they are never active)
         const int lsafe = act ? l : 0;
-        double2 tv = T2[9 * (size_t)e + part9], hv = H2[9 * (size_t)e + part9];
+        double2 tv = ld_pair(T, 9 * (size_t)e + part9);
+        const double2 hv = ld_pair(Hpl, 9 * (size_t)e + part9);
         const double bv = bl[3 * (size_t)lsafe + min(part9, 2)];
         if (!act)
             tv = make_double2(0, 0); // the edge contributes nothing
@@ -702,12 +733,13 @@ __global__ __launch_bounds__(HD_BS) void k_hsc_diag(EV ev, const int32_t* __rest
 // accumulates its own element over the chunk: no cross-lane reduction, summation in list order
 // (bit-reproducible).  The next chunk's loads are in flight while the current one is consumed.
 constexpr int OD_CH = 14; // products per chunk: two 7-product groups per load round
+template <typename S>
 __global__ __launch_bounds__(BS) void k_hsc_offdiag(int nblocks,
                                                     const int32_t* __restrict__ off_ptr,
                                                     const int32_t* __restrict__ off_ei,
                                                     const int32_t* __restrict__ off_ej,
-                                                    const double* __restrict__ Hpl,
-                                                    const double* __restrict__ T,
+                                                    const S* __restrict__ Hpl,
+                                                    const S* __restrict__ T,
                                                     double* __restrict__ Hsc)
 {
     __shared__ double2 stage[BS / 64][2][OD_CH * 9 + 1];
@@ -735,12 +767,10 @@ __global__ __launch_bounds__(BS) void k_hsc_offdiag(int nblocks,
     }
     // software pipeline: index pairs two chunks ahead, operands one chunk ahead
     // (scalars, not arrays: the compiler parks small indexed arrays in scratch memory)
-    const double2* Tq = reinterpret_cast<const double2*>(T) + part;
-    const double2* Hq = reinterpret_cast<const double2*>(Hpl) + part;
     int j0 = min(beg + pj, end - 1), j1 = min(beg + pj + 7, end - 1); // clamped: surplus lanes re-read the last product
     int ei0 = off_ei[j0], ej0 = off_ej[j0], ei1 = off_ei[j1], ej1 = off_ej[j1];
-    double2 tv0 = Tq[9 * (size_t)ei0], hv0 = Hq[9 * (size_t)ej0];
-    double2 tv1 = Tq[9 * (size_t)ei1], hv1 = Hq[9 * (size_t)ej1];
+    double2 tv0 = ld_pair(T, 9 * (size_t)ei0 + part), hv0 = ld_pair(Hpl, 9 * (size_t)ej0 + part);
+    double2 tv1 = ld_pair(T, 9 * (size_t)ei1 + part), hv1 = ld_pair(Hpl, 9 * (size_t)ej1 + part);
     j0 = min(beg + OD_CH + pj, end - 1), j1 = min(beg + OD_CH + pj + 7, end - 1);
     ei0 = off_ei[j0], ej0 = off_ej[j0], ei1 = off_ei[j1], ej1 = off_ej[j1];
     double2* w0 = &stage[w][0][9 * pj + part];
@@ -754,8 +784,8 @@ __global__ __launch_bounds__(BS) void k_hsc_offdiag(int nblocks,
         }
         if (idx + OD_CH < end)
         {
-            tv0 = Tq[9 * (size_t)ei0], hv0 = Hq[9 * (size_t)ej0];
-            tv1 = Tq[9 * (size_t)ei1], hv1 = Hq[9 * (size_t)ej1];
+            tv0 = ld_pair(T, 9 * (size_t)ei0 + part), hv0 = ld_pair(Hpl, 9 * (size_t)ej0 + part);
+            tv1 = ld_pair(T, 9 * (size_t)ei1 + part), hv1 = ld_pair(Hpl, 9 * (size_t)ej1 + part);
             j0 = min(idx + 2 * OD_CH + pj, end - 1), j1 = min(idx + 2 * OD_CH + pj + 7, end - 1);
             ei0 = off_ei[j0], ej0 = off_ej[j0], ei1 = off_ei[j1], ej1 = off_ej[j1];
         }
@@ -787,7 +817,8 @@ __global__ __launch_bounds__(BS) void k_hsc_offdiag(int nblocks,
 // first edge subtracts the contributions of its edges in edge order (fixed order) and
 // finishes the landmark.  Edges of a landmark beyond the block (never with the engine's
 // padded layout) are recomputed from global memory by the owner.
-__device__ __forceinline__ void hplT_x(const double* __restrict__ H, const double* __restrict__ x,
+template <typename S>
+__device__ __forceinline__ void hplT_x(const S* __restrict__ H, const double* __restrict__ x,
                                        double& s0, double& s1, double& s2)
 {
     s0 = 0, s1 = 0, s2 = 0;
@@ -795,9 +826,9 @@ __device__ __forceinline__ void hplT_x(const double* __restrict__ H, const doubl
     for (int m = 0; m < 6; m++)
     {
         const double xm = x[m];
-        s0 += H[m] * xm;
-        s1 += H[6 + m] * xm;
-        s2 += H[12 + m] * xm;
+        s0 += (double)H[m] * xm;
+        s1 += (double)H[6 + m] * xm;
+        s2 += (double)H[12 + m] * xm;
     }
 }
 
@@ -827,9 +858,10 @@ __device__ __forceinline__ void dev_update_poses(int blk, int nP, double lambda,
         partials[blk] = sc;
 }
 
+template <typename S>
 __global__ __launch_bounds__(BS) void k_backsubst_landmarks(
     EV ev, double lambda, const double* __restrict__ invHll, const double* __restrict__ bl,
-    const double* __restrict__ Hpl, const double* __restrict__ xp, double* __restrict__ xl,
+    const S* __restrict__ Hpl, const double* __restrict__ xp, double* __restrict__ xl,
     const double* __restrict__ lms_in, double* __restrict__ lms_out,
     double* __restrict__ partials, int nbl, double lambda_pose, const double* __restrict__ bp,
     const double* __restrict__ poses_in, double* __restrict__ poses_out)
@@ -847,14 +879,13 @@ __global__ __launch_bounds__(BS) void k_backsubst_landmarks(
     const int ebase = blockIdx.x * BS;
     const int e = ebase + t;
     { // stream the block's Hpl slots into LDS (zeros past the end)
-        const double2* src = reinterpret_cast<const double2*>(Hpl) + 9 * (size_t)ebase;
         const long nvalid = 9L * max(0, min(BS, ev.E - ebase));
         double2 v[9];
 #pragma unroll
         for (int i = 0; i < 9; i++)
         {
             const int idx = i * BS + t;
-            v[i] = src[min((long)idx, max(nvalid - 1, 0L))];
+            v[i] = ld_pair(Hpl, 9 * (size_t)ebase + (size_t)min((long)idx, max(nvalid - 1, 0L)));
         }
 #pragma unroll
         for (int i = 0; i < 9; i++)
@@ -966,22 +997,41 @@ void launch_edge_chi(hipStream_t s, const cugo_edges& e, const double* d_poses, 
                            Robust2{{rk.type, rk.delta}, {rk.type_stereo, rk.delta_stereo}}, d_chi_e);
 }
 
-void launch_build(hipStream_t s, const cugo_edges& e, const double* d_poses, const double* d_lms,
-                  cugo_robust rk, double* d_Hpp, double* d_bp, double* d_Hll, double* d_bl,
-                  double* d_Hpl, ReduceScratch rs, double* d_chi)
+// kernel templated on the block storage type S: the launch hook sees the plain kernel name
+#define CUGO_LAUNCH_T(kernel, S, grid, block, lds, stream, ...)                     \
+    do                                                                              \
+    {                                                                               \
+        ::cugo_k::LaunchScope _scope(#kernel, stream);                              \
+        hipLaunchKernelGGL(kernel<S>, grid, block, lds, stream, __VA_ARGS__);       \
+    } while (0)
+
+template <typename S>
+static void launch_build_t(hipStream_t s, const cugo_edges& e, const double* d_poses, const double* d_lms,
+                           cugo_robust rk, double* d_Hpp, double* d_bp, double* d_Hll, double* d_bl,
+                           S* d_Hpl, ReduceScratch rs, double* d_chi)
 {
     const EV ev = make_ev(e);
     const Robust2 r{{rk.type, rk.delta}, {rk.type_stereo, rk.delta_stereo}};
     const int nb = div_up(ev.E > ev.L ? ev.E : ev.L, BS); // also covers the edgeless landmarks
     double* d_rec = rs.d_partials + scratch_partials(ev.E, ev.P, ev.L);
     if (nb > 0)
-        CUGO_LAUNCH(k_build_edges, dim3(nb), dim3(BS), 0, s, ev, d_poses, d_lms, r, d_Hpl, d_Hll,
-                           d_bl, d_rec, rs.d_partials);
+        CUGO_LAUNCH_T(k_build_edges, S, dim3(nb), dim3(BS), 0, s, ev, d_poses, d_lms, r, d_Hpl, d_Hll,
+                      d_bl, d_rec, rs.d_partials);
     if (d_chi)
         CUGO_LAUNCH(k_sum_partials, dim3(1), dim3(BS), 0, s, rs.d_partials, nb, d_chi);
     if (ev.P > 0)
         CUGO_LAUNCH(k_build_poses, dim3(ev.P), dim3(BS),
                            (27 * RS + 32) * sizeof(double), s, ev, d_rec, d_Hpp, d_bp);
+}
+
+void launch_build(hipStream_t s, const cugo_edges& e, const double* d_poses, const double* d_lms,
+                  cugo_robust rk, double* d_Hpp, double* d_bp, double* d_Hll, double* d_bl,
+                  void* d_Hpl, ReduceScratch rs, double* d_chi)
+{
+    if (e.block_f32)
+        launch_build_t(s, e, d_poses, d_lms, rk, d_Hpp, d_bp, d_Hll, d_bl, static_cast<float*>(d_Hpl), rs, d_chi);
+    else
+        launch_build_t(s, e, d_poses, d_lms, rk, d_Hpp, d_bp, d_Hll, d_bl, static_cast<double*>(d_Hpl), rs, d_chi);
 }
 
 void launch_max_diagonal(hipStream_t s, const double* d_Hpp, int nP, const double* d_Hll, int nL,
@@ -997,37 +1047,66 @@ void launch_max_diagonal(hipStream_t s, const double* d_Hpp, int nP, const doubl
     CUGO_LAUNCH(k_max_partials, dim3(1), dim3(BS), 0, s, rs.d_partials, nb, d_out);
 }
 
-void launch_schur(hipStream_t s, const cugo_edges& e, const cugo_hsc_struct& hs, double lambda,
-                  int damp_hsc_diag, const double* d_Hpp, const double* d_bp, const double* d_Hll,
-                  const double* d_bl, const double* d_Hpl, double* d_invHll, double* d_T,
-                  double* d_bsc, double* d_Hsc)
+template <typename S>
+static void launch_schur_t(hipStream_t s, const cugo_edges& e, const cugo_hsc_struct& hs, double lambda,
+                           int damp_hsc_diag, const double* d_Hpp, const double* d_bp, const double* d_Hll,
+                           const double* d_bl, const S* d_Hpl, double* d_invHll, S* d_T,
+                           double* d_bsc, double* d_Hsc)
 {
     const EV ev = make_ev(e);
     if (ev.E > 0)
-        CUGO_LAUNCH(k_schur_edges, dim3(div_up(ev.E, BS)), dim3(BS), 0, s, ev, lambda, d_Hll,
-                           d_Hpl, d_invHll, d_T);
+        CUGO_LAUNCH_T(k_schur_edges, S, dim3(div_up(ev.E, BS)), dim3(BS), 0, s, ev, lambda, d_Hll,
+                      d_Hpl, d_invHll, d_T);
     if (hs.n_blocks > 0)
-        CUGO_LAUNCH(k_hsc_offdiag, dim3(div_up(hs.n_blocks, BS / 64)), dim3(BS), 0, s,
-                           hs.n_blocks, hs.d_off_ptr, hs.d_off_ei, hs.d_off_ej, d_Hpl, d_T, d_Hsc);
+        CUGO_LAUNCH_T(k_hsc_offdiag, S, dim3(div_up(hs.n_blocks, BS / 64)), dim3(BS), 0, s,
+                      hs.n_blocks, hs.d_off_ptr, hs.d_off_ei, hs.d_off_ej, d_Hpl, (const S*)d_T, d_Hsc);
     if (ev.P > 0)
-        CUGO_LAUNCH(k_hsc_diag, dim3(xcd_grid(ev.P)), dim3(HD_BS), 0, s, ev,
-                           hs.d_rowptr, damp_hsc_diag ? lambda : 0.0, d_Hpp, d_bp, d_bl, d_Hpl, d_T,
-                           d_Hsc, d_bsc);
+        CUGO_LAUNCH_T(k_hsc_diag, S, dim3(xcd_grid(ev.P)), dim3(HD_BS), 0, s, ev,
+                      hs.d_rowptr, damp_hsc_diag ? lambda : 0.0, d_Hpp, d_bp, d_bl, d_Hpl, (const S*)d_T,
+                      d_Hsc, d_bsc);
 }
 
-void launch_backsubst_update(hipStream_t s, const cugo_edges& e, double lambda, double lambda_pose,
-                             const double* d_invHll, const double* d_bl, const double* d_bp,
-                             const double* d_Hpl, const double* d_xp, double* d_xl,
-                             const double* d_poses_in, const double* d_lms_in, double* d_poses_out,
-                             double* d_lms_out, ReduceScratch rs, double* d_scale)
+void launch_schur(hipStream_t s, const cugo_edges& e, const cugo_hsc_struct& hs, double lambda,
+                  int damp_hsc_diag, const double* d_Hpp, const double* d_bp, const double* d_Hll,
+                  const double* d_bl, const void* d_Hpl, double* d_invHll, void* d_T,
+                  double* d_bsc, double* d_Hsc)
+{
+    if (e.block_f32)
+        launch_schur_t(s, e, hs, lambda, damp_hsc_diag, d_Hpp, d_bp, d_Hll, d_bl,
+                       static_cast<const float*>(d_Hpl), d_invHll, static_cast<float*>(d_T), d_bsc, d_Hsc);
+    else
+        launch_schur_t(s, e, hs, lambda, damp_hsc_diag, d_Hpp, d_bp, d_Hll, d_bl,
+                       static_cast<const double*>(d_Hpl), d_invHll, static_cast<double*>(d_T), d_bsc, d_Hsc);
+}
+
+template <typename S>
+static void launch_backsubst_update_t(hipStream_t s, const cugo_edges& e, double lambda, double lambda_pose,
+                                      const double* d_invHll, const double* d_bl, const double* d_bp,
+                                      const S* d_Hpl, const double* d_xp, double* d_xl,
+                                      const double* d_poses_in, const double* d_lms_in, double* d_poses_out,
+                                      double* d_lms_out, ReduceScratch rs, double* d_scale)
 {
     const EV ev = make_ev(e);
     const int nbl = div_up(ev.E > ev.L ? ev.E : ev.L, BS), nbp = div_up(ev.P, BS);
     if (nbl + nbp > 0)
-        CUGO_LAUNCH(k_backsubst_landmarks, dim3(nbl + nbp), dim3(BS), 0, s, ev, lambda, d_invHll,
-                           d_bl, d_Hpl, d_xp, d_xl, d_lms_in, d_lms_out, rs.d_partials, nbl,
-                           lambda_pose, d_bp, d_poses_in, d_poses_out);
+        CUGO_LAUNCH_T(k_backsubst_landmarks, S, dim3(nbl + nbp), dim3(BS), 0, s, ev, lambda, d_invHll,
+                      d_bl, d_Hpl, d_xp, d_xl, d_lms_in, d_lms_out, rs.d_partials, nbl,
+                      lambda_pose, d_bp, d_poses_in, d_poses_out);
     CUGO_LAUNCH(k_sum_partials, dim3(1), dim3(BS), 0, s, rs.d_partials, nbl + nbp, d_scale);
+}
+
+void launch_backsubst_update(hipStream_t s, const cugo_edges& e, double lambda, double lambda_pose,
+                             const double* d_invHll, const double* d_bl, const double* d_bp,
+                             const void* d_Hpl, const double* d_xp, double* d_xl,
+                             const double* d_poses_in, const double* d_lms_in, double* d_poses_out,
+                             double* d_lms_out, ReduceScratch rs, double* d_scale)
+{
+    if (e.block_f32)
+        launch_backsubst_update_t(s, e, lambda, lambda_pose, d_invHll, d_bl, d_bp, static_cast<const float*>(d_Hpl),
+                                  d_xp, d_xl, d_poses_in, d_lms_in, d_poses_out, d_lms_out, rs, d_scale);
+    else
+        launch_backsubst_update_t(s, e, lambda, lambda_pose, d_invHll, d_bl, d_bp, static_cast<const double*>(d_Hpl),
+                                  d_xp, d_xl, d_poses_in, d_lms_in, d_poses_out, d_lms_out, rs, d_scale);
 }
 
 } // namespace cugo_k

@@ -54,23 +54,24 @@ struct ReduceScratch
 void launch_errors(hipStream_t s, const cugo_edges& ev, const double* d_poses, const double* d_lms,
                    cugo_robust rk, ReduceScratch rs, double* d_chi);
 
+// d_Hpl / d_T below: double [E][18], or float [E][18] when ev.block_f32 is set
 void launch_build(hipStream_t s, const cugo_edges& ev, const double* d_poses, const double* d_lms,
                   cugo_robust rk, double* d_Hpp, double* d_bp, double* d_Hll, double* d_bl,
-                  double* d_Hpl, ReduceScratch rs, double* d_chi);
+                  void* d_Hpl, ReduceScratch rs, double* d_chi);
 
 void launch_max_diagonal(hipStream_t s, const double* d_Hpp, int nP, const double* d_Hll, int nL,
                          ReduceScratch rs, double* d_out);
 
 void launch_schur(hipStream_t s, const cugo_edges& ev, const cugo_hsc_struct& hs, double lambda,
                   int damp_hsc_diag, const double* d_Hpp, const double* d_bp, const double* d_Hll,
-                  const double* d_bl, const double* d_Hpl, double* d_invHll, double* d_T,
+                  const double* d_bl, const void* d_Hpl, double* d_invHll, void* d_T,
                   double* d_bsc, double* d_Hsc);
 
 // lambda_pose: damping used in the pose part of the scale sum (0 on ranks > 0 of a sharded run
 // so that the all-reduced scale counts lambda*|xp|^2 once)
 void launch_backsubst_update(hipStream_t s, const cugo_edges& ev, double lambda, double lambda_pose,
                              const double* d_invHll, const double* d_bl, const double* d_bp,
-                             const double* d_Hpl, const double* d_xp, double* d_xl,
+                             const void* d_Hpl, const double* d_xp, double* d_xl,
                              const double* d_poses_in, const double* d_lms_in, double* d_poses_out,
                              double* d_lms_out, ReduceScratch rs, double* d_scale);
 

@@ -130,6 +130,9 @@ public:
     /** HIP-event timing of kernel groups on the solver's stream (diagnostic; adds overhead) */
     void setKernelTiming(bool on);
     void kernelTimes(std::vector<std::string>& names, std::vector<double>& ms, std::vector<int>& launches) const;
+    /** GraphOptimisationOptions::useFloat32 after construction; takes effect at the next initialize() */
+    void setUseFloat32(bool on) { options.useFloat32 = on; }
+    bool useFloat32() const { return options.useFloat32; }
 
 private:
     bool verbose = false;

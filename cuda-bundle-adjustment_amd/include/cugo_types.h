@@ -137,6 +137,13 @@ struct CUGO_API GraphOptimisationOptions
 {
     bool perEdgeInformation = false; // per-edge weight vs one weight per edge set
     bool perEdgeCamera = false;      // per-edge camera vs one camera per edge set
+    // The reference's compile-time USE_FLOAT32 ("32bit float in internal floating-point
+    // operations", ref: CMakeLists.txt:8, src/scalar.h:24-28) as a run-time option: the two
+    // per-edge block streams Hpl and Hpl*Hll^-1 are stored as float (they are what the Schur
+    // kernels move: half the HBM traffic); estimates, Jacobians, every accumulator, Hsc and the
+    // Cholesky stay fp64.  chi2 per iteration then agrees with the fp64 run to ~1e-6 relative
+    // (tolerance stated and tested in tests/test_gpu.py::test_float32_block_storage).
+    bool useFloat32 = false;
 };
 
 enum class RobustKernelType

@@ -89,6 +89,12 @@ typedef struct cugo_edges
     const int32_t* d_lm_ptr;    /* [n_landmarks_total+1] */
     const int32_t* d_pose_ptr;  /* [n_poses_total+1]     */
     const int32_t* d_pose_edge; /* [E] edge ids grouped by pose, ascending landmark */
+    /* Element type of the two per-edge block arrays d_Hpl and d_T ([E][18] each) handed to
+     * cugo_construct_quadratic_form / cugo_compute_schur / cugo_backsubst_update:
+     * 0 = double, 1 = float (the fp32-internal mode, ref: the USE_FLOAT32 build option,
+     * CMakeLists.txt:8, src/scalar.h:24-28).  Only the storage of these two streams changes:
+     * every value is widened on load, all arithmetic and every other array stay fp64. */
+    int block_f32;
 } cugo_edges;
 
 typedef struct cugo_robust
@@ -110,11 +116,12 @@ int cugo_compute_active_errors(cugo_ctx* ctx, const cugo_edges* ev, const double
 /* ref: gpu::constructQuadraticForm_<2|3> (cuda_block_solver.h:159-176; .cu:1152-1220) plus
  * the four fillZero calls of BlockSolver::buildSystem (block_solver.cpp:287-294).
  * Outputs (all column-major blocks, reference layout):
- *   d_Hpp [Pfree][36], d_bp [Pfree][6], d_Hll [Lfree][9], d_bl [Lfree][3], d_Hpl [E][18].
+ *   d_Hpp [Pfree][36], d_bp [Pfree][6], d_Hll [Lfree][9], d_bl [Lfree][3], d_Hpl [E][18]
+ *   (d_Hpl and, below, d_T: double, or float when ev->block_f32).
  * Also writes chi2 at these estimates to d_chi[0] if d_chi != NULL. No atomics. */
 int cugo_construct_quadratic_form(cugo_ctx* ctx, const cugo_edges* ev, const double* d_poses,
                                   const double* d_lms, cugo_robust rk, double* d_Hpp,
-                                  double* d_bp, double* d_Hll, double* d_bl, double* d_Hpl,
+                                  double* d_bp, double* d_Hll, double* d_bl, void* d_Hpl,
                                   double* d_chi);
 
 /* ref: gpu::maxDiagonal x2 (cuda_block_solver.h:78-81; block_solver.cpp:309-320).
@@ -146,8 +153,8 @@ typedef struct cugo_hsc_struct
  *   damp_hsc_diag != 0, which reproduces the reference's damped Hsc exactly). */
 int cugo_compute_schur(cugo_ctx* ctx, const cugo_edges* ev, const cugo_hsc_struct* hs,
                        double lambda, int damp_hsc_diag, const double* d_Hpp, const double* d_bp,
-                       const double* d_Hll, const double* d_bl, const double* d_Hpl,
-                       double* d_invHll, double* d_T, double* d_bsc, double* d_Hsc);
+                       const double* d_Hll, const double* d_bl, const void* d_Hpl,
+                       double* d_invHll, void* d_T, double* d_bsc, double* d_Hsc);
 
 /* Sparse block LL^T of Hsc: replaces HscSparseLinearSolver / CuSparseCholeskySolver
  * (ref: src/cuda_linear_solver.cpp:27-57, src/cholesky.hpp:170-309 — cuSOLVER csrchol +
@@ -184,7 +191,7 @@ int cugo_chol_plan_array(cugo_chol* s, const char* name, const int32_t** out);
  * buffer swap).  d_scale[0] = sum_i x_i (lambda x_i + b_i) over [xp; xl]. */
 int cugo_backsubst_update(cugo_ctx* ctx, const cugo_edges* ev, double lambda,
                           const double* d_invHll, const double* d_bl, const double* d_bp,
-                          const double* d_Hpl, const double* d_xp, double* d_xl,
+                          const void* d_Hpl, const double* d_xp, double* d_xl,
                           const double* d_poses_in, const double* d_lms_in, double* d_poses_out,
                           double* d_lms_out, double* d_scale);
 
@@ -247,6 +254,10 @@ int cugo_graph_set_verbose(cugo_graph* g, int verbose);
 /* HIP-event timing of the kernel groups (build, errors, schur, cholesky, backsubst_update) on
  * the solver's own stream; diagnostic (adds event overhead). names: '\n' separated. */
 int cugo_graph_set_kernel_timing(cugo_graph* g, int on);
+/* fp32-internal mode (ref: the USE_FLOAT32 build option, CMakeLists.txt:8; here a run-time switch,
+ * GraphOptimisationOptions::useFloat32): float storage of the Hpl / Hpl*Hll^-1 block streams,
+ * everything else fp64.  Takes effect at the next cugo_graph_initialize(). */
+int cugo_graph_set_float32(cugo_graph* g, int on);
 int cugo_graph_kernel_times(cugo_graph* g, char* names_buf, int buf_len, double* ms,
                             int32_t* launches, int cap);
 /* device-to-device copy on the context stream (used by exchange callbacks) */

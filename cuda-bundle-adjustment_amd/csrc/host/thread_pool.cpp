@@ -21,25 +21,32 @@ namespace
 {
 
 // one parallel walk; workers hold a reference, so a worker that wakes up late finds its own
-// (exhausted) job and never touches the counters of the next one
+// (fully claimed) job and never touches the state of the next one
 struct Job
 {
     void (*fn)(void*, unsigned) = nullptr;
     void* ctx = nullptr;
     unsigned chunks = 0;
-    std::atomic<unsigned> next{0};
+    std::unique_ptr<std::atomic<uint8_t>[]> taken;
     std::atomic<unsigned> done{0};
 
-    void work()
+    // Thread `id` of `nthreads` first takes the chunks id, id + nthreads, ... — the same chunk
+    // goes to the same thread in every walk, so what a thread touched in one walk (the vertex
+    // objects of a landmark range, say) is still in its core's cache in the next — and then
+    // whatever nobody has claimed yet (a worker that wakes up late delays nothing).
+    void work(unsigned id, unsigned nthreads)
     {
-        for (;;)
-        {
-            const unsigned c = next.fetch_add(1, std::memory_order_acq_rel);
-            if (c >= chunks)
-                return;
-            fn(ctx, c);
-            done.fetch_add(1, std::memory_order_acq_rel);
-        }
+        for (unsigned c = id; c < chunks; c += nthreads)
+            run(c);
+        for (unsigned c = 0; c < chunks; c++)
+            run(c);
+    }
+    void run(unsigned c)
+    {
+        if (taken[c].load(std::memory_order_relaxed) || taken[c].exchange(1, std::memory_order_acq_rel))
+            return;
+        fn(ctx, c);
+        done.fetch_add(1, std::memory_order_acq_rel);
     }
 };
 
@@ -54,7 +61,7 @@ struct Pool
     std::atomic<uint64_t> gen_hint{0}; // lock-free copy of `generation` for the short spin
     bool stop = false;
 
-    void worker_main()
+    void worker_main(unsigned id, unsigned nthreads)
     {
         uint64_t seen = 0;
         for (;;)
@@ -74,7 +81,7 @@ struct Pool
                 seen = generation;
                 job = current;
             }
-            job->work();
+            job->work(id, nthreads);
         }
     }
 };
@@ -93,7 +100,7 @@ void create_pool()
     g_pool = new Pool;
     const unsigned n = wanted_threads();
     for (unsigned t = 1; t < n; t++)
-        g_pool->workers.emplace_back([p = g_pool] { p->worker_main(); });
+        g_pool->workers.emplace_back([p = g_pool, t, n] { p->worker_main(t, n); });
     // a forked child has no worker threads: it runs every job in the calling thread
     pthread_atfork(nullptr, nullptr, [] { g_forked.store(true); });
 }
@@ -120,6 +127,9 @@ void pool_run(unsigned chunks, void (*fn)(void*, unsigned), void* ctx)
     std::lock_guard<std::mutex> run(p.run_mutex);
     auto job = std::make_shared<Job>();
     job->fn = fn, job->ctx = ctx, job->chunks = chunks;
+    job->taken.reset(new std::atomic<uint8_t>[chunks]);
+    for (unsigned c = 0; c < chunks; c++)
+        job->taken[c].store(0, std::memory_order_relaxed);
     {
         std::lock_guard<std::mutex> lk(p.m);
         p.current = job;
@@ -127,7 +137,7 @@ void pool_run(unsigned chunks, void (*fn)(void*, unsigned), void* ctx)
         p.gen_hint.store(p.generation, std::memory_order_release);
     }
     p.cv_work.notify_all();
-    job->work();
+    job->work(0, wanted_threads());
     while (job->done.load(std::memory_order_acquire) < chunks)
         std::this_thread::yield();
 }

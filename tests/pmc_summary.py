@@ -6,7 +6,7 @@ for d in sys.argv[1:]:
         print(d, "no counter file"); continue
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f[0])):
-        n = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0]
+        n = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '').split('<')[0]
         acc[n][r['Counter_Name']].append(float(r['Counter_Value']))
     print("==", d)
     for n, cs in sorted(acc.items()):

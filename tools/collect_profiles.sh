@@ -9,7 +9,8 @@ cp "$(ls -t gpurun_out/prof_r01/runc/*_kernel_stats.csv | head -1)" profiles/r01
 python - <<'PY'
 import json
 for src, dst in (("gpurun_out/bench_kitti00.json", "profiles/r01_bench_kitti00.json"),
-                 ("gpurun_out/bench_synth10k.json", "profiles/r01_bench_synth10k_1gpu.json")):
+                 ("gpurun_out/bench_synth10k.json", "profiles/r01_bench_synth10k_1gpu.json"),
+                 ("gpurun_out/bench_kitti00_float32.json", "profiles/r01_bench_kitti00_float32.json")):
     line = [l for l in open(src) if l.startswith("{")][-1]
     json.dump(json.loads(line), open(dst, "w"), indent=1)
 d = json.load(open("profiles/r01_bench_kitti00.json"))

@@ -19,6 +19,7 @@ def per_kernel(d, counter):
         if r["Counter_Name"] != counter:
             continue
         n = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
+        n = n.replace("void ", "").split("<")[0]  # k_foo<double> / k_foo<float> -> k_foo
         acc[n].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}
 

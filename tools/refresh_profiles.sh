@@ -10,3 +10,4 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python tests/pmc_summary.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE > gpurun_out/pmc_summary.txt 2>&1
 tail -2 gpurun_out/gpu_tests.log
+timeout -k 10 300 python bench.py --steps 10 --warmup 2 --float32 > gpurun_out/bench_kitti00_float32.json 2> gpurun_out/bench_kitti00_float32.err

@@ -155,14 +155,23 @@ __device__ __forceinline__ EdgeIn load_edge(const EV& ev, int e, uint8_t fl)
 }
 
 // ---------------------------------------------------------------- reductions -----------
-__global__ __launch_bounds__(BS) void k_sum_partials(const double* __restrict__ part, int n,
-                                                     double* __restrict__ out)
+// one workgroup, fixed order: four partial sums per thread (four loads in flight), then the
+// block tree.  1024 threads: the 5M-edge graph has 19.5k partials per pass
+constexpr int SP_BS = 1024;
+__global__ __launch_bounds__(SP_BS) void k_sum_partials(const double* __restrict__ part, int n,
+                                                        double* __restrict__ out)
 {
-    __shared__ double sm[BS / 64];
-    double v = 0;
-    for (int i = threadIdx.x; i < n; i += BS)
-        v += part[i];
-    v = block_sum(v, sm);
+    __shared__ double sm[SP_BS / 64];
+    double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+    int i = threadIdx.x;
+    for (; i + 3 * SP_BS < n; i += 4 * SP_BS)
+    {
+        const double a = part[i], b = part[i + SP_BS], c = part[i + 2 * SP_BS], d = part[i + 3 * SP_BS];
+        v0 += a, v1 += b, v2 += c, v3 += d;
+    }
+    for (; i < n; i += SP_BS)
+        v0 += part[i];
+    const double v = block_sum((v0 + v1) + (v2 + v3), sm);
     if (threadIdx.x == 0)
         out[0] = v;
 }
@@ -984,7 +993,7 @@ void launch_errors(hipStream_t s, const cugo_edges& e, const double* d_poses, co
     if (nb > 0)
         CUGO_LAUNCH(k_errors, dim3(nb), dim3(BS), 0, s, ev, d_poses, d_lms,
                            Robust2{{rk.type, rk.delta}, {rk.type_stereo, rk.delta_stereo}}, rs.d_partials);
-    CUGO_LAUNCH(k_sum_partials, dim3(1), dim3(BS), 0, s, rs.d_partials, nb, d_chi);
+    CUGO_LAUNCH(k_sum_partials, dim3(1), dim3(SP_BS), 0, s, rs.d_partials, nb, d_chi);
 }
 
 void launch_edge_chi(hipStream_t s, const cugo_edges& e, const double* d_poses, const double* d_lms,
@@ -1018,7 +1027,7 @@ static void launch_build_t(hipStream_t s, const cugo_edges& e, const double* d_p
         CUGO_LAUNCH_T(k_build_edges, S, dim3(nb), dim3(BS), 0, s, ev, d_poses, d_lms, r, d_Hpl, d_Hll,
                       d_bl, d_rec, rs.d_partials);
     if (d_chi)
-        CUGO_LAUNCH(k_sum_partials, dim3(1), dim3(BS), 0, s, rs.d_partials, nb, d_chi);
+        CUGO_LAUNCH(k_sum_partials, dim3(1), dim3(SP_BS), 0, s, rs.d_partials, nb, d_chi);
     if (ev.P > 0)
         CUGO_LAUNCH(k_build_poses, dim3(ev.P), dim3(BS),
                            (27 * RS + 32) * sizeof(double), s, ev, d_rec, d_Hpp, d_bp);
@@ -1092,7 +1101,7 @@ static void launch_backsubst_update_t(hipStream_t s, const cugo_edges& e, double
         CUGO_LAUNCH_T(k_backsubst_landmarks, S, dim3(nbl + nbp), dim3(BS), 0, s, ev, lambda, d_invHll,
                       d_bl, d_Hpl, d_xp, d_xl, d_lms_in, d_lms_out, rs.d_partials, nbl,
                       lambda_pose, d_bp, d_poses_in, d_poses_out);
-    CUGO_LAUNCH(k_sum_partials, dim3(1), dim3(BS), 0, s, rs.d_partials, nbl + nbp, d_scale);
+    CUGO_LAUNCH(k_sum_partials, dim3(1), dim3(SP_BS), 0, s, rs.d_partials, nbl + nbp, d_scale);
 }
 
 void launch_backsubst_update(hipStream_t s, const cugo_edges& e, double lambda, double lambda_pose,

@@ -288,10 +288,18 @@ __global__ __launch_bounds__(BS) void k_build_edges(EV ev, const double* __restr
                                                     double* __restrict__ partials)
 {
     __shared__ double sm[BS / 64];
-    __shared__ double cs[9][BS];
-    __shared__ double rs_[BS * 9]; // per-edge records, 9-double lane stride: conflict-free both ways
+    // 36 KB used twice: first the landmark contributions cs[9][BS] and the per-edge records
+    // rs_[BS*9] (9-double lane stride: conflict-free both ways), at the end the block's 256 Hpl
+    // blocks on their way to coalesced stores
+    __shared__ double2 pool2[BS * 9 + 1];
+    double(*cs)[BS] = reinterpret_cast<double(*)[BS]>(pool2);
+    double* rs_ = reinterpret_cast<double*>(pool2) + 9 * BS;
     const int e = blockIdx.x * BS + threadIdx.x;
     double chi = 0;
+    double H[18];
+#pragma unroll
+    for (int i = 0; i < 18; i++)
+        H[i] = 0;
     LmContrib lc = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     int l = -1;
     // record for the pose pass (k_build_poses): Xc, e, w and {camera index, stereo bit}; w = 0 for
@@ -301,10 +309,6 @@ __global__ __launch_bounds__(BS) void k_build_edges(EV ev, const double* __restr
     {
         const uint8_t fl = ev.flags[e];
         l = ev.lm[e];
-        double H[18];
-#pragma unroll
-        for (int i = 0; i < 18; i++)
-            H[i] = 0;
         if (!(fl & CUGO_EDGE_INACTIVE))
         {
             const EdgeIn in = load_edge(ev, e, fl);
@@ -336,9 +340,6 @@ __global__ __launch_bounds__(BS) void k_build_edges(EV ev, const double* __restr
                     }
             }
         }
-#pragma unroll
-        for (int i = 0; i < 9; i++)
-            st_pair(Hpl, 9 * (size_t)e + i, H[2 * i], H[2 * i + 1]);
     }
     {
         const int t = threadIdx.x;
@@ -403,6 +404,30 @@ __global__ __launch_bounds__(BS) void k_build_edges(EV ev, const double* __restr
         for (int i = 0; i < 9; i++)
             H[i] = 0;
         bl[3 * (size_t)e] = 0, bl[3 * (size_t)e + 1] = 0, bl[3 * (size_t)e + 2] = 0;
+    }
+    // ---- Hpl blocks of the block's 256 slots -> global through LDS: a lane storing its own
+    // 144 bytes (9 stores at a 144-B stride) touches 64 cache lines per store instruction
+    __syncthreads(); // cs / rs_ are no longer read
+    {
+        double* mine = reinterpret_cast<double*>(pool2) + 18 * threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < 18; i++)
+            mine[i] = H[i];
+    }
+    __syncthreads();
+    {
+        const int ebase = blockIdx.x * BS;
+        const long nvalid = 9L * max(0, min(BS, ev.E - ebase));
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+        {
+            const int idx = i * BS + threadIdx.x;
+            if (idx < nvalid)
+            {
+                const double2 v = pool2[idx];
+                st_pair(Hpl, 9 * (size_t)ebase + idx, v.x, v.y);
+            }
+        }
     }
 }
 
@@ -566,6 +591,10 @@ __global__ __launch_bounds__(BS) void k_max_diag(const double* __restrict__ Hpp,
 // ---------------------------------------------------------------- Schur: edges ---------
 // invHll = (Hll + lambda I)^-1 (written by the landmark's first edge lane),
 // T[e] = Hpl[e] * invHll   (ref: computeBschureKernel .cu:1286-1314, lane per edge)
+// The 256 Hpl blocks of a workgroup (36 KB, contiguous) go through LDS: coalesced 16-B loads in,
+// lane e works on its own 18 values in place, coalesced stores of T out.  A lane reading its
+// block straight from memory (9 loads at a 144-B stride) makes every load instruction touch 64
+// cache lines; the vector memory path, not HBM, then sets the pace.
 template <typename S>
 __global__ __launch_bounds__(BS) void k_schur_edges(EV ev, double lambda,
                                                     const double* __restrict__ Hll,
@@ -573,42 +602,69 @@ __global__ __launch_bounds__(BS) void k_schur_edges(EV ev, double lambda,
                                                     double* __restrict__ invHll,
                                                     S* __restrict__ T)
 {
-    const int e = blockIdx.x * BS + threadIdx.x;
-    if (e >= ev.E)
-        return;
-    const int l = ev.lm[e];
-    if (l >= ev.L)
-        return; // fixed landmark: no Hll block
-    const Sym3 iv = sym3_inv(Hll + 9 * (size_t)l, lambda);
-    if (e == ev.lm_ptr[l])
+    __shared__ double2 hs[BS * 9 + 1];
+    const int t = threadIdx.x;
+    const int ebase = blockIdx.x * BS;
+    const int e = ebase + t;
+    const long nvalid = 9L * max(0, min(BS, ev.E - ebase)); // pairs of this block that exist
     {
-        double* o = invHll + 9 * (size_t)l;
-        o[0] = iv.b00, o[1] = iv.b01, o[2] = iv.b02;
-        o[3] = iv.b01, o[4] = iv.b11, o[5] = iv.b12;
-        o[6] = iv.b02, o[7] = iv.b12, o[8] = iv.b22;
+        double2 v[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+        {
+            const int idx = i * BS + t;
+            v[i] = ld_pair(Hpl, 9 * (size_t)ebase + (size_t)min((long)idx, max(nvalid - 1, 0L)));
+        }
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+            hs[i * BS + t] = v[i];
     }
-    const uint8_t fl = ev.flags[e];
-    if (fl & (CUGO_EDGE_FIXED_L | CUGO_EDGE_FIXED_P | CUGO_EDGE_INACTIVE))
-        return;
-    double H[18];
+    bool act = false;
+    Sym3 iv = {0, 0, 0, 0, 0, 0};
+    if (e < ev.E)
+    {
+        const int l = ev.lm[e];
+        if (l < ev.L) // fixed landmark: no Hll block
+        {
+            iv = sym3_inv(Hll + 9 * (size_t)l, lambda);
+            if (e == ev.lm_ptr[l])
+            {
+                double* o = invHll + 9 * (size_t)l;
+                o[0] = iv.b00, o[1] = iv.b01, o[2] = iv.b02;
+                o[3] = iv.b01, o[4] = iv.b11, o[5] = iv.b12;
+                o[6] = iv.b02, o[7] = iv.b12, o[8] = iv.b22;
+            }
+            act = !(ev.flags[e] & (CUGO_EDGE_FIXED_L | CUGO_EDGE_FIXED_P | CUGO_EDGE_INACTIVE));
+        }
+    }
+    __syncthreads();
+    {
+        double* H = reinterpret_cast<double*>(hs) + 18 * t; // this lane's block, overwritten by T
+        double Tt[18];
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+        {
+            const double a = H[r], b = H[6 + r], c = H[12 + r];
+            Tt[r] = a * iv.b00 + b * iv.b01 + c * iv.b02;
+            Tt[6 + r] = a * iv.b01 + b * iv.b11 + c * iv.b12;
+            Tt[12 + r] = a * iv.b02 + b * iv.b12 + c * iv.b22;
+        }
+        // edges without a T block (fixed endpoint, padding) store zeros: nothing reads them
+#pragma unroll
+        for (int i = 0; i < 18; i++)
+            H[i] = act ? Tt[i] : 0.0;
+    }
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < 9; i++)
     {
-        const double2 v = ld_pair(Hpl, 9 * (size_t)e + i);
-        H[2 * i] = v.x, H[2 * i + 1] = v.y;
+        const int idx = i * BS + t;
+        if (idx < nvalid)
+        {
+            const double2 v = hs[idx];
+            st_pair(T, 9 * (size_t)ebase + idx, v.x, v.y);
+        }
     }
-    double Tt[18];
-#pragma unroll
-    for (int r = 0; r < 6; r++)
-    {
-        const double a = H[r], b = H[6 + r], c = H[12 + r];
-        Tt[r] = a * iv.b00 + b * iv.b01 + c * iv.b02;
-        Tt[6 + r] = a * iv.b01 + b * iv.b11 + c * iv.b12;
-        Tt[12 + r] = a * iv.b02 + b * iv.b12 + c * iv.b22;
-    }
-#pragma unroll
-    for (int i = 0; i < 9; i++)
-        st_pair(T, 9 * (size_t)e + i, Tt[2 * i], Tt[2 * i + 1]);
 }
 
 // ---------------------------------------------------------------- Schur: diagonal ------

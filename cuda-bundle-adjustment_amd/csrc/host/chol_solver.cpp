@@ -76,9 +76,8 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
         CUGO_HIP(hipMemset(d_stamps, 0, 64 * sizeof(long long)));
         cugo_k::set_debug_stamps(d_stamps);
     }
-    CUGO_HIP(hipMemsetAsync(d_fail, 0, sizeof(int32_t), s));
     cugo_k::launch_chol_assemble(s, dev, d_fronts.data(), (size_t)plan.front_doubles, d_Hsc, lambda,
-                                 d_bsc);
+                                 d_bsc, d_fail, false);
     for (int st = 0; st < plan.n_stages; st++)
     {
         const int t0 = plan.stage_task_ptr[st], t1 = plan.stage_task_ptr[st + 1];

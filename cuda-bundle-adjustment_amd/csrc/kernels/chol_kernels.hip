@@ -74,9 +74,12 @@ __global__ __launch_bounds__(CBS) void k_assemble_blocks(CholPlanDev p, double* 
 }
 
 __global__ __launch_bounds__(CBS) void k_assemble_rhs(CholPlanDev p, double* __restrict__ fronts,
-                                                      const double* __restrict__ bsc)
+                                                      const double* __restrict__ bsc,
+                                                      int32_t* __restrict__ fail)
 {
     const int j = blockIdx.x * CBS + threadIdx.x;
+    if (j == 0)
+        *fail = 0; // the zero-pivot flag of this factorisation (a 4-byte memset is a 4 us launch)
     if (j >= 6 * p.n)
         return;
     const int jb = j / 6, comp = j % 6;
@@ -1287,16 +1290,16 @@ void set_debug_stamps(long long* d_buf)
 
 void launch_chol_assemble(hipStream_t s, const CholPlanDev& p, double* d_fronts,
                           size_t front_doubles, const double* d_Hsc, double lambda,
-                          const double* d_bsc)
+                          const double* d_bsc, int32_t* d_fail, bool fronts_are_zero)
 {
-    (void)hipMemsetAsync(d_fronts, 0, front_doubles * sizeof(double), s);
+    if (!fronts_are_zero)
+        (void)hipMemsetAsync(d_fronts, 0, front_doubles * sizeof(double), s);
     const long n = 36L * p.n_hsc_blocks;
     if (n > 0)
         CUGO_LAUNCH(k_assemble_blocks, dim3((unsigned)((n + CBS - 1) / CBS)), dim3(CBS), 0, s,
                            p, d_fronts, d_Hsc, lambda);
-    if (p.n > 0)
-        CUGO_LAUNCH(k_assemble_rhs, dim3((6 * p.n + CBS - 1) / CBS), dim3(CBS), 0, s, p,
-                           d_fronts, d_bsc);
+    CUGO_LAUNCH(k_assemble_rhs, dim3(std::max(1, (6 * p.n + CBS - 1) / CBS)), dim3(CBS), 0, s, p,
+                       d_fronts, d_bsc, d_fail);
 }
 
 void launch_chol_subtree_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,

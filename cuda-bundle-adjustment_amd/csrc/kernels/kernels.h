@@ -126,8 +126,10 @@ struct CholPlanDev
     double* junk;              // 64 x 1024 doubles
 };
 
+// also resets *d_fail; fronts_are_zero: the caller has already cleared d_fronts
 void launch_chol_assemble(hipStream_t s, const CholPlanDev& p, double* d_fronts, size_t front_doubles,
-                          const double* d_Hsc, double lambda, const double* d_bsc);
+                          const double* d_Hsc, double lambda, const double* d_bsc, int32_t* d_fail,
+                          bool fronts_are_zero);
 void launch_chol_subtree_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,
                                int ntasks, size_t lds_bytes, int32_t* d_fail);
 // one etree level: extend-add(pivot columns) / potrf (+ extend-add of the boundary columns) /

@@ -35,6 +35,8 @@ WORKLOADS = {
     "kitti00": (1322, 133383, 561116, 0, 4000, 0.7),
     "kitti07": (248, 26127, 95037, 7, 500, 0.7),
     "synth10k": (10000, 1000000, 5000000, 10000, 0, 0.0),
+    # ORB-SLAM2-style local BA window (launch-latency regime; not a BASELINE config)
+    "localba": (30, 3000, 12600, 30, 0, 0.7),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_PEAK_TFLOPS = 78.6    # MI355X fp64 vector / matrix peak

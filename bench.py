@@ -195,7 +195,6 @@ def main():
         "k_up_potrf": ("mfma", sstats.get("up_potrf_flops", 0.0), n_fact),
         # fused trsm + syrk tiles: algorithmic flops (each L21 row tile counted once)
         "k_up_trsyrk": ("mfma", sstats.get("up_trsm_flops", 0.0) + sstats.get("up_syrk_flops", 0.0), n_fact),
-        "k_up_extend_add": ("hbm", sstats.get("up_ea_bytes", 0.0), n_fact),
         "k_backward_stage": ("hbm", sstats.get("backward_bytes", 0.0), n_fact),
     }
     groups, kernels = {}, {}

@@ -8,16 +8,16 @@
 //   front F = [ pivot block columns | boundary block rows | 1 rhs row ]   dense, column-major
 //
 //   stage 0 (optional)  : whole bottom subtrees, one workgroup per subtree, fronts in postorder
-//                         (only when there are >= 64 of them; k_subtree_factor)
-//   upper stages        : one etree level per stage, three batched kernels per level so that a
+//                         (off by default, CUGO_MIN_SUBTREE_TASKS=0 enables it; k_subtree_factor)
+//   upper stages        : one etree level per stage, two batched kernels per level so that a
 //                         big front is spread over many workgroups (256 CUs / 8 XCDs):
-//        k_up_extend_add  children update matrices -> pivot columns of the parents
-//        k_up_potrf       L11 = chol(F11) in LDS, then W = L11^-1 on the matrix cores
-//                         (1 workgroup / front; extra workgroups of the same launch do the
-//                         extend-add of the boundary columns)
+//        k_up_potrf       1 workgroup / front: extend-add of the children into F11, L11 = chol(F11)
+//                         in LDS, then W = L11^-1 on the matrix cores; extra workgroups of the
+//                         same launch do the extend-add of everything below F11
 //        k_up_trsyrk      per 64x64 tile of the update matrix: X = B W^T for its two L21 row
 //                         tiles, U -= X_i X_j^T, all v_mfma_f64_16x16x4_f64
-//   backward            : k_backward_stage per level, x_J = W^T (y_J - L21^T x_R): two mat-vecs
+//   backward            : k_backward_stage per level, x_J = W^T (y_J - L21^T x_R): two mat-vecs;
+//                         the ancestor part of L21^T x_R is done one launch ahead (extra workgroups)
 //
 // The right-hand side rides along as the last row of every front, so L y = b is a by-product
 // of the factorisation (y ends in the rhs row of the pivot columns); only the backward

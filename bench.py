@@ -94,8 +94,12 @@ def main():
             self.__cuda_array_interface__ = {"data": (int(ptr), False), "shape": (int(n),),
                                              "typestr": "<f8", "version": 2}
 
+    views = {}  # (address, length) -> zero-copy tensor view: the solver re-uses the same buffers every trial
+
     def exchange(ptr, n, op):
-        t = torch.as_tensor(_DevPtr(ptr, n), device=dev)
+        t = views.get((ptr, n))
+        if t is None:
+            t = views[(ptr, n)] = torch.as_tensor(_DevPtr(ptr, n), device=dev)
         rop = dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX
         if args.backend == "nccl":
             dist.all_reduce(t, op=rop)

@@ -214,7 +214,7 @@ Engine::Engine() : impl_(new Impl)
     int dev = 0;
     CUGO_HIP(hipGetDevice(&dev));
     impl_->ctx.device = dev;
-    CUGO_HIP(hipStreamCreateWithFlags(&impl_->ctx.stream, hipStreamNonBlocking));
+    impl_->ctx.stream = cache_stream_acquire();
     impl_->chol.ctx = &impl_->ctx;
     impl_->profile = std::getenv("CUGO_PROFILE") != nullptr;
 }
@@ -225,12 +225,11 @@ Engine::~Engine()
     {
         if (cugo_k::launch_hook() == impl_)
             cugo_k::set_launch_hook(nullptr);
-        if (impl_->ctx.stream)
-        {
-            (void)hipStreamSynchronize(impl_->ctx.stream);
-            (void)hipStreamDestroy(impl_->ctx.stream);
-        }
+        hipStream_t s = impl_->ctx.stream;
+        if (s)
+            (void)hipStreamSynchronize(s);
         delete impl_;
+        cache_stream_release(s); // back to the process-wide pool: creating one costs 1-2 ms
     }
 }
 

@@ -35,6 +35,12 @@ struct HipError : std::runtime_error
             throw ::cugo_host::HipError(_e, #expr, __FILE__, __LINE__);                  \
     } while (0)
 
+// device_cache.cpp: cached hipMalloc / hipHostMalloc (blocks are recycled, not returned to the driver)
+void* cache_alloc(size_t bytes, bool pinned, size_t* got_bytes);
+void cache_free(void* p);
+hipStream_t cache_stream_acquire(); // a non-blocking stream of the current device
+void cache_stream_release(hipStream_t s); // the stream must be idle
+
 template <typename T>
 class DevBuf
 {
@@ -46,21 +52,21 @@ public:
     void release()
     {
         if (p_)
-            (void)hipFree(p_);
+            cache_free(p_);
         p_ = nullptr;
         cap_ = n_ = 0;
     }
-    // grow-only; contents are NOT preserved
+    // grow-only; contents are NOT preserved (and a fresh buffer is NOT zeroed)
     void resize(size_t n)
     {
         if (n > cap_)
         {
             if (p_)
-                (void)hipFree(p_);
+                cache_free(p_);
             p_ = nullptr;
-            const size_t want = n + n / 8 + 16;
-            CUGO_HIP(hipMalloc(reinterpret_cast<void**>(&p_), want * sizeof(T)));
-            cap_ = want;
+            size_t got = 0;
+            p_ = static_cast<T*>(cache_alloc((n + 16) * sizeof(T), false, &got));
+            cap_ = got / sizeof(T);
         }
         n_ = n;
     }
@@ -94,17 +100,18 @@ public:
     ~PinnedBuf()
     {
         if (p_)
-            (void)hipHostFree(p_);
+            cache_free(p_);
     }
     void resize(size_t n)
     {
         if (n > cap_)
         {
             if (p_)
-                (void)hipHostFree(p_);
+                cache_free(p_);
             p_ = nullptr;
-            CUGO_HIP(hipHostMalloc(reinterpret_cast<void**>(&p_), (n + 16) * sizeof(T), hipHostMallocDefault));
-            cap_ = n + 16;
+            size_t got = 0;
+            p_ = static_cast<T*>(cache_alloc((n + 16) * sizeof(T), true, &got));
+            cap_ = got / sizeof(T);
         }
         n_ = n;
     }

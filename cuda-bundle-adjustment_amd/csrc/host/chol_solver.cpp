@@ -12,17 +12,36 @@ using namespace cugo_host;
 void cugo_chol::upload(hipStream_t s)
 {
     const CholPlan& P = plan;
-    d_ncb.upload(P.ncb, s), d_nb.upload(P.nb, s), d_off.upload(P.off, s), d_col0.upload(P.col0, s);
-    d_woff.upload(P.woff, s), d_l21off.upload(P.l21off, s), d_ldf.upload(P.ldf, s);
-    d_alias_of.upload(P.alias_of, s), d_bw_np.upload(P.bw_np, s);
-    d_rows_ptr.upload(P.rows_ptr, s), d_rows.upload(P.rows, s);
-    d_child_ptr.upload(P.child_ptr, s), d_child.upload(P.child, s);
-    d_rel_ptr.upload(P.rel_ptr, s), d_rel.upload(P.rel, s);
-    d_task_ptr.upload(P.task_ptr, s), d_task_fronts.upload(P.task_fronts, s);
-    d_blk_front.upload(P.blk_front, s), d_blk_row.upload(P.blk_row, s);
-    d_blk_col.upload(P.blk_col, s), d_blk_trans.upload(P.blk_trans, s);
-    d_perm.upload(P.perm, s), d_col_front.upload(P.col_front, s);
-    d_wl.upload(P.wl, s);
+    // All index arrays of the plan travel in TWO host-to-device copies (a pageable copy costs
+    // ~20 us whatever its size, and there are 23 arrays: 0.4 ms of a cold call on a small graph)
+    std::vector<int32_t> pack32;
+    std::vector<int64_t> pack64;
+    auto put32 = [&pack32](const std::vector<int32_t>& v) {
+        const size_t o = pack32.size();
+        pack32.insert(pack32.end(), v.begin(), v.end());
+        pack32.resize((pack32.size() + 3) & ~size_t(3)); // keep every array 16-byte aligned
+        return o;
+    };
+    auto put64 = [&pack64](const std::vector<int64_t>& v) {
+        const size_t o = pack64.size();
+        pack64.insert(pack64.end(), v.begin(), v.end());
+        pack64.resize((pack64.size() + 1) & ~size_t(1));
+        return o;
+    };
+    const size_t o_ncb = put32(P.ncb), o_nb = put32(P.nb), o_col0 = put32(P.col0);
+    const size_t o_alias = put32(P.alias_of), o_bwnp = put32(P.bw_np);
+    const size_t o_rows_ptr = put32(P.rows_ptr), o_rows = put32(P.rows);
+    const size_t o_child_ptr = put32(P.child_ptr), o_child = put32(P.child);
+    const size_t o_rel_ptr = put32(P.rel_ptr), o_rel = put32(P.rel);
+    const size_t o_task_ptr = put32(P.task_ptr), o_task_fronts = put32(P.task_fronts);
+    const size_t o_blk_front = put32(P.blk_front), o_blk_row = put32(P.blk_row), o_blk_col = put32(P.blk_col);
+    const size_t o_perm = put32(P.perm), o_col_front = put32(P.col_front), o_wl = put32(P.wl);
+    const size_t o_trans = pack32.size(); // bytes
+    pack32.resize(o_trans + (P.blk_trans.size() + 3) / 4 + 4, 0);
+    if (!P.blk_trans.empty())
+        std::memcpy(pack32.data() + o_trans, P.blk_trans.data(), P.blk_trans.size());
+    const size_t o_off = put64(P.off), o_woff = put64(P.woff), o_l21off = put64(P.l21off), o_ldf = put64(P.ldf);
+    d_pack32.upload(pack32, s), d_pack64.upload(pack64, s);
     d_fronts.resize((size_t)P.front_doubles + 16);
     d_xnew.resize((size_t)6 * P.n + 16);
     d_junk.resize(64 * 1024);
@@ -32,20 +51,23 @@ void cugo_chol::upload(hipStream_t s)
 
     cugo_k::CholPlanDev& D = dev;
     D.n_fronts = P.n_super;
-    D.ncb = d_ncb.data(), D.nb = d_nb.data(), D.off = d_off.data(), D.col0 = d_col0.data();
-    D.rows_ptr = d_rows_ptr.data(), D.rows = d_rows.data();
-    D.child_ptr = d_child_ptr.data(), D.child = d_child.data();
-    D.rel_ptr = d_rel_ptr.data(), D.rel = d_rel.data();
+    const int32_t* b32 = d_pack32.data();
+    const int64_t* b64 = d_pack64.data();
+    D.ncb = b32 + o_ncb, D.nb = b32 + o_nb, D.off = b64 + o_off, D.col0 = b32 + o_col0;
+    D.rows_ptr = b32 + o_rows_ptr, D.rows = b32 + o_rows;
+    D.child_ptr = b32 + o_child_ptr, D.child = b32 + o_child;
+    D.rel_ptr = b32 + o_rel_ptr, D.rel = b32 + o_rel;
     D.n_stages = P.n_stages;
-    D.task_ptr = d_task_ptr.data(), D.task_fronts = d_task_fronts.data();
+    D.task_ptr = b32 + o_task_ptr, D.task_fronts = b32 + o_task_fronts;
     D.n_hsc_blocks = (int)P.blk_front.size();
-    D.blk_front = d_blk_front.data(), D.blk_row = d_blk_row.data();
-    D.blk_col = d_blk_col.data(), D.blk_trans = d_blk_trans.data();
-    D.n = P.n, D.perm = d_perm.data(), D.col_front = d_col_front.data();
+    D.blk_front = b32 + o_blk_front, D.blk_row = b32 + o_blk_row;
+    D.blk_col = b32 + o_blk_col, D.blk_trans = reinterpret_cast<const uint8_t*>(b32 + o_trans);
+    D.n = P.n, D.perm = b32 + o_perm, D.col_front = b32 + o_col_front;
     D.junk = d_junk.data();
-    D.woff = d_woff.data(), D.winv = d_winv.data(), D.nc_max = P.nc_max;
-    D.l21off = d_l21off.data(), D.l21 = d_l21.data();
-    D.ldf = d_ldf.data(), D.alias_of = d_alias_of.data(), D.bw_np = d_bw_np.data();
+    D.woff = b64 + o_woff, D.winv = d_winv.data(), D.nc_max = P.nc_max;
+    D.l21off = b64 + o_l21off, D.l21 = d_l21.data();
+    D.ldf = b64 + o_ldf, D.alias_of = b32 + o_alias, D.bw_np = b32 + o_bwnp;
+    d_wl_ptr = b32 + o_wl;
     lds_factor = cugo_k::chol_lds_factor_bytes(P.nc_max);
     lds_backward = cugo_k::chol_lds_backward_bytes(P.nc_max, P.ld_max);
 }
@@ -85,7 +107,7 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
             cugo_k::launch_chol_subtree_stage(s, dev, d_fronts.data(), t0, t1 - t0, lds_factor, d_fail);
         else
             cugo_k::launch_chol_upper_stage(
-                s, dev, d_fronts.data(), t0, t1 - t0, d_wl.data(), plan.ea_ptr[st],
+                s, dev, d_fronts.data(), t0, t1 - t0, d_wl_ptr, plan.ea_ptr[st],
                 plan.ea_ptr[st + 1] - plan.ea_ptr[st], plan.eab_ptr[st],
                 plan.eab_ptr[st + 1] - plan.eab_ptr[st], plan.syrk_ptr[st],
                 plan.syrk_ptr[st + 1] - plan.syrk_ptr[st], lds_factor, d_fail);
@@ -95,7 +117,7 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
         const int t0 = plan.stage_task_ptr[st], t1 = plan.stage_task_ptr[st + 1];
         // the level's fronts, plus the ahead-of-time mat-vecs of their children as extra workgroups
         cugo_k::launch_chol_backward_stage(s, dev, d_fronts.data(), t0, t1 - t0, lds_backward, d_xnew.data(),
-                                           d_x, d_wl.data() + 3L * plan.bwg_ptr[st],
+                                           d_x, d_wl_ptr + 3L * plan.bwg_ptr[st],
                                            plan.bwg_ptr[st + 1] - plan.bwg_ptr[st]);
         const int st_top = st;
         if (dbg && st_top == plan.n_stages - 1)

@@ -13,12 +13,10 @@ struct cugo_chol
     cugo_k::CholPlanDev dev{};
     size_t lds_factor = 0, lds_backward = 0;
 
-    cugo_host::DevBuf<int32_t> d_ncb, d_nb, d_col0, d_rows_ptr, d_rows, d_child_ptr, d_child,
-        d_rel_ptr, d_rel, d_task_ptr, d_task_fronts, d_blk_front, d_blk_row, d_blk_col, d_perm,
-        d_col_front, d_wl;
-    cugo_host::DevBuf<int64_t> d_off, d_woff, d_l21off, d_ldf;
-    cugo_host::DevBuf<int32_t> d_alias_of, d_bw_np;
-    cugo_host::DevBuf<uint8_t> d_blk_trans;
+    // the plan's index arrays, packed (chol_solver.cpp: upload)
+    cugo_host::DevBuf<int32_t> d_pack32;
+    cugo_host::DevBuf<int64_t> d_pack64;
+    const int32_t* d_wl_ptr = nullptr; // work-item triples inside d_pack32
     cugo_host::DevBuf<double> d_fronts, d_xnew, d_junk, d_winv, d_l21;
 
     void analyze(int n, const int32_t* rowptr, const int32_t* colind);

@@ -666,6 +666,7 @@ void Engine::build_structure()
 {
     Impl& m = *impl_;
     const auto t0 = Clock::now();
+    InitLaps laps;
     hipStream_t s = m.ctx.stream;
     const int P = m.P, L = m.L;
     // pose-major view of the global co-visibility
@@ -708,6 +709,7 @@ void Engine::build_structure()
             },
             &rc);
     };
+    laps.lap("structure: pose-major covis");
     // rows: diagonal first, then ascending columns (ref: sparse_block_matrix.cpp:80-155; O(M)
     // with a marker array instead of the reference's dense P x P byte map)
     m.hsc_rowptr.assign(P + 1, 0);
@@ -752,6 +754,7 @@ void Engine::build_structure()
     for (int p = 0; p < P; p++)
         m.hsc_rowptr[p + 1] += m.hsc_rowptr[p];
     const int B = (int)m.hsc_colind.size();
+    laps.lap("structure: Hsc pattern");
     // contribution lists of the off-diagonal blocks from the LOCAL edges, built row by row
     // (pose-major): pos[q] gives the slot of column q in the current row, so every product is
     // placed with O(1) work; inside a block the contributions are in ascending landmark order.
@@ -809,6 +812,7 @@ void Engine::build_structure()
             }
         });
     }
+    laps.lap("structure: product lists");
     m.d_hsc_rowptr.upload(m.hsc_rowptr, s), m.d_hsc_colind.upload(m.hsc_colind, s);
     m.d_off_ptr.upload(off_cnt, s), m.d_off_ei.upload(off_ei, s), m.d_off_ej.upload(off_ej, s);
     m.d_sys.resize(36 * (size_t)B + 6 * (size_t)P + 16);
@@ -817,11 +821,13 @@ void Engine::build_structure()
     m.hs.d_rowptr = m.d_hsc_rowptr.data(), m.hs.d_colind = m.d_hsc_colind.data();
     m.hs.d_off_ptr = m.d_off_ptr.data(), m.hs.d_off_ei = m.d_off_ei.data();
     m.hs.d_off_ej = m.d_off_ej.data();
+    laps.lap("structure: uploads");
     prof_[PROF_BUILD_STRUCTURE] += ms_since(t0);
 
     const auto t1 = Clock::now();
     m.chol.analyze(P, m.hsc_rowptr.data(), m.hsc_colind.data());
     prof_[PROF_SYMBOLIC] += ms_since(t1);
+    laps.lap("structure: symbolic + plan upload");
 
     sstats_.hsc_blocks = B;
     sstats_.products = products;

@@ -171,10 +171,13 @@ int main(int argc, char** argv)
 {
     if (argc < 2)
     {
-        std::fprintf(stderr, "usage: %s graph.json [iterations]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s graph.json [iterations] [float32]\n", argv[0]);
         return 2;
     }
     const int iterations = argc > 2 ? std::atoi(argv[2]) : 10;
+    // the reference selects 32-bit internal floats at build time (cmake -DUSE_FLOAT32=ON); here it
+    // is an option of the optimiser
+    const bool float32 = argc > 3 && std::string(argv[3]) == "float32";
     std::ifstream in(argv[1]);
     if (!in)
     {
@@ -189,6 +192,7 @@ int main(int argc, char** argv)
     cugo::GraphOptimisationOptions options;
     options.perEdgeInformation = true;
     options.perEdgeCamera = true;
+    options.useFloat32 = float32;
     auto optimizer = std::make_unique<cugo::CudaGraphOptimisationImpl>(options);
 
     cugo::PoseVertexSet poses(false);

@@ -632,3 +632,10 @@ def test_cpp_sample_reads_reference_json_format(oracle_lib, tmp_path):
     g.initialize(); g.optimize(1); g.initialize(); g.optimize(10)
     assert_trajectories_match(g.stats(), ref, 1e-10)
     g.close()
+    # GraphOptimisationOptions::useFloat32 through the C++ API: within the stated fp32 tolerance
+    out32 = subprocess.run([exe, path, "10", "float32"], capture_output=True, text=True, timeout=120)
+    assert out32.returncode == 0, out32.stderr
+    chi32 = [float(m.group(1)) for m in re.finditer(r"iter:\s*\d+, chi2: ([0-9.eE+-]+)", out32.stdout)]
+    assert len(chi32) == 10
+    for a, b in zip(chi32, ref):
+        assert abs(a - b["chi2"]) <= 0.06 + 1e-5 * b["chi2"]

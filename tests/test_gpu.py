@@ -639,3 +639,22 @@ def test_cpp_sample_reads_reference_json_format(oracle_lib, tmp_path):
     assert len(chi32) == 10
     for a, b in zip(chi32, ref):
         assert abs(a - b["chi2"]) <= 0.06 + 1e-5 * b["chi2"]
+
+
+def test_repeated_new_optimisers_no_memory_drift(oracle_lib):
+    """a new optimiser per call (the ORB-SLAM2 pattern) over changing topologies: device blocks
+    and streams are recycled by the process-wide cache, results are bitwise reproducible and the
+    free device memory does not drift (tools/soak.py, short run)"""
+    import importlib.util
+    from conftest import ROOT
+    import os
+    spec = importlib.util.spec_from_file_location("soak", os.path.join(ROOT, "tools", "soak.py"))
+    soak = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(soak)
+    import sys
+    argv = sys.argv
+    try:
+        sys.argv = ["soak.py", "32"]
+        soak.main()
+    finally:
+        sys.argv = argv

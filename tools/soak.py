@@ -8,8 +8,9 @@ import os
 import sys
 import time
 
+import ctypes
+
 import numpy as np
-import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 cugo = importlib.import_module("cuda-bundle-adjustment_amd")
@@ -17,7 +18,14 @@ cugo = importlib.import_module("cuda-bundle-adjustment_amd")
 
 def main():
     cycles = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    torch.cuda.init()
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        hip.hipDeviceSynchronize()
+        free, total = ctypes.c_size_t(), ctypes.c_size_t()
+        assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        return free.value
+
     rng = np.random.default_rng(0)
     free0 = None
     chi_first = {}
@@ -42,10 +50,8 @@ def main():
         g.optimize(2)
         g.close()
         if c == 8:
-            torch.cuda.synchronize()
-            free0 = torch.cuda.mem_get_info()[0]
-    torch.cuda.synchronize()
-    free1 = torch.cuda.mem_get_info()[0]
+            free0 = free_bytes()
+    free1 = free_bytes()
     print("cycles %d in %.1f s; device memory free after warm-up %.1f MiB, at the end %.1f MiB (drift %.1f MiB)" %
           (cycles, time.perf_counter() - t0, free0 / 2**20, free1 / 2**20, (free0 - free1) / 2**20))
     assert free0 - free1 < 64 * 2**20, "device memory keeps growing"

@@ -56,6 +56,9 @@ def main():
         for a, b in zip(st, ref):
             rel = abs(a["chi2"] - b["chi2"]) / max(abs(b["chi2"]), 1e-6)
             worst = max(worst, rel)
+            if rel > 3e-11:
+                print("case %d: P %d L %d rk %s iteration %d rel %.2e chi2 %.6g trials %d lambda %.3g"
+                      % (c, P, L, rk, a["iteration"], rel, b["chi2"], b["trials"], b["lam"]))
             assert rel < 1e-7, (c, P, L, rk, a, b)
             assert a["trials"] == b["trials"], (c, a, b)
         assert np.abs(pose - prob.pose).max() < 1e-6 and np.abs(lm - prob.lm).max() < 1e-5, c

@@ -12,7 +12,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcugo_hip.so")
+# CUGO_LIB selects another build of the same library (tools/run_san.sh: the sanitizer build)
+LIB_PATH = os.environ.get("CUGO_LIB") or os.path.join(_HERE, "libcugo_hip.so")
 _lib = None
 
 OK = 0
@@ -89,6 +90,34 @@ def device_count():
     return lib().cugo_device_count()
 
 
+UNIQUE_ID_BYTES = 128
+
+
+def set_device(device):
+    check(lib().cugo_set_device(int(device)))
+
+
+class Comm:
+    """cugo_comm_*: RCCL communicator over the ranks of a multi-GPU job (collective constructor)"""
+
+    def __init__(self, unique_id, rank, world):
+        self._c = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), UNIQUE_ID_BYTES)
+        check(lib().cugo_comm_create(buf, int(rank), int(world), C.byref(self._c)))
+
+    def close(self):
+        if self._c:
+            lib().cugo_comm_destroy(self._c)
+            self._c = C.c_void_p()
+
+
+def comm_unique_id():
+    """rank 0 of a multi-GPU job: the RCCL unique id to hand to every rank (bytes)"""
+    buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+    check(lib().cugo_comm_unique_id(buf))
+    return buf.raw
+
+
 def _p(a, t):
     return a.ctypes.data_as(t)
 
@@ -124,9 +153,10 @@ class Graph:
     """cugo_graph_*: the reference's public optimiser class behind a flat-array interface
     (ref: include/cuda_graph_optimisation.h:132-252)."""
 
-    def __init__(self, per_edge_information=True, per_edge_camera=True):
+    def __init__(self, per_edge_information=True, per_edge_camera=True, plan_only=False):
         self._g = C.c_void_p()
-        check(lib().cugo_graph_create(int(per_edge_information), int(per_edge_camera), C.byref(self._g)))
+        create = lib().cugo_graph_create_plan_only if plan_only else lib().cugo_graph_create
+        check(create(int(per_edge_information), int(per_edge_camera), C.byref(self._g)))
         self._cb = None
         self.pose_ids = np.zeros(0, np.int32)
         self.lm_ids = np.zeros(0, np.int32)
@@ -194,6 +224,16 @@ class Graph:
             fn(ptr, n, op)
         self._cb = EXCHANGE_FN(_cb)
         check(lib().cugo_graph_set_shard(self._g, rank, world, self._cb, None))
+
+    def set_comm(self, comm):
+        """native RCCL exchange on the solver's stream (comm: a Comm object)"""
+        check(lib().cugo_graph_set_comm(self._g, comm._c))
+        self._comm = comm  # keep it alive
+
+    def exchange_stats(self):
+        b, c = C.c_double(), C.c_int32()
+        check(lib().cugo_graph_exchange_stats(self._g, C.byref(b), C.byref(c)))
+        return dict(bytes=b.value, calls=c.value)
 
     def set_verbose(self, v):
         lib().cugo_graph_set_verbose(self._g, int(v))
@@ -265,10 +305,10 @@ class Graph:
 
 
 def graph_from_arrays(d, per_edge_information=True, per_edge_camera=True, rk=(RK_NONE, 1.0),
-                      pose_ids=None, lm_ids=None):
+                      pose_ids=None, lm_ids=None, plan_only=False):
     """Build a Graph from the flat-array problem dict used by tests/oracle.Problem
     (positions are used as ids unless ids are given)."""
-    g = Graph(per_edge_information, per_edge_camera)
+    g = Graph(per_edge_information, per_edge_camera, plan_only)
     P, L = len(d["pose"]), len(d["lm"])
     pid = np.arange(P, dtype=np.int32) if pose_ids is None else np.asarray(pose_ids, np.int32)
     lid = np.arange(L, dtype=np.int32) if lm_ids is None else np.asarray(lm_ids, np.int32)

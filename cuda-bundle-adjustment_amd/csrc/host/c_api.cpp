@@ -10,6 +10,7 @@
 #include "chol_solver.h"
 #include "engine.h"
 #include "hip_util.h"
+#include "rccl_comm.h"
 
 using namespace cugo_host;
 
@@ -325,6 +326,17 @@ int cugo_graph_create(int per_edge_information, int per_edge_camera, cugo_graph*
         *out = g.release();
     });
 }
+int cugo_graph_create_plan_only(int per_edge_information, int per_edge_camera, cugo_graph** out)
+{
+    return guarded([&] {
+        auto g = std::make_unique<cugo_graph>();
+        g->options.perEdgeInformation = per_edge_information != 0;
+        g->options.perEdgeCamera = per_edge_camera != 0;
+        g->options.planOnly = true;
+        g->opt = std::make_unique<cugo::CudaGraphOptimisationImpl>(g->options);
+        *out = g.release();
+    });
+}
 void cugo_graph_destroy(cugo_graph* g) { delete g; }
 
 int cugo_graph_add_poses(cugo_graph* g, int n, const int32_t* ids, const double* qt, const uint8_t* fixed)
@@ -443,6 +455,61 @@ int cugo_graph_get_edge_active(cugo_graph* g, int dim, int n, uint8_t* active)
 int cugo_graph_set_shard(cugo_graph* g, int rank, int world, cugo_exchange_fn fn, void* user)
 {
     return guarded([&] { g->opt->setShard(rank, world, fn, user); });
+}
+int cugo_comm_unique_id(void* id128)
+{
+    return guarded([&] {
+        if (!id128)
+            throw std::runtime_error("cugo_comm_unique_id: null buffer");
+        cugo_host::RcclComm::unique_id(id128);
+    });
+}
+struct cugo_comm
+{
+    std::shared_ptr<cugo_host::RcclComm> c;
+};
+int cugo_comm_create(const void* id128, int rank, int world, cugo_comm** out)
+{
+    return guarded([&] {
+        if (!id128 || !out || world < 1 || rank < 0 || rank >= world)
+            throw std::runtime_error("cugo_comm_create: bad arguments");
+        auto* h = new cugo_comm;
+        try
+        {
+            h->c = std::make_shared<cugo_host::RcclComm>(id128, rank, world);
+        }
+        catch (...)
+        {
+            delete h;
+            throw;
+        }
+        *out = h;
+    });
+}
+void cugo_comm_destroy(cugo_comm* comm) { delete comm; }
+int cugo_graph_set_comm(cugo_graph* g, cugo_comm* comm)
+{
+    return guarded([&] {
+        if (!comm)
+            throw std::runtime_error("cugo_graph_set_comm: null communicator");
+        g->opt->setComm(comm->c);
+    });
+}
+int cugo_graph_exchange_stats(cugo_graph* g, double* bytes, int32_t* calls)
+{
+    return guarded([&] {
+        int c = 0;
+        double b = 0;
+        g->opt->exchangeStats(b, c);
+        if (bytes)
+            *bytes = b;
+        if (calls)
+            *calls = c;
+    });
+}
+int cugo_set_device(int device)
+{
+    return guarded([&] { CUGO_HIP(hipSetDevice(device)); });
 }
 int cugo_graph_initialize(cugo_graph* g)
 {

@@ -10,12 +10,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
+#include <memory>
 #include <numeric>
 #include <thread>
 
 #include "../kernels/kernels.h"
 #include "chol_solver.h"
 #include "hip_util.h"
+#include "rccl_comm.h"
 #include "thread_pool.h"
 
 namespace cugo_host
@@ -58,7 +60,11 @@ struct Engine::Impl : cugo_k::LaunchHook
     int rank = 0, world = 1;
     cugo_exchange_fn xfn = nullptr;
     void* xuser = nullptr;
+    std::shared_ptr<RcclComm> comm; // native exchange (RCCL on the solver's stream); else xfn
+    double xchg_bytes = 0;          // payload bytes all-reduced since initialize()
+    int xchg_calls = 0;
     bool profile = false;
+    bool plan_only = false; // host side only (no device): see Engine::Engine
 
     int Pall = 0, Lall = 0, P = 0, L = 0, E = 0;
     int shard_l0 = 0, shard_l1 = 0; // landmark index range owned by this rank
@@ -99,6 +105,10 @@ struct Engine::Impl : cugo_k::LaunchHook
     cugo_hsc_struct hs{};
     bool structure_dirty = true;
     uint64_t structure_sig = 0; // hash of the flattened topology the structure was built for
+    // ... and the topology itself (compared on a hash hit), saved by build_structure()
+    int sig_dims[8] = {0}, pending_dims[8] = {0};
+    std::vector<int32_t> sig_e_pose, sig_e_lm, sig_cov_pose;
+    std::vector<uint8_t> sig_flags;
 
     // optional HIP-event timing of kernel groups
     bool ktiming = false;
@@ -181,15 +191,24 @@ struct Engine::Impl : cugo_k::LaunchHook
     double* bsc() { return d_sys.data() + 36 * (size_t)hs.n_blocks; }
     cugo_k::ReduceScratch rs() { return {ctx.scratch.data(), ctx.scratch.size()}; }
 
+    // all-reduce of n doubles at d over the shards.  With a communicator (cugo_graph_set_comm) this
+    // is one ncclAllReduce queued on the solver's stream: no host synchronisation, no callback.
+    // The callback form (cugo_graph_set_shard) is the test hook: it has to wait for the stream.
     void exchange(double* d, size_t n, int op)
     {
-        if (world > 1)
+        if (world <= 1 && !comm) // a 1-rank communicator still issues its (identity) collectives
+            return;
+        xchg_bytes += 8.0 * (double)n;
+        xchg_calls++;
+        if (comm)
         {
-            if (!xfn)
-                throw std::runtime_error("cugo: sharded run without an exchange function");
-            CUGO_HIP(hipStreamSynchronize(ctx.stream));
-            xfn(d, n, op, xuser);
+            timed("exchange", [&] { comm->all_reduce(d, n, op, ctx.stream); });
+            return;
         }
+        if (!xfn)
+            throw std::runtime_error("cugo: sharded run without a communicator or an exchange function");
+        CUGO_HIP(hipStreamSynchronize(ctx.stream));
+        xfn(d, n, op, xuser);
     }
 };
 
@@ -202,8 +221,14 @@ const char* Engine::profile_name(int i)
     return names[i];
 }
 
-Engine::Engine() : impl_(new Impl)
+Engine::Engine(bool plan_only) : impl_(new Impl)
 {
+    if (plan_only)
+    {
+        impl_->plan_only = true;
+        impl_->chol.ctx = nullptr; // host-only analysis (cugo_chol with a null context)
+        return;
+    }
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
     {
@@ -251,7 +276,21 @@ void Engine::set_shard(int rank, int world, cugo_exchange_fn fn, void* user)
 {
     if (world < 1 || rank < 0 || rank >= world)
         throw std::runtime_error("cugo: bad shard");
+    impl_->comm.reset();
     impl_->rank = rank, impl_->world = world, impl_->xfn = fn, impl_->xuser = user;
+}
+
+void Engine::set_comm(std::shared_ptr<RcclComm> comm)
+{
+    if (!comm)
+        throw std::runtime_error("cugo: null communicator");
+    impl_->rank = comm->rank(), impl_->world = comm->world(), impl_->xfn = nullptr, impl_->xuser = nullptr;
+    impl_->comm = std::move(comm);
+}
+
+void Engine::exchange_stats(double& bytes, int& calls) const
+{
+    bytes = impl_->xchg_bytes, calls = impl_->xchg_calls;
 }
 
 static constexpr unsigned kMaxHostThreads = 16;
@@ -500,6 +539,7 @@ void Engine::initialize(FlatGraph& g)
         m.slot_threshold.assign(E, 0.0);
     m.Etot = Etot;
     m.last_err_buf = 0;
+    m.xchg_bytes = 0, m.xchg_calls = 0;
     auto fill_slots = [&](int ia, int ib) {
         for (int i = ia; i < ib; i++)
         {
@@ -573,7 +613,9 @@ void Engine::initialize(FlatGraph& g)
         });
     }
     laps.lap("engine: pose-major view");
-    // ---- upload --------------------------------------------------------------------------
+    // ---- upload (a plan-only engine has no device: it skips to the topology signature) -----
+    if (!m.plan_only)
+    {
     m.d_e_pose.upload(m.h_e_pose, s), m.d_e_lm.upload(m.h_e_lm, s), m.d_flags.upload(m.h_flags, s);
     m.d_meas.upload(meas, s), m.d_omega.upload(omega, s), m.d_cams.upload(g.cams, s);
     if (m.n_cams > 1)
@@ -603,6 +645,7 @@ void Engine::initialize(FlatGraph& g)
     laps.lap("engine: enqueue uploads");
     CUGO_HIP(hipStreamSynchronize(s)); // host staging vectors go out of scope
     laps.lap("engine: upload sync");
+    }
 
     cugo_edges& ev = m.ev;
     ev.n_edges = E, ev.n_poses_total = m.Pall, ev.n_landmarks_total = m.Lall;
@@ -652,12 +695,44 @@ void Engine::initialize(FlatGraph& g)
         mix(m.h_e_lm.data(), sizeof(int32_t) * m.h_e_lm.size());
         mix(m.h_flags.data(), m.h_flags.size());
         mix(m.cov_pose.data(), sizeof(int32_t) * m.cov_pose.size());
-        if (h != m.structure_sig || std::getenv("CUGO_NO_STRUCTURE_REUSE"))
+        // the hash only rejects fast: on a hit the arrays the structure was built from are compared
+        // (a 64-bit collision must not replay a plan of another topology)
+        auto same = [](const auto& a, const auto& b) {
+            return a.size() == b.size() && (a.empty() || std::memcmp(a.data(), b.data(), a.size() * sizeof(a[0])) == 0);
+        };
+        const bool hit = h == m.structure_sig && std::memcmp(dims, m.sig_dims, sizeof dims) == 0 &&
+                         same(m.h_e_pose, m.sig_e_pose) && same(m.h_e_lm, m.sig_e_lm) &&
+                         same(m.h_flags, m.sig_flags) && same(m.cov_pose, m.sig_cov_pose);
+        if (!hit || std::getenv("CUGO_NO_STRUCTURE_REUSE"))
             m.structure_dirty = true;
         m.structure_sig = h;
+        std::memcpy(m.pending_dims, dims, sizeof dims);
     }
     laps.lap("engine: topology hash");
     prof_[PROF_INITIALIZE] += ms_since(t0);
+    if (m.plan_only && m.structure_dirty)
+        build_structure(); // no optimize() will follow: the structure is all there is to do
+}
+
+void Engine::fill_structure_stats(int B, double products, double offdiag_products)
+{
+    Impl& m = *impl_;
+    // remember what this structure was built from (Engine::initialize compares on a hash hit)
+    std::memcpy(m.sig_dims, m.pending_dims, sizeof m.sig_dims);
+    m.sig_e_pose = m.h_e_pose, m.sig_e_lm = m.h_e_lm, m.sig_flags = m.h_flags, m.sig_cov_pose = m.cov_pose;
+    sstats_.hsc_blocks = B;
+    sstats_.products = products;
+    sstats_.offdiag_products = offdiag_products;
+    sstats_.nnzL = m.chol.plan.nnzL;
+    sstats_.chol_flops = m.chol.plan.flops;
+    sstats_.supernodes = m.chol.plan.n_super;
+    sstats_.stages = m.chol.plan.n_stages;
+    sstats_.front_bytes = 8.0 * (double)m.chol.plan.front_doubles;
+    sstats_.up_potrf_flops = m.chol.plan.up_potrf_flops;
+    sstats_.up_trsm_flops = m.chol.plan.up_trsm_flops;
+    sstats_.up_syrk_flops = m.chol.plan.up_syrk_flops;
+    sstats_.up_ea_bytes = m.chol.plan.up_ea_bytes;
+    sstats_.backward_bytes = m.chol.plan.backward_bytes;
 }
 
 // Hsc pattern from landmark co-visibility + contribution lists + Cholesky analysis
@@ -813,6 +888,17 @@ void Engine::build_structure()
         });
     }
     laps.lap("structure: product lists");
+    if (m.plan_only)
+    {
+        m.hs = cugo_hsc_struct{};
+        m.hs.n_blocks = B;
+        prof_[PROF_BUILD_STRUCTURE] += ms_since(t0);
+        const auto t1p = Clock::now();
+        m.chol.analyze(P, m.hsc_rowptr.data(), m.hsc_colind.data());
+        prof_[PROF_SYMBOLIC] += ms_since(t1p);
+        fill_structure_stats(B, products, (double)Moff);
+        return;
+    }
     m.d_hsc_rowptr.upload(m.hsc_rowptr, s), m.d_hsc_colind.upload(m.hsc_colind, s);
     m.d_off_ptr.upload(off_cnt, s), m.d_off_ei.upload(off_ei, s), m.d_off_ej.upload(off_ej, s);
     m.d_sys.resize(36 * (size_t)B + 6 * (size_t)P + 16);
@@ -829,25 +915,15 @@ void Engine::build_structure()
     prof_[PROF_SYMBOLIC] += ms_since(t1);
     laps.lap("structure: symbolic + plan upload");
 
-    sstats_.hsc_blocks = B;
-    sstats_.products = products;
-    sstats_.offdiag_products = (double)Moff;
-    sstats_.nnzL = m.chol.plan.nnzL;
-    sstats_.chol_flops = m.chol.plan.flops;
-    sstats_.supernodes = m.chol.plan.n_super;
-    sstats_.stages = m.chol.plan.n_stages;
-    sstats_.front_bytes = 8.0 * (double)m.chol.plan.front_doubles;
-    sstats_.up_potrf_flops = m.chol.plan.up_potrf_flops;
-    sstats_.up_trsm_flops = m.chol.plan.up_trsm_flops;
-    sstats_.up_syrk_flops = m.chol.plan.up_syrk_flops;
-    sstats_.up_ea_bytes = m.chol.plan.up_ea_bytes;
-    sstats_.backward_bytes = m.chol.plan.backward_bytes;
+    fill_structure_stats(B, products, (double)Moff);
     m.structure_dirty = false;
 }
 
 void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool verbose)
 {
     Impl& m = *impl_;
+    if (m.plan_only)
+        throw std::runtime_error("cugo: no HIP device in use (plan-only optimiser)");
     hipStream_t s = m.ctx.stream;
     const int maxq = 10;
     const double tau = 1e-5;
@@ -855,7 +931,7 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
 
     if (m.structure_dirty)
         build_structure();
-    const bool sharded = m.world > 1;
+    const bool sharded = m.world > 1 || m.comm;
     int32_t* d_fail = reinterpret_cast<int32_t*>(m.d_scal.data() + 4);
     auto sync_prof = [&](int item, Clock::time_point t0) {
         if (m.profile)

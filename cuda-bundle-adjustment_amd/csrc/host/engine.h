@@ -3,6 +3,7 @@
 // CudaGraphOptimisationImpl::optimize (ref: src/cuda_graph_optimisation.cpp:48-154).
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -10,6 +11,8 @@
 
 namespace cugo_host
 {
+
+class RcclComm;
 
 // Result of flattening a graph (ref: VertexSet::generateEstimateData + EdgeSet::init,
 // src/optimisable_graph.hpp:84-126,474-572).  Indices: free vertices first.
@@ -66,12 +69,18 @@ void shard_range(const std::vector<int32_t>& lm_cnt, int rank, int world, int& l
 class Engine
 {
 public:
-    Engine();
+    // plan_only: no device is touched; initialize() stops after the host-side flattening and
+    // builds the structure (Hsc pattern, product lists, ordering, symbolic factor) right away
+    explicit Engine(bool plan_only = false);
     ~Engine();
     Engine(const Engine&) = delete;
     Engine& operator=(const Engine&) = delete;
 
     void set_shard(int rank, int world, cugo_exchange_fn fn, void* user);
+    // native exchange: RCCL communicator over the ranks of the job (shared by all optimisers of the
+    // process); all-reduces then run on the solver's stream without a host synchronisation
+    void set_comm(std::shared_ptr<RcclComm> comm);
+    void exchange_stats(double& bytes, int& calls) const; // since the last initialize()
     // ref: BlockSolver::initialize (block_solver.cpp:21-137)
     // float storage of the Hpl / T block streams (GraphOptimisationOptions::useFloat32); takes
     // effect at the next initialize().  The environment variable CUGO_FLOAT32=1 forces it on.
@@ -107,6 +116,7 @@ public:
 
 private:
     void build_structure();
+    void fill_structure_stats(int B, double products, double offdiag_products);
     Impl* impl_;
     int E_global_ = 0;
     StructureStats sstats_;

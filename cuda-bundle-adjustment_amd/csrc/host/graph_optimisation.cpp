@@ -41,7 +41,7 @@ CudaGraphOptimisation::Ptr CudaGraphOptimisation::create()
 CudaGraphOptimisationImpl::CudaGraphOptimisationImpl() : engine_(new Engine) {}
 
 CudaGraphOptimisationImpl::CudaGraphOptimisationImpl(GraphOptimisationOptions& opts)
-    : options(opts), engine_(new Engine)
+    : options(opts), engine_(new Engine(opts.planOnly))
 {
 }
 
@@ -50,6 +50,16 @@ CudaGraphOptimisationImpl::~CudaGraphOptimisationImpl() {}
 void CudaGraphOptimisationImpl::setShard(int rank, int world, ExchangeFn fn, void* user)
 {
     engine_->set_shard(rank, world, fn, user);
+}
+
+void CudaGraphOptimisationImpl::setComm(std::shared_ptr<cugo_host::RcclComm> comm)
+{
+    engine_->set_comm(std::move(comm));
+}
+
+void CudaGraphOptimisationImpl::exchangeStats(double& bytes, int& calls) const
+{
+    engine_->exchange_stats(bytes, calls);
 }
 
 int CudaGraphOptimisationImpl::nActiveEdges() const { return engine_->n_active_edges(); }
@@ -354,6 +364,8 @@ void CudaGraphOptimisationImpl::optimize(int niterations)
         std::fprintf(stderr, "[cugo optimize] %-24s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - lap_t).count());
         lap_t = n;
     };
+    if (options.planOnly)
+        throw std::runtime_error("cugo: no HIP device in use: this optimiser is plan-only (GraphOptimisationOptions::planOnly)");
     std::vector<cugo_host::IterRecord> rec;
     engine_->optimize(niterations, rec, verbose);
     lap("engine optimize");

@@ -15,6 +15,7 @@
 namespace cugo_host
 {
 class Engine;
+class RcclComm;
 }
 
 namespace cugo
@@ -122,6 +123,10 @@ public:
 
     // ---- extensions (not in the reference) ----
     void setShard(int rank, int world, ExchangeFn fn, void* user);
+    /** native exchange of a landmark-sharded run: the per-trial all-reduce of [Hsc | bsc] runs as an
+     *  RCCL collective on the solver's stream (communicator: cugo_comm_create of include/cugo_hip.h) */
+    void setComm(std::shared_ptr<cugo_host::RcclComm> comm);
+    void exchangeStats(double& bytes, int& calls) const;
     const std::vector<LmTrace>& lmTrace() const { return trace_; }
     int nActiveEdges() const;
     /** B, M, nnz(L), flops, supernodes, stages, front bytes, off-diagonal products, then per

@@ -144,6 +144,11 @@ struct CUGO_API GraphOptimisationOptions
     // Cholesky stay fp64.  chi2 per iteration then agrees with the fp64 run to ~1e-6 relative
     // (tolerance stated and tested in tests/test_gpu.py::test_float32_block_storage).
     bool useFloat32 = false;
+    // Extension: a plan-only optimiser needs no GPU.  initialize() then runs the host side only
+    // (flattening, index assignment, landmark-major layout, Hsc pattern, product lists, ordering and
+    // symbolic factorisation — what structureStats() reports); optimize() fails.  Used to size a
+    // problem ahead of time and to run the host code under sanitizers (make SAN=1).
+    bool planOnly = false;
 };
 
 enum class RobustKernelType

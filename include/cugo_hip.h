@@ -202,6 +202,12 @@ typedef struct cugo_graph cugo_graph; /* CudaGraphOptimisationImpl + its vertex/
 /* ref: CudaGraphOptimisationImpl(options) include/cuda_graph_optimisation.h:206;
  * GraphOptimisationOptions src/graph_optimisation_options.h:8-19 */
 int cugo_graph_create(int per_edge_information, int per_edge_camera, cugo_graph** out);
+/* Extension: a plan-only graph needs no GPU.  cugo_graph_initialize() then runs the host side only —
+ * flattening and index assignment (ref: src/block_solver.cpp:21-137), Hsc pattern and product lists
+ * (ref: src/sparse_block_matrix.cpp:63-156), ordering + symbolic factorisation (ref:
+ * src/cholesky.hpp:97-98,295-296) — and cugo_graph_structure_stats() reports the result;
+ * cugo_graph_optimize() fails.  Sizes a problem ahead of time; also what `make SAN=1` exercises. */
+int cugo_graph_create_plan_only(int per_edge_information, int per_edge_camera, cugo_graph** out);
 void cugo_graph_destroy(cugo_graph* g);
 /* vertices: ids are caller ids (ref: PoseVertex(id, Se3D, fixed), LandmarkVertex(id, Vec3d,
  * fixed); src/optimisable_graph.h:109-155) */
@@ -231,6 +237,24 @@ int cugo_graph_n_outliers(cugo_graph* g, int dim);
 /* active flag of the first n edges of the set, in insertion order */
 int cugo_graph_get_edge_active(cugo_graph* g, int dim, int n, uint8_t* active);
 int cugo_graph_set_shard(cugo_graph* g, int rank, int world, cugo_exchange_fn fn, void* user);
+/* Native exchange (one process per GPU, RCCL over xGMI; not in the reference, which is single-GPU:
+ * src/cuda_device.cpp:264-282).  Rank 0 of the job calls cugo_comm_unique_id() (ncclGetUniqueId,
+ * CUGO_UNIQUE_ID_BYTES bytes) and hands the id to every rank by any channel; every rank then calls
+ * cugo_comm_create() (a collective: ncclCommInitRank on the current device) once per process and
+ * attaches the communicator to its optimisers with cugo_graph_set_comm().  From then on the
+ * per-trial sum of [Hsc | bsc] and of (F-hat, scale) are ncclAllReduce calls queued on the
+ * solver's own stream: no host synchronisation and no callback.  librccl is loaded on first use.
+ * The communicator must outlive the last optimize() of the graphs that use it. */
+#define CUGO_UNIQUE_ID_BYTES 128
+typedef struct cugo_comm cugo_comm;
+int cugo_comm_unique_id(void* id128);
+int cugo_comm_create(const void* id128, int rank, int world, cugo_comm** out);
+void cugo_comm_destroy(cugo_comm* comm);
+int cugo_graph_set_comm(cugo_graph* g, cugo_comm* comm);
+/* payload bytes and number of all-reduce calls since the last cugo_graph_initialize() */
+int cugo_graph_exchange_stats(cugo_graph* g, double* bytes, int32_t* calls);
+/* hipSetDevice for the calling thread: a rank binds its GPU (LOCAL_RANK) before creating graphs */
+int cugo_set_device(int device);
 /* the landmark index range [*l0, *l1) that shard `rank` of `world` owns, given the number
  * of active edges of every landmark (host only; the rule cugo_graph_initialize applies) */
 int cugo_shard_range(int n_landmarks_total, const int32_t* edges_per_landmark, int rank, int world,

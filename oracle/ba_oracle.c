@@ -353,7 +353,10 @@ static int edge_active(const ba_problem* p, int e)
 
 double ba_compute_errors(const ba_problem* p, double* errors, double* Xcs)
 {
-    double chi_set[2] = {0, 0}; /* per edge set, then added (block_solver.cpp:256-267) */
+    double chi_mono = 0, chi_stereo = 0; /* per edge set, then added (block_solver.cpp:256-267) */
+#ifdef BA_OMP /* timing-only build (cpu_baseline, all cores): the summation order is not fixed */
+#pragma omp parallel for reduction(+ : chi_mono, chi_stereo) schedule(static)
+#endif
     for (int e = 0; e < p->n_edges; e++)
     {
         if (!edge_active(p, e))
@@ -363,13 +366,16 @@ double ba_compute_errors(const ba_problem* p, double* errors, double* Xcs)
         ba_edge_eval(p->pose + 7 * p->e_pose[e], p->lm + 3 * p->e_lm[e], p->e_meas + 3 * e,
                      st ? 3 : 2, p->e_omega[e], p->e_cam + 5 * e, p->rk_type, p->rk_delta, er, xc,
                      &chi, 0, 0, 0);
-        chi_set[st] += chi;
+        if (st)
+            chi_stereo += chi;
+        else
+            chi_mono += chi;
         if (errors)
             memcpy(errors + 3 * e, er, sizeof er);
         if (Xcs)
             memcpy(Xcs + 3 * e, xc, sizeof xc);
     }
-    return chi_set[0] + chi_set[1];
+    return chi_mono + chi_stereo;
 }
 
 /* ------------------------------------------------------------------ build ----------- */
@@ -391,7 +397,23 @@ double ba_build_system(const ba_problem* p, double* Hpp, double* bp, double* Hll
         memset(bl, 0, sizeof(double) * 3 * nlf);
     if (Hpl)
         memset(Hpl, 0, sizeof(double) * 18 * p->n_edges);
-    double chi_set[2] = {0, 0};
+    double chi_mono = 0, chi_stereo = 0;
+#ifdef BA_OMP
+    /* pose blocks are hit by hundreds of edges each: every thread sums into its own copy, the
+     * copies are added at the end; landmark blocks (a few edges each) use atomic adds */
+#pragma omp parallel reduction(+ : chi_mono, chi_stereo)
+    {
+    double* Hpp_shared = Hpp;
+    double* bp_shared = bp;
+    double* Hpp_t = Hpp ? (double*)calloc((size_t)36 * (npf + 1), sizeof(double)) : 0;
+    double* bp_t = bp ? (double*)calloc((size_t)6 * (npf + 1), sizeof(double)) : 0;
+#define Hpp Hpp_t
+#define bp bp_t
+#define BA_ATOMIC _Pragma("omp atomic")
+#pragma omp for schedule(static)
+#else
+#define BA_ATOMIC
+#endif
     for (int e = 0; e < p->n_edges; e++)
     {
         if (!edge_active(p, e))
@@ -401,7 +423,10 @@ double ba_build_system(const ba_problem* p, double* Hpp, double* bp, double* Hll
         double er[3], chi, w, JP[18], JL[9];
         ba_edge_eval(p->pose + 7 * ip, p->lm + 3 * il, p->e_meas + 3 * e, dim, p->e_omega[e],
                      p->e_cam + 5 * e, p->rk_type, p->rk_delta, er, 0, &chi, JP, JL, &w);
-        chi_set[st] += chi;
+        if (st)
+            chi_stereo += chi;
+        else
+            chi_mono += chi;
         const int pf = !p->pose_fixed[ip], lf = !p->lm_fixed[il];
         /* C(r,c) = w * sum_m A(m,r) B(m,c), col-major (MatTMulMat .cu:186-198) */
         if (pf)
@@ -439,6 +464,7 @@ double ba_build_system(const ba_problem* p, double* Hpp, double* bp, double* Hll
                         double s = 0;
                         for (int m = 0; m < dim; m++)
                             s += JL[r * dim + m] * JL[c * dim + m];
+                        BA_ATOMIC
                         H[c * 3 + r] += w * s;
                     }
                 if (b)
@@ -446,6 +472,7 @@ double ba_build_system(const ba_problem* p, double* Hpp, double* bp, double* Hll
                     double s = 0;
                     for (int m = 0; m < dim; m++)
                         s += JL[c * dim + m] * er[m];
+                    BA_ATOMIC
                     b[c] += w * s;
                 }
             }
@@ -463,9 +490,25 @@ double ba_build_system(const ba_problem* p, double* Hpp, double* bp, double* Hll
                 }
         }
     }
+#ifdef BA_OMP
+#undef Hpp
+#undef bp
+#pragma omp critical
+    {
+        if (Hpp_t)
+            for (int i = 0; i < 36 * npf; i++)
+                Hpp_shared[i] += Hpp_t[i];
+        if (bp_t)
+            for (int i = 0; i < 6 * npf; i++)
+                bp_shared[i] += bp_t[i];
+    }
+    free(Hpp_t);
+    free(bp_t);
+    } /* omp parallel */
+#endif
     free(pidx);
     free(lidx);
-    return chi_set[0] + chi_set[1];
+    return chi_mono + chi_stereo;
 }
 
 /* ------------------------------------------------------------------ dense LL^T ------ */
@@ -979,6 +1022,9 @@ static void schur_bsr(const ba_problem* p, const ba_struct* s, const double* Hpp
     for (int r = 0; r < npf; r++) /* initializeHschur .cu:1316-1325 */
         memcpy(Hsc + 36 * s->rowptr[r], Hpp + 36 * r, sizeof(double) * 36);
     memcpy(bsc, bp, sizeof(double) * 6 * npf); /* bp.copyTo(bsc) .cu:2017 */
+#ifdef BA_OMP /* like the reference's kernels: one landmark per thread, atomic adds into bsc / Hsc */
+#pragma omp parallel for schedule(dynamic, 256)
+#endif
     for (int l = 0; l < nlf; l++)
     {
         double* iH = invHll + 9 * l;
@@ -1003,6 +1049,7 @@ static void schur_bsr(const ba_problem* p, const ba_struct* s, const double* Hpp
                 double v = 0;
                 for (int m = 0; m < 3; m++)
                     v += T[m * 6 + r] * bl[3 * l + m];
+                BA_ATOMIC
                 bsc[6 * ra + r] -= v;
             }
             for (int b = a; b < a1; b++)
@@ -1017,6 +1064,7 @@ static void schur_bsr(const ba_problem* p, const ba_struct* s, const double* Hpp
                         double v = 0;
                         for (int m = 0; m < 3; m++)
                             v += T[m * 6 + r] * Hb[m * 6 + c];
+                        BA_ATOMIC
                         dst[c * 6 + r] -= v;
                     }
             }
@@ -1122,6 +1170,9 @@ static int solve_with(const ba_problem* p, const ba_struct* s, double lambda, in
     }
     if (ok)
     { /* schurComplementPost .cu:1419-1442 */
+#ifdef BA_OMP
+#pragma omp parallel for schedule(static)
+#endif
         for (int l = 0; l < nlf; l++)
         {
             double cl[3] = {bl[3 * l], bl[3 * l + 1], bl[3 * l + 2]};

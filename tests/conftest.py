@@ -22,10 +22,27 @@ PROBLEM_KEYS = ["pose", "pose_fixed", "lm", "lm_fixed", "e_pose", "e_lm", "e_ste
                 "e_omega", "e_cam"]
 GOLDEN_GRAPHS = ["tiny_3x8", "small_10x200", "loop_12x150", "reject_8x60", "zero_noise_6x40",
                  "cauchy_8x80", "tukey_8x80", "huber_8x80"]
-# chi2 relative tolerance per fixture.  1e-10 is the north-star bar; reject_8x60 starts 4
-# orders of magnitude from the optimum with rejected trials and amplifies round-off (the two
-# independent CPU restatements already differ by 2e-9 on it), so it is a control-flow fixture.
-GOLDEN_TOL = {"reject_8x60": 1e-6}
+# chi2 relative tolerance: 1e-10 (the north star) on every fixture.  The stress fixture reject_8x60
+# starts 4 orders of magnitude from the optimum and takes rejected trials; it amplifies round-off by
+# itself: the oracle run against ITSELF with the edges summed in another order differs by up to 3e-9
+# from iteration 6 on (tests/oracle.self_sensitivity).  For such a fixture the bar of iteration i is
+# max(1e-10, 4 x that measured self-sensitivity) — derived from the problem, not picked.
+STRESS_FIXTURES = ("reject_8x60",)
+_TOL_CACHE = {}
+
+
+def golden_tolerances(name, niter=10):
+    """(per-iteration relative chi2 tolerance list, absolute tolerance of the final estimates)"""
+    if name not in STRESS_FIXTURES:
+        return [1e-10] * niter, 1e-9
+    if name not in _TOL_CACHE:
+        import numpy as np
+        import oracle
+        g = np.load(golden_path(name + ".npz"))
+        P = oracle.Problem(*[g[k] for k in PROBLEM_KEYS], rk_type=int(g["rk_type"]), rk_delta=float(g["rk_delta"]))
+        sens, est = oracle.self_sensitivity(P, niter, seeds=(1, 2, 3), with_estimates=True)
+        _TOL_CACHE[name] = ([max(1e-10, 4.0 * s) for s in sens], max(1e-9, 4.0 * est))
+    return _TOL_CACHE[name]
 
 
 @pytest.fixture(scope="session")

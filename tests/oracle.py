@@ -55,6 +55,26 @@ def lib():
     return _LIB
 
 
+_FAST = None
+
+
+def fast_lib():
+    """Timing-only variant of the same source for bench.py's cpu_baseline leg: -O3 -march=native
+    -fopenmp -DBA_OMP (OpenMP over edges / landmarks; the summation order is then not fixed, so it
+    is never the parity checker).  Compiled on the machine that runs it (-march=native) into a
+    temporary directory; OMP_NUM_THREADS selects 1 thread or all cores."""
+    global _FAST
+    if _FAST is None:
+        import tempfile
+        out = os.path.join(tempfile.mkdtemp(prefix="ba_oracle_fast_"), "libba_oracle_fast.so")
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fopenmp", "-DBA_OMP", "-fPIC", "-std=c99",
+                               "-shared", "-o", out, os.path.join(ORACLE_DIR, "ba_oracle.c"), "-lm"])
+        _FAST = C.CDLL(out)
+        _FAST.ba_compute_errors.restype = C.c_double
+        _FAST.ba_build_system.restype = C.c_double
+    return _FAST
+
+
 def _p(a, t):
     return a.ctypes.data_as(t) if a is not None else None
 
@@ -154,12 +174,47 @@ class Problem:
                                  _p(dxl, _dp))
         return bool(ok), dxp, dxl
 
-    def optimize(self, niter, dense=False):
+    def optimize(self, niter, dense=False, use_lib=None):
         info = (IterInfo * max(niter, 1))()
         s = self._c()
-        n = lib().ba_optimize(C.byref(s), int(niter), int(dense), info)
+        n = (use_lib or lib()).ba_optimize(C.byref(s), int(niter), int(dense), info)
         return [dict(iteration=info[i].iteration, chi2=info[i].chi2, lam=info[i].lambda_,
                      rho=info[i].rho, trials=info[i].trials) for i in range(n)]
+
+
+def self_sensitivity(prob, niter, seeds=(1, 2), with_estimates=False):
+    """Conditioning probe.  The SAME oracle solves the SAME problem (a) with the edges listed in
+    another order (every sum over edges then runs in another, equally valid order) and (b) with its
+    other factorisation (dense LL^T instead of block-sparse with minimum-degree ordering).  Returns,
+    per LM iteration, the largest relative chi2 difference between those runs and the reference run
+    (running maximum over the iterations: a difference made in iteration i is carried into the later
+    ones), or None when a probe takes another accept / reject path.  A GPU-vs-oracle difference of the
+    same size is round-off amplified by the problem, not an error of either implementation."""
+    base = prob.copy()
+    ref = base.optimize(niter)
+    worst = [0.0] * len(ref)
+    runs = []
+    for sd in seeds:
+        perm = np.random.default_rng(sd).permutation(prob.n_edges)
+        q = Problem(prob.pose, prob.pose_fixed, prob.lm, prob.lm_fixed, prob.e_pose[perm], prob.e_lm[perm],
+                    prob.e_stereo[perm], prob.e_meas[perm], prob.e_omega[perm], prob.e_cam[perm],
+                    prob.rk_type, prob.rk_delta)
+        runs.append((q.optimize(niter), q))
+    if prob.n_poses <= 400:
+        q = prob.copy()
+        runs.append((q.optimize(niter, dense=True), q))
+    est = 0.0
+    for r, q in runs:
+        if len(r) != len(ref) or any(a["trials"] != b["trials"] for a, b in zip(r, ref)):
+            return None
+        for i, (a, b) in enumerate(zip(r, ref)):
+            worst[i] = max(worst[i], abs(a["chi2"] - b["chi2"]) / max(abs(b["chi2"]), 1e-6))
+        est = max(est, float(np.abs(q.pose - base.pose).max()), float(np.abs(q.lm - base.lm).max()))
+    for i in range(1, len(worst)):
+        worst[i] = max(worst[i], worst[i - 1])
+    if with_estimates:
+        return worst, est
+    return worst
 
 
 def edge_eval(pose7, Xw, meas, dim, omega, cam, rk_type=RK_NONE, rk_delta=1.0):

@@ -1,9 +1,9 @@
 """GPU parity tests: every call goes through the C ABI of libcugo_hip.so and is checked
 against the CPU oracle (oracle/ba_oracle.c) and the committed numpy goldens.
 
-Tolerances: chi2 per iteration 1e-10 relative (north star), estimates 1e-9 absolute
-(well-conditioned fixtures); the stress fixture reject_8x60 uses the looser tolerance stated
-in conftest.GOLDEN_TOL.  Kernel-level block outputs: 1e-11 relative to the block scale.
+Tolerances: chi2 per iteration 1e-10 relative (north star), estimates 1e-9 absolute; the stress
+fixture reject_8x60 uses max(1e-10, 4 x the oracle's own measured order sensitivity) per iteration
+(conftest.golden_tolerances).  Kernel-level block outputs: 1e-11 relative to the block scale.
 """
 import ctypes as C
 import importlib
@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 import synth
-from conftest import GOLDEN_GRAPHS, GOLDEN_TOL, PROBLEM_KEYS, golden_path
+from conftest import GOLDEN_GRAPHS, PROBLEM_KEYS, golden_path, golden_tolerances
 
 pytestmark = pytest.mark.gpu
 
@@ -265,8 +265,10 @@ def run_graph(d, niter, rk=(0, 1.0), **kw):
 
 
 def assert_trajectories_match(got, ref, tol, check_trials=True):
+    """tol: one relative chi2 tolerance, or one per iteration"""
     assert len(got) == len(ref)
-    for a, b in zip(got, ref):
+    tols = list(tol) if isinstance(tol, (list, tuple)) else [tol] * len(ref)
+    for a, b, tol in zip(got, ref, tols):
         assert abs(a["chi2"] - b["chi2"]) <= tol * max(abs(b["chi2"]), 1e-6), (a, b)
         if check_trials:
             assert a["trials"] == b["trials"]
@@ -283,10 +285,9 @@ def test_lm_trajectory_vs_golden_and_oracle(oracle_lib, name):
         assert len(out["stats"]) <= 2 and all(s["chi2"] < 1e-12 for s in out["stats"])
         np.testing.assert_allclose(out["pose"], g["pose_out"], rtol=0, atol=1e-9)
         return
-    tol = GOLDEN_TOL.get(name, 1e-10)
+    tol, etol = golden_tolerances(name)   # 1e-10 / 1e-9; measured conditioning for the stress fixture
     tr = [dict(chi2=t[1], lam=t[2], trials=int(t[4])) for t in g["trace"]]
     assert_trajectories_match(out["stats"], tr, tol)
-    etol = 1e-9 if name not in GOLDEN_TOL else 1e-6
     np.testing.assert_allclose(out["pose"], g["pose_out"], rtol=0, atol=etol)
     np.testing.assert_allclose(out["lm"], g["lm_out"], rtol=0, atol=10 * etol)
     # and the C oracle on the same input
@@ -540,32 +541,61 @@ def test_ids_fixed_vertices_and_reinitialize(oracle_lib):
     del prob
 
 
-def test_kitti00_shape_full_size(oracle_lib):
+@pytest.fixture(scope="module")
+def kitti00(oracle_lib):
+    """BASELINE configs 2 / 3 / 5 share this graph (1322 / 133 383 / 561 116, seed 0) and ONE
+    10-iteration run of the fp64 oracle on it."""
+    d, prob = synth_problem(oracle_lib, 1322, 133383, 561116, seed=0, lc=4000)
+    ref = prob.optimize(10)
+    return dict(d=d, ref=ref, pose=prob.pose.copy(), lm=prob.lm.copy())
+
+
+def test_kitti00_shape_full_size(kitti00):
     """BASELINE config 2 shape (1322 / 133 383 / 561 116): parity with the oracle plus
     size-independent properties (monotone chi2, bitwise reproducibility)."""
-    d, prob = synth_problem(oracle_lib, 1322, 133383, 561116, seed=0, lc=4000)
+    d = kitti00["d"]
     out = run_graph(d, 10)
     chi = [s["chi2"] for s in out["stats"]]
     assert len(chi) == 10 and all(b < a for a, b in zip(chi, chi[1:]))
     assert out["nedges"] == 561116
-    ref = prob.optimize(10)
-    assert_trajectories_match(out["stats"], ref, 1e-10)
-    assert rmse(out["pose"][:, :4], prob.pose[:, :4]) < 1e-11
-    assert rmse(out["pose"][:, 4:], prob.pose[:, 4:]) < 1e-9
-    assert rmse(out["lm"], prob.lm) < 1e-8
+    assert_trajectories_match(out["stats"], kitti00["ref"], 1e-10)
+    assert rmse(out["pose"][:, :4], kitti00["pose"][:, :4]) < 1e-11
+    assert rmse(out["pose"][:, 4:], kitti00["pose"][:, 4:]) < 1e-9
+    assert rmse(out["lm"], kitti00["lm"]) < 1e-8
     again = run_graph(d, 10)
     assert chi == [s["chi2"] for s in again["stats"]]
 
 
-def test_sharded_two_ranks_on_one_gpu_matches_single(oracle_lib):
-    """landmark-sharded path with world=2 emulated in ONE process: two graphs take turns and
-    exchange through host memory. Exercises partial Hsc/bsc/chi/scale sums + replicated LL^T."""
+def test_kitti00_float32_full_size(kitti00):
+    """BASELINE config 5 at full size: the fp32-internal mode (float storage of the Hpl / Hpl*invHll
+    block streams, everything else fp64) against the fp64 oracle, tolerance of DESIGN.md section 4a:
+    chi2 of every iteration within 1e-5 relative, same LM trial counts, poses within 1e-4 and
+    landmarks within 1e-3 absolute."""
+    d = kitti00["d"]
+    g = cugo.graph_from_arrays(d)
+    g.set_float32(True)
+    g.initialize(); g.optimize(10)
+    st, pose, lm = g.stats(), g.poses(), g.landmarks()
+    g.close()
+    ref = kitti00["ref"]
+    assert len(st) == len(ref) == 10
+    assert [a["trials"] for a in st] == [b["trials"] for b in ref]
+    rel = max(abs(a["chi2"] - b["chi2"]) / b["chi2"] for a, b in zip(st, ref))
+    assert 1e-13 < rel < 1e-5, rel   # float storage really in use, and inside the stated tolerance
+    assert np.abs(pose - kitti00["pose"]).max() < 1e-4 and np.abs(lm - kitti00["lm"]).max() < 1e-3
+    print("config 5 full size: max rel chi2 diff %.3e, pose %.3e, landmark %.3e"
+          % (rel, np.abs(pose - kitti00["pose"]).max(), np.abs(lm - kitti00["lm"]).max()))
+
+
+def run_sharded_in_threads(d, world, niter):
+    """landmark-sharded run with `world` shards emulated in ONE process on one GPU: one optimiser
+    per shard in its own thread, the all-reduce goes through host memory (the callback form of the
+    exchange; the RCCL form needs one GPU per rank).  Returns the per-rank results."""
     import threading
-    d, prob = synth_problem(oracle_lib, 150, 2200, 9000, seed=9, lc=60)
-    single = run_graph(d, 6)
-    world = 2
+    import devmem
     bufs, barrier, results = {}, threading.Barrier(world), [None] * world
     lock = threading.Lock()
+    ctxs = [devmem.Ctx() for _ in range(world)]
 
     def make_exchange(rank):
         def fn(ptr, n, op):
@@ -574,20 +604,20 @@ def test_sharded_two_ranks_on_one_gpu_matches_single(oracle_lib):
             with lock:
                 bufs[rank] = host
             barrier.wait()
-            tot = bufs[0] + bufs[1] if op == 0 else np.maximum(bufs[0], bufs[1])
+            tot = bufs[0].copy()
+            for r in range(1, world):  # fixed rank order
+                tot = tot + bufs[r] if op == 0 else np.maximum(tot, bufs[r])
             barrier.wait()
             cugo.check(cugo.lib().cugo_memcpy_h2d(ctxs[rank].h, C.c_void_p(ptr), tot.ctypes.data_as(C.c_void_p), 8 * n))
         return fn
-
-    import devmem
-    ctxs = [devmem.Ctx() for _ in range(world)]
 
     def worker(rank):
         g = cugo.graph_from_arrays(d)
         g.set_shard(rank, world, make_exchange(rank))
         g.initialize()
-        g.optimize(6)
-        results[rank] = dict(stats=g.stats(), pose=g.poses(), lm=g.landmarks())
+        g.optimize(niter)
+        results[rank] = dict(stats=g.stats(), pose=g.poses(), lm=g.landmarks(), xstats=g.exchange_stats(),
+                             nedges=g.n_active_edges())
         g.close()
 
     ts = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
@@ -595,11 +625,81 @@ def test_sharded_two_ranks_on_one_gpu_matches_single(oracle_lib):
     [t.join() for t in ts]
     for c in ctxs:
         c.close()
-    for r in range(world):
-        assert results[r] is not None
-        assert_trajectories_match(results[r]["stats"], single["stats"], 1e-11)
-        np.testing.assert_allclose(results[r]["pose"], single["pose"], rtol=0, atol=1e-10)
-        np.testing.assert_allclose(results[r]["lm"], single["lm"], rtol=0, atol=1e-9)
+    return results
+
+
+def test_kitti00_two_shards_match_unsharded(kitti00):
+    """BASELINE config 3 (kitti_00 landmark-sharded) at full size with 2 shards on one GPU: both
+    ranks reproduce the unsharded chi2 trajectory (the partial Schur systems are summed in a
+    different order, so not bitwise) and the oracle's, and end at the same estimates."""
+    d = kitti00["d"]
+    res = run_sharded_in_threads(d, 2, 10)
+    single = run_graph(d, 10)
+    for r in range(2):
+        assert res[r] is not None and res[r]["nedges"] == 561116
+        assert_trajectories_match(res[r]["stats"], single["stats"], 1e-11)
+        assert_trajectories_match(res[r]["stats"], kitti00["ref"], 1e-10)
+        assert rmse(res[r]["pose"], single["pose"]) < 1e-11 and rmse(res[r]["lm"], single["lm"]) < 1e-10
+        # exchanges: 3 at iteration 0 + 2 per LM trial; payload = [Hsc | bsc] + scalars
+        trials = sum(max(s["trials"], 0) + 1 for s in res[r]["stats"])
+        assert res[r]["xstats"]["calls"] >= 3 + 2 * 10 and res[r]["xstats"]["calls"] <= 3 + 2 * trials + 2
+    assert [s["chi2"] for s in res[0]["stats"]] == [s["chi2"] for s in res[1]["stats"]]  # ranks agree bitwise
+
+
+def test_synth10k_full_size(oracle_lib):
+    """BASELINE config 4 at full size on one GPU (10 000 poses / 1 000 000 landmarks / 5 000 000 mono
+    edges): the first 2 LM iterations against the oracle at 1e-10, then size-independent properties
+    of the 10-iteration run — strictly decreasing chi2, the edge count, bitwise reproducibility."""
+    d = cugo.synth(10000, 1000000, 5000000, seed=10000, n_loop_closures=0, stereo_fraction=0.0)
+    assert not d["e_stereo"].any()
+    prob = oracle_lib.Problem(d["pose"], d["pose_fixed"], d["lm"], d["lm_fixed"], d["e_pose"], d["e_lm"],
+                              d["e_stereo"], d["e_meas"], d["e_omega"], d["e_cam"])
+    g = cugo.graph_from_arrays(d)
+    g.initialize(); g.optimize(10)
+    st, pose = g.stats(), g.poses()
+    assert g.n_active_edges() == 5000000
+    chi = [s["chi2"] for s in st]
+    assert len(chi) == 10 and all(b < a for a, b in zip(chi, chi[1:]))
+    ref = prob.optimize(2)
+    assert_trajectories_match(st[:2], ref, 1e-10)
+    ids_p, ids_l = np.arange(10000, dtype=np.int32), np.arange(1000000, dtype=np.int32)
+    g.set_poses(ids_p, d["pose"]); g.set_landmarks(ids_l, d["lm"])
+    g.initialize(); g.optimize(10)
+    assert chi == [s["chi2"] for s in g.stats()] and np.array_equal(pose, g.poses())
+    g.close()
+
+
+def test_native_comm_single_rank(oracle_lib):
+    """cugo_comm_* (RCCL inside the library): a 1-rank communicator issues its (identity)
+    ncclAllReduce calls on the solver's stream; the run is bitwise the single-GPU run.  RCCL does not
+    allow two ranks on one device, so the multi-rank form is exercised by bench.py --gpus N only."""
+    d, _ = synth_problem(oracle_lib, 150, 2200, 9000, seed=9, lc=60)
+    single = run_graph(d, 6)
+    comm = cugo.Comm(cugo.comm_unique_id(), 0, 1)
+    g = cugo.graph_from_arrays(d)
+    g.set_comm(comm)
+    g.initialize(); g.optimize(6)
+    st, pose, xs = g.stats(), g.poses(), g.exchange_stats()
+    g.close()
+    comm.close()
+    assert [s["chi2"] for s in st] == [s["chi2"] for s in single["stats"]]
+    assert np.array_equal(pose, single["pose"])
+    B = single["sstats"]["hsc_blocks"]
+    assert xs["calls"] >= 3 + 2 * 6 and xs["bytes"] >= 6 * 8 * (36 * B + 6 * 149)
+
+
+def test_sharded_two_ranks_on_one_gpu_matches_single(oracle_lib):
+    """landmark-sharded path with world=2 and world=3 emulated in ONE process: the graphs take turns
+    and exchange through host memory. Exercises partial Hsc/bsc/chi/scale sums + replicated LL^T."""
+    d, prob = synth_problem(oracle_lib, 150, 2200, 9000, seed=9, lc=60)
+    single = run_graph(d, 6)
+    for world in (2, 3):
+        results = run_sharded_in_threads(d, world, 6)
+        for r in range(world):
+            assert results[r] is not None
+            assert_trajectories_match(results[r]["stats"], single["stats"], 1e-11)
+            np.testing.assert_allclose(results[r]["pose"], single["pose"], rtol=0, atol=1e-10)
+            np.testing.assert_allclose(results[r]["lm"], single["lm"], rtol=0, atol=1e-9)
 
 
 def test_cpp_sample_reads_reference_json_format(oracle_lib, tmp_path):

@@ -266,3 +266,77 @@ def test_shard_ranges_partition_all_landmarks(lib):
             loads.append(int(cnt[a:b].sum()))
         assert prev == len(cnt)
         assert max(loads) - min(loads) <= 2 * cnt.max() + 1
+
+
+def _expected_structure(d):
+    """Hsc block count and block-product counts of a flat-array problem, straight from the definition
+    (ref: src/sparse_block_matrix.cpp:63-156 and findHschureMulBlockIndicesKernel .cu:1347-1378)"""
+    pf, lf = d["pose_fixed"].astype(bool), d["lm_fixed"].astype(bool)
+    ff = ~pf[d["e_pose"]] & ~lf[d["e_lm"]]
+    pairs = set()
+    products = offdiag = 0
+    P = len(pf)
+    for p in np.flatnonzero(~pf):
+        pairs.add((int(p), int(p)))
+    order = np.argsort(d["e_lm"][ff], kind="stable")
+    ep, el = d["e_pose"][ff][order], d["e_lm"][ff][order]
+    starts = np.flatnonzero(np.r_[True, el[1:] != el[:-1], True]) if len(el) else np.array([0])
+    for a, b in zip(starts[:-1], starts[1:]):
+        ps = sorted(int(p) for p in ep[a:b])
+        k = len(ps)
+        products += k * (k + 1) // 2
+        offdiag += k * (k - 1) // 2
+        for i in range(k):
+            for j in range(i, k):
+                pairs.add((ps[i], ps[j]))
+    return len(pairs), products, offdiag
+
+
+@pytest.mark.parametrize("shape", ["small_mixed", "fixed_heavy", "medium", "all_landmarks_fixed"])
+def test_plan_only_graph_runs_the_whole_host_side(lib, shape):
+    """a plan-only graph (no GPU) drives flattening, index assignment, landmark-major layout, Hsc
+    pattern, product lists, ordering and symbolic factorisation; its statistics match the
+    definitions.  This is also the entry `tools/run_san.sh` runs under ASan + UBSan."""
+    import synth
+    if shape == "small_mixed":
+        d = synth.make_problem(n_poses=14, n_landmarks=260, mean_obs=3.6, seed=4, fixed_poses=(0, 5),
+                               fixed_landmarks=(3, 77, 200), loop_closure=True)
+    elif shape == "fixed_heavy":
+        d = synth.make_problem(n_poses=30, n_landmarks=400, mean_obs=5.0, seed=9, fixed_poses=tuple(range(0, 30, 2)),
+                               fixed_landmarks=tuple(range(0, 400, 3)), loop_closure=True, stereo_frac=1.0)
+    elif shape == "medium":
+        d = cugo.synth(248, 26127, 95037, seed=7, n_loop_closures=500)
+    else:
+        d = synth.make_problem(n_poses=9, n_landmarks=80, seed=2, fixed_landmarks=tuple(range(80)))
+    B, products, offdiag = _expected_structure(d)
+    g = cugo.graph_from_arrays(d, plan_only=True)
+    g.initialize()
+    s = g.structure_stats()
+    assert int(s["hsc_blocks"]) == B and int(s["products"]) == products and int(s["offdiag_products"]) == offdiag
+    active = int(np.count_nonzero(~(d["pose_fixed"].astype(bool)[d["e_pose"]] & d["lm_fixed"].astype(bool)[d["e_lm"]])))
+    assert g.n_active_edges() == active
+    assert s["supernodes"] >= 1 and s["nnzL"] >= 21 * int(np.count_nonzero(d["pose_fixed"] == 0))
+    g.initialize()  # re-initialise: the structure is re-used (same topology) and stays consistent
+    assert g.structure_stats() == s
+    with pytest.raises(cugo.CugoError, match="plan-only"):
+        g.optimize(1)
+    g.close()
+
+
+def test_plan_only_sharded_structure_is_global(lib):
+    """every shard sees the GLOBAL Hsc pattern (the all-reduce payload has the same layout on every
+    rank) and the shards' product lists partition the unsharded one"""
+    d = cugo.synth(60, 900, 3700, seed=1)
+    B, products, offdiag = _expected_structure(d)
+    tot = 0
+    for world in (2, 3):
+        tot = 0
+        for r in range(world):
+            g = cugo.graph_from_arrays(d, plan_only=True)
+            g.set_shard(r, world, lambda ptr, n, op: None)
+            g.initialize()
+            s = g.structure_stats()
+            assert int(s["hsc_blocks"]) == B
+            tot += int(s["offdiag_products"])
+            g.close()
+        assert tot == offdiag

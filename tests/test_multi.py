@@ -3,7 +3,9 @@
 The product's shard rule (cugo_shard_range, host logic of libcugo_hip.so) splits the landmarks;
 each rank builds the partial Schur system of ITS landmarks with the CPU oracle, the ranks
 all-reduce [Hsc | bsc | chi2] over gloo exactly as the GPU path all-reduces its device buffer,
-and the sum must equal the unsharded system (lambda enters once, after the reduction)."""
+and the sum must equal the unsharded system (lambda enters once, after the reduction).  The
+product's own sharded host path runs too (plan-only graphs: flattening of the shard, global Hsc
+pattern, per-shard product lists), its counts all-reduced over gloo."""
 import importlib
 import os
 import socket
@@ -61,8 +63,23 @@ def _worker(rank, world, port, out_dir):
     # max-reduction used for the first lambda
     mx = torch.tensor([float(np.abs(np.diag(part.schur_dense(0.0)[0])).max())], dtype=torch.float64)
     dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    # the PRODUCT's own sharded host path (plan-only graph, no GPU): every rank flattens its shard and
+    # builds the structure; the Hsc pattern must be the global one on every rank (same all-reduce
+    # payload layout) and the ranks' block-product lists must partition the unsharded list
+    g = cugo.graph_from_arrays(d, plan_only=True)
+    g.set_shard(rank, world, lambda ptr, n, op: None)
+    g.initialize()
+    ss = g.structure_stats()
+    g.close()
+    gu = cugo.graph_from_arrays(d, plan_only=True)
+    gu.initialize()
+    su = gu.structure_stats()
+    gu.close()
+    cnt = torch.tensor([ss["offdiag_products"], ss["hsc_blocks"]], dtype=torch.float64)
+    dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+    ok_plan = int(cnt[0].item()) == int(su["offdiag_products"]) and int(cnt[1].item()) == world * int(su["hsc_blocks"])
     with open(os.path.join(out_dir, "rank%d.txt" % rank), "w") as f:
-        f.write("%d %d %d %d %d %d\n" % (ok_H, ok_b, ok_chi, ok_cover, l0, l1))
+        f.write("%d %d %d %d %d %d %d\n" % (ok_H, ok_b, ok_chi, ok_cover, l0, l1, ok_plan))
     dist.destroy_process_group()
 
 
@@ -76,6 +93,6 @@ def test_two_rank_gloo_exchange_matches_unsharded(tmp_path):
     ranges = []
     for r in range(2):
         vals = [int(v) for v in open(tmp_path / ("rank%d.txt" % r)).read().split()]
-        assert vals[:4] == [1, 1, 1, 1], vals
-        ranges.append(vals[4:])
+        assert vals[:4] == [1, 1, 1, 1] and vals[6] == 1, vals
+        ranges.append(vals[4:6])
     assert ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][1] == 500

@@ -1,6 +1,10 @@
 """Randomised parity sweep (not part of the test-suite): small graphs with random sizes, fixed
 vertices, stereo fractions, robust kernels, information / camera modes and Cholesky plan knobs,
-GPU (through the C ABI) against the CPU oracle.
+GPU (through the C ABI) against the CPU oracle.  Bar: chi2 of every LM iteration within 1e-10
+relative (the north star).  The sweep deliberately includes degenerate graphs (e.g. 19 poses seen
+through 11 landmarks: the Schur system is singular up to the damping); there a difference above the
+bar is accepted only if the oracle ALONE moves by as much when it sums in another order
+(tests/oracle.self_sensitivity), and is printed.
 
     python tools/fuzz.py [cases] [seed]           (needs an MI355X)
 """
@@ -17,11 +21,13 @@ cugo = importlib.import_module("cuda-bundle-adjustment_amd")
 import oracle  # noqa: E402
 import synth   # noqa: E402
 
+TOL = 1e-10  # north-star relative chi2 tolerance
+
 
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-    worst = 0.0
+    worst, worst_excused, excused = 0.0, 0.0, 0
     for c in range(cases):
         P = int(rng.integers(3, 48))
         L = int(rng.integers(8, 500))
@@ -53,16 +59,28 @@ def main():
         pose, lm = g.poses(), g.landmarks()
         g.close()
         assert len(st) == len(ref), (c, len(st), len(ref))
-        for a, b in zip(st, ref):
+        sens = None
+        for i, (a, b) in enumerate(zip(st, ref)):
             rel = abs(a["chi2"] - b["chi2"]) / max(abs(b["chi2"]), 1e-6)
-            worst = max(worst, rel)
-            if rel > 3e-11:
-                print("case %d: P %d L %d rk %s iteration %d rel %.2e chi2 %.6g trials %d lambda %.3g"
-                      % (c, P, L, rk, a["iteration"], rel, b["chi2"], b["trials"], b["lam"]))
-            assert rel < 1e-7, (c, P, L, rk, a, b)
             assert a["trials"] == b["trials"], (c, a, b)
+            if rel <= TOL:
+                worst = max(worst, rel)
+                continue
+            # Above the north-star bar: accepted only if the problem itself amplifies round-off that
+            # much — measured with the oracle alone (tests/oracle.self_sensitivity: the same C code,
+            # other summation order / other factorisation).  Every such case is printed.
+            if sens is None:
+                fresh = oracle.Problem(*synth.problem_fields(d))
+                fresh.rk_type, fresh.rk_delta = rk
+                sens = oracle.self_sensitivity(fresh, 6) or [float("inf")] * len(ref)
+            print("case %d: P %d L %d E %d rk %s iteration %d: gpu-vs-oracle %.2e, oracle-vs-reordered-oracle %.2e "
+                  "(chi2 %.6g)" % (c, P, L, len(d["e_pose"]), rk, a["iteration"], rel, sens[i], b["chi2"]))
+            assert rel <= 4.0 * sens[i], ("difference not explained by conditioning", c, P, L, rk, a, b, sens)
+            excused += 1
+            worst_excused = max(worst_excused, rel)
         assert np.abs(pose - prob.pose).max() < 1e-6 and np.abs(lm - prob.lm).max() < 1e-5, c
-    print("fuzz ok: %d cases, worst relative chi2 difference %.2e" % (cases, worst))
+    print("fuzz ok: %d cases at the 1e-10 bar (worst %.2e); %d iteration(s) of ill-conditioned cases above it, "
+          "each within 4x of the oracle's own order sensitivity (worst %.2e)" % (cases, worst, excused, worst_excused))
 
 
 if __name__ == "__main__":

@@ -1,0 +1,13 @@
+#!/bin/bash
+# CPU sanitizer run of the host code (AddressSanitizer + UndefinedBehaviorSanitizer), no GPU needed:
+# builds libcugo_hip_san.so (make SAN=1) and runs the host test-suite against it — symbolic plan
+# replay, synthetic generator, shard ranges, host-only cugo_chol_analyze, and the plan-only graphs
+# that drive the whole flattening + structure build (tests/test_host.py).
+set -e
+cd "$(dirname "$0")/.."
+make -C cuda-bundle-adjustment_amd SAN=1 -j8 -s
+RT=$(/opt/rocm/lib/llvm/bin/clang++ -print-file-name=libclang_rt.asan-x86_64.so)
+# python itself is not instrumented: preload the runtime, leak checking off (the interpreter leaks)
+export LD_PRELOAD="$RT" ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:halt_on_error=1" \
+       UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1" CUGO_LIB="$PWD/cuda-bundle-adjustment_amd/libcugo_hip_san.so"
+python -m pytest tests/test_host.py -x -q "$@"

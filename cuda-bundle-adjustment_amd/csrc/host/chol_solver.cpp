@@ -110,7 +110,7 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
                 s, dev, d_fronts.data(), t0, t1 - t0, d_wl_ptr, plan.ea_ptr[st],
                 plan.ea_ptr[st + 1] - plan.ea_ptr[st], plan.eab_ptr[st],
                 plan.eab_ptr[st + 1] - plan.eab_ptr[st], plan.syrk_ptr[st],
-                plan.syrk_ptr[st + 1] - plan.syrk_ptr[st], lds_factor, d_fail);
+                plan.syrk_ptr[st + 1] - plan.syrk_ptr[st], plan.stage_tile[st], lds_factor, d_fail);
     }
     for (int st = plan.n_stages - 1; st >= 0; st--)
     {

@@ -32,6 +32,8 @@ CholOptions CholOptions::from_env()
         o.min_subtree_tasks = std::max(0, std::atoi(s));
     if (const char* s = std::getenv("CUGO_MAX_FRONT_COLS"))
         o.max_front_cols = std::min(16, std::max(1, std::atoi(s)));
+    if (const char* s = std::getenv("CUGO_TILE32_MAX_TILES"))
+        o.tile32_max_tiles = std::max(0, std::atoi(s));
     return o;
 }
 
@@ -742,9 +744,24 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
     P.l21off.assign(ns, -1);
     P.l21_doubles = 0;
     std::vector<int32_t> ea, eab, sy, bwg;
+    P.stage_tile.assign(P.n_stages, 64);
     for (int st = 0; st < P.n_stages; st++)
     {
         const bool subtree = P.has_subtree_stage && st == 0;
+        int TS = 64;
+        if (!subtree)
+        { // tile edge of this level
+            long n64 = 0;
+            for (int t = P.stage_task_ptr[st]; t < P.stage_task_ptr[st + 1]; t++)
+            {
+                const int f = P.task_fronts[P.task_ptr[t]];
+                const long nti = (6 * (P.nb[f] - P.ncb[f]) + 1 + 63) / 64;
+                n64 += nti * (nti + 1) / 2;
+            }
+            if (n64 <= opt.tile32_max_tiles)
+                TS = 32;
+            P.stage_tile[st] = TS;
+        }
         if (!subtree)
             for (int t = P.stage_task_ptr[st]; t < P.stage_task_ptr[st + 1]; t++)
             {
@@ -781,7 +798,7 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
                 // tj = -1: a tile row without a diagonal tile (only the rhs row, or no boundary
                 // at all) still needs its L21 rows solved and stored
                 const int nrs = 6 * (nb - ncb), nbelow = nrs + 1;
-                const int nti = (nbelow + 63) / 64, ntj = (nrs + 63) / 64;
+                const int nti = (nbelow + TS - 1) / TS, ntj = (nrs + TS - 1) / TS;
                 for (int tj = 0; tj < ntj; tj++)
                     for (int ti = tj; ti < nti; ti++)
                     {

@@ -20,6 +20,7 @@ struct CholOptions
     // CUGO_MIN_SUBTREE_TASKS=0 turns it on (kept under test).
     int min_subtree_tasks = 1 << 30;
     int max_front_cols = 16; // hard cap on pivot block columns of a front (LDS-resident L11)
+    int tile32_max_tiles = 64; // a level with at most this many 64x64 tiles is cut into 32x32 tiles (0: never)
     static CholOptions from_env();
 };
 
@@ -62,6 +63,9 @@ struct CholPlan
     //   syrk        : 64x64 tile (row tile a, col tile b), a >= b
     std::vector<int32_t> wl;
     std::vector<int32_t> ea_ptr, eab_ptr, syrk_ptr, bwg_ptr; // [n_stages+1] item ranges per stage
+    // edge of the syrk tiles of each stage: 64, or 32 where a level has so few 64-tiles that the
+    // launch would leave most CUs idle (its duration is then one tile's, and a 32-tile is shorter)
+    std::vector<int32_t> stage_tile;
     // backward pass: boundary block rows of a front that lie in its PARENT's pivot columns (they come
     // first).  The mat-vec over the remaining rows — ancestors above the parent, solved earlier —
     // is done one launch ahead by extra workgroups riding with the parent's level (items bwg:

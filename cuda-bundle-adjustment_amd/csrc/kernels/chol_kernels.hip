@@ -990,6 +990,154 @@ __device__ __forceinline__ void dev_trsyrk_tile(double* __restrict__ F, long ld,
     }
 }
 
+// The same for ONE 32x32 tile: used on the levels with few fronts (the separator chains near the
+// root), where a launch has far fewer 64x64 tiles than the chip has CUs and its duration is the
+// duration of one tile — which is bound by the f64 matrix pipe of one CU (trsm of two 64-row
+// panels: 672 MFMAs, syrk: 384; 64 cycles each, four SIMDs).  A 32x32 tile needs 336 + 96 and
+// there are four times as many of them to spread over the idle CUs.
+//   trsm roles  : wave w -> row group w & 1 (16 rows), column block of X dealt by (w >> 1) so that
+//                 the waves sharing a SIMD (w mod 4) carry 11 / 10 K-blocks in total
+//   syrk roles  : waves 0..3 (one per SIMD), one 16x16 sub-tile each over the whole pivot width
+constexpr int TPST32 = 48; // panel stride: the two 16-lane halves of a ds_read_b64 hit different banks
+__device__ __forceinline__ void dev_trsyrk_tile32(double* __restrict__ F, long ld, int ncs, int nt, int nrs,
+                                                  int ti, int tj, const double* __restrict__ Wg,
+                                                  double* __restrict__ L21, long ld2,
+                                                  double* __restrict__ lds, double* __restrict__ junk)
+{
+    constexpr int KC = KC_SYRK;
+    constexpr int PST = TPST32;
+    double* sink = junk + ((blockIdx.x & 63) << 10) + threadIdx.x; // private slot of this lane
+    const int ncp = pad16(ncs), nblk = ncp >> 4;
+    const int tt = threadIdx.x, lane = tt & 63, ln = lane & 15, lk = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tt >> 6);
+    const int rg = w & 1, g = w >> 1;
+    const bool solo = tj < 0, diag = tj == ti, two = !solo && !diag;
+    double* Pi = lds;
+    double* Pj = lds + KC * PST;
+    double* Wl = lds + 2 * KC * PST; // lower block triangle of W, block (I,K) at (I(I+1)/2 + K)*256, [k][m]
+    double* U = F + (long)ncs * ld + ncs;
+    // column block of this wave: the blocks in the order of their cost (block cb needs cb+1
+    // K-blocks) go to the groups 0,1,3,2,4,5,7,6: even and odd groups — which sit on different
+    // SIMD pairs — then carry 6+3+2 and 5+4+1 K-blocks
+    const int pos = (0x67542310 >> (4 * g)) & 15; // position of group g in that order (nibble g)
+    const int cb = nblk - 1 - pos, nK = cb + 1;         // cb < 0: no block
+    // ---- all global loads first: W into LDS (once per workgroup), the B tile(s), the U entries
+    const int nwblk = nblk * (nblk + 1) / 2;
+    double wv[6];
+    int wdst[6];
+#pragma unroll
+    for (int u = 0; u < 6; u++)
+    {
+        const int f = tt + u * 1024; // element of the staged triangle: block f>>8, k = (f>>4)&15, m = f&15
+        const int blk = min(f >> 8, nwblk - 1);
+        int I = 0;
+        while ((I + 1) * (I + 2) / 2 <= blk)
+            I++;
+        const int K = blk - I * (I + 1) / 2;
+        const int k = (f >> 4) & 15, m = f & 15;
+        wdst[u] = (f >> 8) < nwblk ? f : -1;
+        wv[u] = ldg32(Wg, (unsigned)(16 * K + k) * (unsigned)ncp + (unsigned)(16 * I + m));
+    }
+    const int r = lane & 31, kq = 2 * w + (lane >> 5); // B staging: 32 rows x 32 columns per round
+    const int gi = 32 * ti + r, gj = 32 * tj + r;
+    const double* B = F + ncs; // (row i, col k) = B[k*ld + i]
+    const unsigned uld = (unsigned)ld;
+    const unsigned gic = (unsigned)min(gi, nt - 1), gjc = (unsigned)min(max(gj, 0), nt - 1);
+    const bool iok = gi < nt, jok = two && gj < nt;
+    double vi[3], vj[3];
+#pragma unroll
+    for (int u = 0; u < 3; u++)
+    {
+        const int k = kq + 32 * u;
+        const unsigned kc = (unsigned)min(k, ncs - 1);
+        const double bi = ldg32(B, kc * uld + gic);
+        const double bj = two ? ldg32(B, kc * uld + gjc) : 0.0;
+        vi[u] = (k < ncs && iok) ? bi : 0.0;
+        vj[u] = (k < ncs && jok) ? bj : 0.0;
+    }
+    const int wc = w & 1, wr = (w >> 1) & 1; // syrk role of waves 0..3
+    double uold[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+    {
+        const int i = 32 * ti + 16 * wr + ln, j = 32 * tj + 16 * wc + lk + 4 * q;
+        const bool ok = !solo && w < 4 && i < nt && j < nrs && i >= j;
+        const double* src = ok ? U + ((long)j * ld + i) : sink;
+        uold[q] = *src;
+    }
+#pragma unroll
+    for (int u = 0; u < 3; u++)
+    {
+        const int k = kq + 32 * u;
+        if (k < ncp)
+        {
+            Pi[k * PST + r] = vi[u];
+            if (two)
+                Pj[k * PST + r] = vj[u];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 6; u++)
+        if (wdst[u] >= 0)
+            Wl[wdst[u]] = wv[u];
+    __syncthreads();
+    // ---- X = B W^T for this wave's row group and column block (both panels)
+    double4_t xi = {0, 0, 0, 0}, xj = {0, 0, 0, 0};
+    if (cb >= 0)
+    {
+        for (int kb = 0; kb < nK; kb++)
+        {
+            const double* Wb = Wl + (cb * (cb + 1) / 2 + kb) * 256 + lk * 16 + ln; // W[16cb+m][16kb+k]
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++)
+            {
+                const int ko = (16 * kb + lk + 4 * kk) * PST + 16 * rg + ln;
+                const double av = Wb[64 * kk];
+                xi = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Pi[ko], xi, 0, 0, 0);
+                if (two)
+                    xj = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Pj[ko], xj, 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads(); // every wave has read B: the panels may be overwritten with X
+    if (cb >= 0)
+    {
+        const int row = 32 * ti + 16 * rg + ln;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            const int c = 16 * cb + lk + 4 * q;
+            Pi[c * PST + 16 * rg + ln] = xi[q];
+            if (two)
+                Pj[c * PST + 16 * rg + ln] = xj[q];
+            if (!two && c < ncs && row < nt) // diag or solo: this tile owns L21 rows ti
+                L21[(long)c * ld2 + row] = xi[q];
+        }
+    }
+    __syncthreads();
+    if (!solo && w < 4)
+    { // ---- U(ti,tj) -= X_i X_j^T, one 16x16 sub-tile per wave
+        const double* Pa = diag ? Pi : Pj;
+        double4_t acc = {0, 0, 0, 0};
+        for (int k0 = 0; k0 < ncs; k0 += 4)
+        {
+            const int k = min(k0 + lk, ncs - 1); // clamped: no branch around the LDS reads
+            const bool kok = k0 + lk < ncs;
+            const double av = Pa[k * PST + 16 * wc + ln];
+            const double bv = Pi[k * PST + 16 * wr + ln];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(kok ? av : 0.0, bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            const int i = 32 * ti + 16 * wr + ln, j = 32 * tj + 16 * wc + lk + 4 * q;
+            const bool ok = i < nt && j < nrs && i >= j;
+            double* dst = ok ? U + ((long)j * ld + i) : sink;
+            *dst = uold[q] - acc[q];
+        }
+    }
+}
+
 // backward substitution of one front: x_J = W^T (y_J - L21^T x_R), W = L11^-1 from dev_winv.
 // Both halves are matrix-vector products: 16 lanes per pivot column, all loads of a lane in
 // flight together, a 16-lane butterfly at the end.  No serial triangular solve.
@@ -1185,6 +1333,17 @@ __global__ __launch_bounds__(BIG) void k_up_trsyrk(CholPlanDev p, double* __rest
     stamp_value(4, 6, 1000000L * (it[1] * 10 + it[2] + 1) + 1000L * ncs + nrs);
 }
 
+__global__ __launch_bounds__(BIG) void k_up_trsyrk32(CholPlanDev p, double* __restrict__ fronts,
+                                                     const int32_t* __restrict__ wl)
+{
+    extern __shared__ double lds[];
+    const int32_t* it = wl + 3 * blockIdx.x;
+    const int f = it[0];
+    const int ncs = 6 * p.ncb[f], nrs = 6 * (p.nb[f] - p.ncb[f]);
+    dev_trsyrk_tile32(fronts + p.off[f], p.ldf[f], ncs, nrs + 1, nrs, it[1], it[2], p.winv + p.woff[f],
+                      p.l21 + p.l21off[f], nrs + 1, lds, p.junk);
+}
+
 // the ancestor part of a front's backward mat-vec, one launch ahead of the front itself:
 // v_j = y_j - sum_{i >= 6*npb} L21[i,j] x_R[i] for the 16 columns j0.. (one wave per column, its
 // 64 lanes stride the rows), parked in xnew at the front's own positions
@@ -1314,7 +1473,7 @@ void launch_chol_subtree_stage(hipStream_t s, const CholPlanDev& p, double* d_fr
 
 void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,
                              int ntasks, const int32_t* d_wl, int eap0, int neap, int ea0, int nea,
-                             int sy0, int nsy, size_t lds_bytes, int32_t* d_fail)
+                             int sy0, int nsy, int tile, size_t lds_bytes, int32_t* d_fail)
 {
     (void)lds_bytes;
     if (ntasks <= 0)
@@ -1322,7 +1481,13 @@ void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fron
     ensure_lds(reinterpret_cast<const void*>(k_up_potrf), chol_lds_potrf_bytes());
     CUGO_LAUNCH(k_up_potrf, dim3(ntasks + neap + nea), dim3(BIG), chol_lds_potrf_bytes(), s, p, d_fronts,
                 task0, ntasks, d_wl + 3L * eap0, neap, d_wl + 3L * ea0, d_fail);
-    if (nsy > 0)
+    if (nsy > 0 && tile == 32)
+    {
+        const size_t lds32 = (2 * KC_SYRK * TPST32 + 21 * 256) * sizeof(double);
+        ensure_lds(reinterpret_cast<const void*>(k_up_trsyrk32), lds32);
+        CUGO_LAUNCH(k_up_trsyrk32, dim3(nsy), dim3(BIG), lds32, s, p, d_fronts, d_wl + 3L * sy0);
+    }
+    else if (nsy > 0)
     {
         ensure_lds(reinterpret_cast<const void*>(k_up_trsyrk), trsyrk_lds() * sizeof(double));
         CUGO_LAUNCH(k_up_trsyrk, dim3(nsy), dim3(BIG), trsyrk_lds() * sizeof(double), s, p, d_fronts,

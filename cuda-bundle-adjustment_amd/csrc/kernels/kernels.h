@@ -134,9 +134,10 @@ void launch_chol_subtree_stage(hipStream_t s, const CholPlanDev& p, double* d_fr
                                int ntasks, size_t lds_bytes, int32_t* d_fail);
 // one etree level: extend-add(pivot columns) / potrf (+ extend-add of the boundary columns) /
 // fused trsm+syrk kernels over the work items d_wl[...]
+// tile: edge of the update-matrix tiles of this level's items (64, or 32 on levels with few fronts)
 void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,
                              int ntasks, const int32_t* d_wl, int eap0, int neap, int ea0, int nea,
-                             int sy0, int nsy, size_t lds_bytes, int32_t* d_fail);
+                             int sy0, int nsy, int tile, size_t lds_bytes, int32_t* d_fail);
 // backward substitution of one level: ntasks workgroups solve the level's fronts; ngemv more
 // workgroups (items d_wl_gemv: front, first column, -) do the ancestor part of the mat-vec of
 // the CHILDREN of these fronts, which the next launch then does not have to wait for

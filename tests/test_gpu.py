@@ -213,7 +213,10 @@ def test_float32_block_kernels_vs_oracle(ctx, oracle_lib):
                                  {"CUGO_ND_LEAF": "4", "CUGO_MAX_SUPER_COLS": "3", "CUGO_TARGET_TASKS": "4",
                                   "CUGO_MIN_SUBTREE_TASKS": "0"},
                                  {"CUGO_ND_LEAF": "1000", "CUGO_MAX_SUPER_COLS": "1", "CUGO_TARGET_TASKS": "100000"},
-                                 {"CUGO_MAX_SUPER_COLS": "24", "CUGO_ZERO_FRAC": "0.9", "CUGO_MIN_SUBTREE_TASKS": "0"}])
+                                 {"CUGO_MAX_SUPER_COLS": "24", "CUGO_ZERO_FRAC": "0.9", "CUGO_MIN_SUBTREE_TASKS": "0"},
+                                 # every level cut into 64x64 tiles (small problems otherwise take the 32x32 form)
+                                 {"CUGO_TILE32_MAX_TILES": "0"},
+                                 {"CUGO_TILE32_MAX_TILES": "0", "CUGO_ALIAS_CHAINS": "0", "CUGO_MAX_SUPER_COLS": "5"}])
 def test_sparse_cholesky_vs_numpy(ctx, env, monkeypatch):
     from test_host import covis_pattern, patterns, random_spd_bsr
     for k, v in env.items():

@@ -49,7 +49,13 @@ class Robust(C.Structure):
 
 class HscStruct(C.Structure):
     _fields_ = [("n_blocks", C.c_int), ("d_rowptr", C.c_void_p), ("d_colind", C.c_void_p),
-                ("d_off_ptr", C.c_void_p), ("d_off_ei", C.c_void_p), ("d_off_ej", C.c_void_p)]
+                ("d_off_ptr", C.c_void_p), ("d_off_ei", C.c_void_p), ("d_off_ej", C.c_void_p),
+                # landmark-major product plan (cugo_hsc_plan_create fills these; NULL = gather kernels)
+                ("n_groups", C.c_int), ("n_slots", C.c_int), ("n_rhs", C.c_int),
+                ("d_grp_ptr", C.c_void_p), ("d_grp_nwave", C.c_void_p), ("d_slot_rhs", C.c_void_p),
+                ("d_slot_ptr", C.c_void_p),
+                ("d_prod", C.c_void_p), ("d_red_ptr", C.c_void_p), ("d_red_slot", C.c_void_p),
+                ("d_blk_pose", C.c_void_p), ("d_part_H", C.c_void_p), ("d_part_b", C.c_void_p)]
 
 
 class SynthParams(C.Structure):
@@ -300,7 +306,7 @@ class Graph:
         n = lib().cugo_graph_structure_stats(self._g, _p(o, _f64p), 16)
         keys = ["hsc_blocks", "products", "nnzL", "chol_flops", "supernodes", "stages", "front_bytes",
                 "offdiag_products", "up_potrf_flops", "up_trsm_flops", "up_syrk_flops", "up_ea_bytes",
-                "backward_bytes"]
+                "backward_bytes", "schur_slots"]
         return dict(zip(keys[:n], o[:n].tolist()))
 
 

@@ -11,6 +11,7 @@
 #include "engine.h"
 #include "hip_util.h"
 #include "rccl_comm.h"
+#include "schur_plan.h"
 
 using namespace cugo_host;
 
@@ -156,6 +157,9 @@ int cugo_compute_schur(cugo_ctx* ctx, const cugo_edges* ev, const cugo_hsc_struc
                        double* d_invHll, void* d_T, double* d_bsc, double* d_Hsc)
 {
     return guarded([&] {
+        if (!d_T && !hs->d_grp_ptr)
+            throw std::runtime_error("cugo_compute_schur: d_T may only be NULL with a landmark-major plan "
+                                     "(cugo_hsc_plan_create); the gather kernels read T from memory");
         cugo_k::launch_schur(ctx->stream, *ev, *hs, lambda, damp_hsc_diag, d_Hpp, d_bp, d_Hll, d_bl,
                              d_Hpl, d_invHll, d_T, d_bsc, d_Hsc);
         CUGO_HIP(hipGetLastError());
@@ -326,6 +330,32 @@ int cugo_graph_create(int per_edge_information, int per_edge_camera, cugo_graph*
         *out = g.release();
     });
 }
+struct cugo_hsc_plan
+{
+    cugo_host::SchurPlanDevice dev;
+};
+int cugo_hsc_plan_create(cugo_ctx* ctx, int n_edges, int n_poses_free, const int32_t* h_pose, const int32_t* h_lm,
+                         const uint8_t* h_flags, const int32_t* h_rowptr, const int32_t* h_colind,
+                         cugo_hsc_struct* hs, cugo_hsc_plan** out)
+{
+    int rc = guarded([&] {
+        if (!ctx || !hs || !out)
+            throw std::runtime_error("cugo_hsc_plan_create: null argument");
+        *out = nullptr;
+        cugo_host::SchurPlanDevice::clear(*hs);
+        cugo_host::SchurPlanHost h;
+        cugo_host::build_schur_plan(n_edges, n_poses_free, h_pose, h_lm, h_flags, h_rowptr, h_colind, h);
+        if (!h.usable)
+            throw std::invalid_argument("cugo_hsc_plan_create: a landmark's active edges straddle two 256-slot groups");
+        auto p = std::make_unique<cugo_hsc_plan>();
+        p->dev.upload(h, ctx->stream);
+        p->dev.fill(*hs);
+        *out = p.release();
+    });
+    return rc;
+}
+void cugo_hsc_plan_destroy(cugo_hsc_plan* plan) { delete plan; }
+
 int cugo_graph_create_plan_only(int per_edge_information, int per_edge_camera, cugo_graph** out)
 {
     return guarded([&] {

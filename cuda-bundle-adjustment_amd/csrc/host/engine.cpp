@@ -18,6 +18,7 @@
 #include "chol_solver.h"
 #include "hip_util.h"
 #include "rccl_comm.h"
+#include "schur_plan.h"
 #include "thread_pool.h"
 
 namespace cugo_host
@@ -103,6 +104,8 @@ struct Engine::Impl : cugo_k::LaunchHook
 
     cugo_edges ev{};
     cugo_hsc_struct hs{};
+    SchurPlanDevice splan; // landmark-major product plan of the Schur complement (schur_plan.h)
+    bool splan_on = false;
     bool structure_dirty = true;
     uint64_t structure_sig = 0; // hash of the flattened topology the structure was built for
     // ... and the topology itself (compared on a hash hit), saved by build_structure()
@@ -635,7 +638,8 @@ void Engine::initialize(FlatGraph& g)
         const char* env = std::getenv("CUGO_FLOAT32");
         m.ev.block_f32 = (m.f32_blocks || (env && env[0] == '1')) ? 1 : 0;
         const size_t per_edge = m.ev.block_f32 ? 9 : 18;
-        m.d_Hpl.resize(per_edge * (size_t)E + 16), m.d_T.resize(per_edge * (size_t)E + 16);
+        m.d_Hpl.resize(per_edge * (size_t)E + 16);
+        m.d_T.release(); // allocated on demand (gather kernels only), see optimize()
     }
     m.d_x.resize(6 * (size_t)m.P + 3 * (size_t)m.L + 16);
     m.d_tmp.resize(36 * (size_t)m.P + 16);
@@ -830,6 +834,18 @@ void Engine::build_structure()
         m.hsc_rowptr[p + 1] += m.hsc_rowptr[p];
     const int B = (int)m.hsc_colind.size();
     laps.lap("structure: Hsc pattern");
+    // Landmark-major product plan (schur_plan.h), on request (CUGO_SCHUR_PLAN=1): every Hpl block is
+    // then read once per Schur complement and T is never written (284 MB instead of 730 MB of
+    // memory-side traffic on the kitti_00 shape) — but the kernel pair takes as long as the
+    // destination-major gather kernels (196 vs 192 us there: half of its partial slots hold a single
+    // product) and the plan costs 4 ms more to build, so the gather kernels stay the default
+    // (DESIGN.md section 4b).  Unusable if a landmark's active edges straddle two 256-slot groups.
+    SchurPlanHost sp;
+    if (std::getenv("CUGO_SCHUR_PLAN"))
+        build_schur_plan(m.E, P, m.h_e_pose.data(), m.h_e_lm.data(), m.h_flags.data(), m.hsc_rowptr.data(),
+                         m.hsc_colind.data(), sp);
+    m.splan_on = sp.usable;
+    laps.lap("structure: landmark-major product plan");
     // contribution lists of the off-diagonal blocks from the LOCAL edges, built row by row
     // (pose-major): pos[q] gives the slot of column q in the current row, so every product is
     // placed with O(1) work; inside a block the contributions are in ascending landmark order.
@@ -838,6 +854,7 @@ void Engine::build_structure()
         return (m.h_flags[e] & (CUGO_EDGE_FIXED_L | CUGO_EDGE_FIXED_P | CUGO_EDGE_INACTIVE)) == 0;
     };
     std::vector<int32_t> off_cnt(B + 1, 0);
+    if (!m.splan_on)
     parallel_rows([&](unsigned, int p0, int p1) {
         std::vector<int32_t> pos(P, -1);
         for (int p = p0; p < p1; p++)
@@ -861,6 +878,7 @@ void Engine::build_structure()
         off_cnt[k + 1] += off_cnt[k];
     const size_t Moff = (size_t)off_cnt[B];
     std::vector<int32_t> off_ei(Moff), off_ej(Moff);
+    if (!m.splan_on)
     {
         std::vector<int32_t> fill(off_cnt.begin(), off_cnt.end() - 1);
         parallel_rows([&](unsigned, int p0, int p1) {
@@ -888,6 +906,15 @@ void Engine::build_structure()
         });
     }
     laps.lap("structure: product lists");
+    // off-diagonal products: from the lists, or (plan) all products minus one per free-free edge
+    double n_offdiag = (double)Moff;
+    if (m.splan_on)
+    {
+        double nff = 0;
+        for (int e = 0; e < m.E; e++)
+            nff += free_free(e);
+        n_offdiag = (double)sp.prod.size() - nff;
+    }
     if (m.plan_only)
     {
         m.hs = cugo_hsc_struct{};
@@ -896,7 +923,8 @@ void Engine::build_structure()
         const auto t1p = Clock::now();
         m.chol.analyze(P, m.hsc_rowptr.data(), m.hsc_colind.data());
         prof_[PROF_SYMBOLIC] += ms_since(t1p);
-        fill_structure_stats(B, products, (double)Moff);
+        fill_structure_stats(B, products, n_offdiag);
+        sstats_.schur_slots = m.splan_on ? sp.n_slots : 0;
         return;
     }
     m.d_hsc_rowptr.upload(m.hsc_rowptr, s), m.d_hsc_colind.upload(m.hsc_colind, s);
@@ -907,6 +935,14 @@ void Engine::build_structure()
     m.hs.d_rowptr = m.d_hsc_rowptr.data(), m.hs.d_colind = m.d_hsc_colind.data();
     m.hs.d_off_ptr = m.d_off_ptr.data(), m.hs.d_off_ei = m.d_off_ei.data();
     m.hs.d_off_ej = m.d_off_ej.data();
+    if (m.splan_on)
+    {
+        m.splan.upload(sp, s);
+        m.splan.fill(m.hs);
+    }
+    else
+        SchurPlanDevice::clear(m.hs);
+    sstats_.schur_slots = m.splan_on ? sp.n_slots : 0;
     laps.lap("structure: uploads");
     prof_[PROF_BUILD_STRUCTURE] += ms_since(t0);
 
@@ -915,7 +951,7 @@ void Engine::build_structure()
     prof_[PROF_SYMBOLIC] += ms_since(t1);
     laps.lap("structure: symbolic + plan upload");
 
-    fill_structure_stats(B, products, (double)Moff);
+    fill_structure_stats(B, products, n_offdiag);
     m.structure_dirty = false;
 }
 
@@ -990,9 +1026,13 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
         {
             auto ts = Clock::now();
             m.timed("schur", [&] {
+                // T = Hpl invHll is only materialised for the gather kernels (the landmark-major
+                // plan keeps it in LDS)
+                if (!m.splan_on && m.d_T.size() == 0)
+                    m.d_T.resize((m.ev.block_f32 ? 9 : 18) * (size_t)m.E + 16);
                 cugo_k::launch_schur(s, m.ev, m.hs, lambda, 0, m.d_Hpp.data(), m.bp(),
                                      m.d_Hll.data(), m.bl(), m.d_Hpl.data(), m.d_invHll.data(),
-                                     m.d_T.data(), m.bsc(), m.Hsc());
+                                     m.splan_on ? nullptr : m.d_T.data(), m.bsc(), m.Hsc());
             });
             if (sharded)
                 m.exchange(m.d_sys.data(), 36 * (size_t)m.hs.n_blocks + 6 * (size_t)m.P, 0);

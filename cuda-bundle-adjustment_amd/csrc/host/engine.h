@@ -46,7 +46,7 @@ struct StructureStats
 {
     double hsc_blocks = 0, products = 0, nnzL = 0, chol_flops = 0, supernodes = 0, stages = 0,
            front_bytes = 0, offdiag_products = 0, up_potrf_flops = 0, up_trsm_flops = 0,
-           up_syrk_flops = 0, up_ea_bytes = 0, backward_bytes = 0;
+           up_syrk_flops = 0, up_ea_bytes = 0, backward_bytes = 0, schur_slots = 0;
 };
 
 enum ProfItem

@@ -667,6 +667,337 @@ __global__ __launch_bounds__(BS) void k_schur_edges(EV ev, double lambda,
     }
 }
 
+// ---------------------------------------------------------------- Schur: landmark-major -
+// k_schur_fused = k_schur_edges + the H-side and b-side products of the group's own landmarks.
+// (ref: computeBschureKernel + computeHschureKernel, src/cuda/cuda_block_solver.cu:1286-1345.)
+// The 256 Hpl blocks of the workgroup are in LDS anyway (36 KB); T = Hpl invHll is kept beside
+// them (36 KB) and every product T_a Hpl_b^T of the group's landmarks is formed from LDS: each Hpl
+// block is read from HBM ONCE for the whole Schur complement and T never has to be written (it
+// is, if the caller passes a T array: the C ABI's d_T output).
+// Products are summed per (group, destination block) — a "partial slot" of the host-built plan
+// (csrc/host/schur_plan.cpp) — by ONE group of 6 lanes (lane = row r of the 6x6 sum, 6 column
+// accumulators in registers), in list order: no atomics, fixed order.  A wave runs 10 such lane
+// groups at once.  Operand traffic per product and lane: 3 ds_read_b64 (its row of T_a) + 9
+// ds_read_b128 (Hpl_b, the same address for the 6 lanes: broadcast) for 18 FMAs.
+// k_hsc_reduce then adds the slots of every Hsc block in group order.
+constexpr int SF_LG = 10;        // lane groups per wave
+constexpr int SF_PCAP = 3072;    // products of a group staged in LDS (6 KB); longer lists are read from memory
+constexpr int SF_SCAP = 640;     // partial slots of a group whose list bounds are staged in LDS
+struct SchurPlanDev
+{
+    const int32_t* grp_ptr;
+    const int32_t* grp_nwave;
+    const int32_t* slot_rhs;
+    const int32_t* slot_ptr;
+    const uint16_t* prod;
+    double* part_H;
+    double* part_b;
+};
+
+// operands of one product for lane r of a lane group: its row of T_a and the whole Hpl_b
+struct SfOperands
+{
+    double t0, t1, t2;
+    double2 h[9];
+};
+__device__ __forceinline__ void sf_load(SfOperands& o, unsigned ab, int r, const double* __restrict__ hs,
+                                        const double* __restrict__ ts)
+{
+    const int a = ab & 255, b = ab >> 8;
+    const double* T = ts + 18 * a + r;
+    o.t0 = T[0], o.t1 = T[6], o.t2 = T[12];
+    const double2* H = reinterpret_cast<const double2*>(hs + 18 * b); // 144-B blocks: 16-B aligned
+#pragma unroll
+    for (int q = 0; q < 9; q++)
+        o.h[q] = H[q];
+}
+__device__ __forceinline__ void sf_fma(const SfOperands& o, double (&acc)[6])
+{
+    const double* hd = reinterpret_cast<const double*>(o.h);
+#pragma unroll
+    for (int c = 0; c < 6; c++)
+    { // (T_a Hpl_b^T)(r, c) = sum_m T_a(r, m) Hpl_b(c, m); blocks are 6x3 column-major
+        double sacc = o.t0 * hd[c];
+        sacc = fma(o.t1, hd[6 + c], sacc);
+        sacc = fma(o.t2, hd[12 + c], sacc);
+        acc[c] += sacc;
+    }
+}
+
+// Products i0, i0 + stride, ... < i1 of a slot, summed in that order.  Software pipeline, two
+// register sets in turn: the operands of the next product are read from LDS while the 18 FMAs of
+// the current one run (a lane group works through its list alone: nothing else hides the latency).
+// RHS: the slot is a diagonal block (a == b): also (T_a bl)(r).
+template <bool RHS>
+__device__ __forceinline__ void sf_slot_products(const uint16_t* __restrict__ pl, int i0, int i1, int stride, int r,
+                                                 const double* __restrict__ hs, const double* __restrict__ ts,
+                                                 const double* __restrict__ sbl, double (&acc)[6], double& rhs)
+{
+    if (i0 >= i1)
+        return;
+    SfOperands A, B;
+    // list entries are read two products ahead, operands one ahead: neither LDS latency is exposed
+    const int last = i1 - 1;
+    unsigned abA = pl[i0], abB = pl[min(i0 + stride, last)], abC = pl[min(i0 + 2 * stride, last)];
+    sf_load(A, abA, r, hs, ts);
+    int i = i0;
+    while (true)
+    {
+        // A holds product i, abB its successor's entry
+        const int in = i + stride;
+        const unsigned abD = pl[min(i + 3 * stride, last)];
+        if (in < i1)
+            sf_load(B, abB, r, hs, ts);
+        double l0 = 0, l1 = 0, l2 = 0;
+        if (RHS)
+        {
+            const double* bl3 = sbl + 3 * (abA & 255);
+            l0 = bl3[0], l1 = bl3[1], l2 = bl3[2];
+        }
+        sf_fma(A, acc);
+        if (RHS)
+            rhs += A.t0 * l0 + A.t1 * l1 + A.t2 * l2;
+        if (in >= i1)
+            break;
+        // B holds product in, abC the entry after it
+        const int in2 = in + stride;
+        const unsigned abE = pl[min(i + 4 * stride, last)];
+        if (in2 < i1)
+            sf_load(A, abC, r, hs, ts);
+        if (RHS)
+        {
+            const double* bl3 = sbl + 3 * (abB & 255);
+            l0 = bl3[0], l1 = bl3[1], l2 = bl3[2];
+        }
+        sf_fma(B, acc);
+        if (RHS)
+            rhs += B.t0 * l0 + B.t1 * l1 + B.t2 * l2;
+        if (in2 >= i1)
+            break;
+        abA = abC, abB = abD, abC = abE;
+        i = in2;
+    }
+}
+
+constexpr int SF_BS = 1024; // 16 waves on a 256-edge group (its LDS footprint allows one workgroup per CU anyway)
+constexpr int SF_LR = (9 * BS + SF_BS - 1) / SF_BS; // load rounds
+template <typename S>
+__global__ __launch_bounds__(SF_BS) void k_schur_fused(EV ev, double lambda, const double* __restrict__ Hll,
+                                                    const double* __restrict__ bl, const S* __restrict__ Hpl,
+                                                    double* __restrict__ invHll, S* __restrict__ T,
+                                                    SchurPlanDev pl)
+{
+    __shared__ double2 hs2[BS * 9];
+    __shared__ double2 ts2[BS * 9];
+    __shared__ double sbl[BS * 3];
+    __shared__ uint16_t sprod[SF_PCAP];
+    __shared__ int32_t sptr[SF_SCAP + 1], srhs[SF_SCAP];
+    __shared__ double wsc[SF_BS / 64][SF_LG * 6 * 7]; // per wave: the lane groups' sums of a long slot
+    const int t = threadIdx.x;
+    const int g = blockIdx.x, ebase = g * BS;
+    const int e = ebase + t;
+    const long nvalid = 9L * max(0, min(BS, ev.E - ebase)); // pairs of this block that exist
+    {
+        double2 v[SF_LR];
+#pragma unroll
+        for (int i = 0; i < SF_LR; i++)
+        {
+            const int idx = i * SF_BS + t; // 2304 pairs of the group's 256 blocks
+            v[i] = ld_pair(Hpl, 9 * (size_t)ebase + (size_t)min((long)min(idx, 9 * BS - 1), max(nvalid - 1, 0L)));
+        }
+#pragma unroll
+        for (int i = 0; i < SF_LR; i++)
+            if (i * SF_BS + t < 9 * BS)
+                hs2[i * SF_BS + t] = v[i];
+    }
+    const int s0 = pl.grp_ptr[g], s1 = pl.grp_ptr[g + 1];
+    const int p0 = pl.slot_ptr[s0], np = pl.slot_ptr[s1] - p0;
+    const bool staged = np <= SF_PCAP && s1 - s0 <= SF_SCAP;
+    if (staged)
+    {
+        for (int i = t; i < np; i += SF_BS)
+            sprod[i] = pl.prod[p0 + i];
+        for (int i = t; i <= s1 - s0; i += SF_BS)
+            sptr[i] = pl.slot_ptr[s0 + i] - p0;
+        for (int i = t; i < s1 - s0; i += SF_BS)
+            srhs[i] = pl.slot_rhs[s0 + i];
+    }
+    bool act = false;
+    Sym3 iv = {0, 0, 0, 0, 0, 0};
+    double b0 = 0, b1 = 0, b2 = 0;
+    if (t < BS && e < ev.E)
+    {
+        const int l = ev.lm[e];
+        if (l < ev.L) // fixed landmark: no Hll block
+        {
+            iv = sym3_inv(Hll + 9 * (size_t)l, lambda);
+            b0 = bl[3 * (size_t)l], b1 = bl[3 * (size_t)l + 1], b2 = bl[3 * (size_t)l + 2];
+            if (e == ev.lm_ptr[l])
+            {
+                double* o = invHll + 9 * (size_t)l;
+                o[0] = iv.b00, o[1] = iv.b01, o[2] = iv.b02;
+                o[3] = iv.b01, o[4] = iv.b11, o[5] = iv.b12;
+                o[6] = iv.b02, o[7] = iv.b12, o[8] = iv.b22;
+            }
+            act = !(ev.flags[e] & (CUGO_EDGE_FIXED_L | CUGO_EDGE_FIXED_P | CUGO_EDGE_INACTIVE));
+        }
+    }
+    if (t < BS)
+        sbl[3 * t] = b0, sbl[3 * t + 1] = b1, sbl[3 * t + 2] = b2;
+    __syncthreads();
+    double* hs = reinterpret_cast<double*>(hs2);
+    double* ts = reinterpret_cast<double*>(ts2);
+    if (t < BS)
+    {
+        const double* H = hs + 18 * t; // this lane's block
+        double* Tt = ts + 18 * t;
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+        {
+            const double a = H[r], b = H[6 + r], c = H[12 + r];
+            // edges without a T block (fixed endpoint, padding) hold zeros: no product refers to them
+            Tt[r] = act ? a * iv.b00 + b * iv.b01 + c * iv.b02 : 0.0;
+            Tt[6 + r] = act ? a * iv.b01 + b * iv.b11 + c * iv.b12 : 0.0;
+            Tt[12 + r] = act ? a * iv.b02 + b * iv.b12 + c * iv.b22 : 0.0;
+        }
+    }
+    __syncthreads();
+    if (T)
+    { // the reference's Hpl_invHll output, on request
+#pragma unroll
+        for (int i = 0; i < SF_LR; i++)
+        {
+            const int idx = i * SF_BS + t;
+            if (idx < nvalid)
+            {
+                const double2 v = ts2[idx];
+                st_pair(T, 9 * (size_t)ebase + idx, v.x, v.y);
+            }
+        }
+    }
+    // ---- products.  The group's slots come longest first (host plan).  The first n_wave of them
+    // (more than SF_LONG products: the diagonal blocks, mostly) are taken by a whole wave each: lane
+    // group lg forms every 10th product, the ten sums are added in lane-group order through LDS.
+    // The others go to single lane groups: s_w + u, s_w + u + 80, ...
+    const int lane = t & 63, w = t >> 6;
+    const int lg = lane / 6, r = lane - 6 * lg;
+    if (lg >= SF_LG)
+        return;
+    const int nwave = pl.grp_nwave[g];
+    for (int sl = s0 + w; sl < s0 + nwave; sl += SF_BS / 64)
+    {
+        const int i0 = staged ? sptr[sl - s0] : pl.slot_ptr[sl] - p0;
+        const int i1 = staged ? sptr[sl - s0 + 1] : pl.slot_ptr[sl + 1] - p0;
+        const int ri = staged ? srhs[sl - s0] : pl.slot_rhs[sl];
+        double acc[6] = {0, 0, 0, 0, 0, 0}, rhs = 0;
+        const uint16_t* plist = staged ? sprod : pl.prod + p0;
+        if (ri >= 0) // wave-uniform: the whole wave works on this slot
+            sf_slot_products<true>(plist, i0 + lg, i1, SF_LG, r, hs, ts, sbl, acc, rhs);
+        else
+            sf_slot_products<false>(plist, i0 + lg, i1, SF_LG, r, hs, ts, sbl, acc, rhs);
+        double* sc = wsc[w] + (6 * lg + r) * 7;
+#pragma unroll
+        for (int c = 0; c < 6; c++)
+            sc[c] = acc[c];
+        sc[6] = rhs;
+        // wavefront scope: a wave's LDS operations complete in order, only the compiler must not
+        // move them (a workgroup-scope fence would also wait for the partial stores in flight)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lg == 0)
+        {
+            double tot[7] = {0, 0, 0, 0, 0, 0, 0};
+            for (int g2 = 0; g2 < SF_LG; g2++)
+#pragma unroll
+                for (int c = 0; c < 7; c++)
+                    tot[c] += wsc[w][(6 * g2 + r) * 7 + c];
+            double* o = pl.part_H + 36 * (size_t)sl;
+#pragma unroll
+            for (int c = 0; c < 6; c++)
+                o[6 * c + r] = tot[c];
+            if (ri >= 0)
+                pl.part_b[6 * (size_t)ri + r] = tot[6];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    const int unit = w * SF_LG + lg;
+    for (int sl = s0 + nwave + unit; sl < s1; sl += (SF_BS / 64) * SF_LG)
+    {
+        const int i0 = staged ? sptr[sl - s0] : pl.slot_ptr[sl] - p0;
+        const int i1 = staged ? sptr[sl - s0 + 1] : pl.slot_ptr[sl + 1] - p0;
+        const int ri = staged ? srhs[sl - s0] : pl.slot_rhs[sl];
+        double acc[6] = {0, 0, 0, 0, 0, 0}, rhs = 0;
+        const uint16_t* plist = staged ? sprod : pl.prod + p0;
+        if (ri >= 0)
+            sf_slot_products<true>(plist, i0, i1, 1, r, hs, ts, sbl, acc, rhs);
+        else
+            sf_slot_products<false>(plist, i0, i1, 1, r, hs, ts, sbl, acc, rhs);
+        double* o = pl.part_H + 36 * (size_t)sl;
+#pragma unroll
+        for (int c = 0; c < 6; c++)
+            o[6 * c + r] = acc[c];
+        if (ri >= 0)
+            pl.part_b[6 * (size_t)ri + r] = rhs;
+    }
+}
+
+// Hsc[k] = [Hpp(p) (+ lambda I)] - sum of the block's partial slots (group order);
+// bsc[p] = bp[p] - sum of the rhs partials of the diagonal block.  One wave per Hsc block, lane =
+// element: a slot is 288 contiguous bytes.
+__global__ __launch_bounds__(BS) void k_hsc_reduce(int nblocks, const int32_t* __restrict__ red_ptr,
+                                                   const int32_t* __restrict__ red_slot,
+                                                   const int32_t* __restrict__ slot_rhs,
+                                                   const int32_t* __restrict__ blk_pose,
+                                                   const double* __restrict__ part_H,
+                                                   const double* __restrict__ part_b, double lambda_diag,
+                                                   const double* __restrict__ Hpp, const double* __restrict__ bp,
+                                                   double* __restrict__ Hsc, double* __restrict__ bsc)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int k = blockIdx.x * (BS / 64) + w;
+    if (k >= nblocks)
+        return;
+    const int p = blk_pose[k]; // (all 64 lanes stay: each holds a slot id for the shuffles below)
+    const int q0 = red_ptr[k], q1 = red_ptr[k + 1];
+    const int el = lane < 36 ? lane : min(lane - 36, 5); // element of H (lanes 0..35) or of the rhs (36..41)
+    double sum = 0;
+    for (int qb = q0; qb < q1; qb += 64)
+    { // the slot ids of up to 64 slots with one coalesced load, then eight partial loads in flight
+        const int n = min(64, q1 - qb);
+        const int mine = red_slot[qb + min(lane, n - 1)];
+        const int mine_rhs = (p >= 0) ? slot_rhs[mine] : 0;
+        for (int u0 = 0; u0 < n; u0 += 8)
+        {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+            {
+                const int src = min(u0 + u, n - 1);
+                const int sl = __shfl(mine, src), rh = __shfl(mine_rhs, src);
+                v[u] = lane < 36 ? part_H[36 * (size_t)sl + el] : (p >= 0 ? part_b[6 * (size_t)rh + el] : 0.0);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (u0 + u < n)
+                    sum += v[u];
+        }
+    }
+    if (lane < 36)
+    {
+        double val = -sum;
+        if (p >= 0)
+        {
+            val += Hpp[36 * (size_t)p + lane];
+            if (lane % 7 == 0) // diagonal element of the 6x6 block
+                val += lambda_diag;
+        }
+        Hsc[36 * (size_t)k + lane] = val;
+    }
+    else if (p >= 0 && lane < 42)
+        bsc[6 * (size_t)p + el] = bp[6 * (size_t)p + el] - sum;
+}
+
 // ---------------------------------------------------------------- Schur: diagonal ------
 // Hsc(p,p) = Hpp[p] (+lambda I) - sum_e T_e Hpl_e^T ; bsc[p] = bp[p] - sum_e T_e bl[l(e)]
 // One workgroup per pose, its edge list dealt to the four waves in chunks of 7 edges.  As in
@@ -1119,6 +1450,18 @@ static void launch_schur_t(hipStream_t s, const cugo_edges& e, const cugo_hsc_st
                            double* d_bsc, double* d_Hsc)
 {
     const EV ev = make_ev(e);
+    if (hs.d_grp_ptr && hs.n_groups == div_up(ev.E, BS))
+    {
+        const SchurPlanDev pl{hs.d_grp_ptr, hs.d_grp_nwave, hs.d_slot_rhs, hs.d_slot_ptr, hs.d_prod, hs.d_part_H, hs.d_part_b};
+        if (ev.E > 0)
+            CUGO_LAUNCH_T(k_schur_fused, S, dim3(hs.n_groups), dim3(SF_BS), 0, s, ev, lambda, d_Hll, d_bl, d_Hpl,
+                          d_invHll, d_T, pl);
+        if (hs.n_blocks > 0)
+            CUGO_LAUNCH(k_hsc_reduce, dim3(div_up(hs.n_blocks, BS / 64)), dim3(BS), 0, s, hs.n_blocks, hs.d_red_ptr,
+                        hs.d_red_slot, hs.d_slot_rhs, hs.d_blk_pose, hs.d_part_H, hs.d_part_b,
+                        damp_hsc_diag ? lambda : 0.0, d_Hpp, d_bp, d_Hsc, d_bsc);
+        return;
+    }
     if (ev.E > 0)
         CUGO_LAUNCH_T(k_schur_edges, S, dim3(div_up(ev.E, BS)), dim3(BS), 0, s, ev, lambda, d_Hll,
                       d_Hpl, d_invHll, d_T);

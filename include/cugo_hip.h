@@ -142,7 +142,36 @@ typedef struct cugo_hsc_struct
     const int32_t* d_off_ptr; /* [B+1] (empty range for diagonal blocks) */
     const int32_t* d_off_ei;  /* [M_off] */
     const int32_t* d_off_ej;  /* [M_off] */
+    /* Landmark-major product plan (optional: with d_grp_ptr == NULL cugo_compute_schur gathers the
+     * products destination-major through the contribution lists above).  A group = 256 consecutive
+     * edge slots; the products of a group's landmarks are summed per (group, Hsc block) into a
+     * partial slot, the slots of every block are then added in group order.  Built by
+     * cugo_hsc_plan_create(); requires that no landmark has active edges in two groups. */
+    int n_groups;                /* ceil(n_edges / 256) */
+    int n_slots, n_rhs;
+    const int32_t* d_grp_ptr;    /* [n_groups+1] partial slots of each group (longest product list first) */
+    const int32_t* d_grp_nwave;  /* [n_groups] leading slots of the group that a whole wave works on */
+    const int32_t* d_slot_rhs;   /* [n_slots] index of the slot's rhs partial (diagonal block) or -1 */
+    const int32_t* d_slot_ptr;   /* [n_slots+1] product range of each slot */
+    const uint16_t* d_prod;      /* [M] a | b << 8: slots (within the group) of the T and Hpl operand */
+    const int32_t* d_red_ptr;    /* [B+1] partial slots of every Hsc block ... */
+    const int32_t* d_red_slot;   /* [n_slots] ... in group order */
+    const int32_t* d_blk_pose;   /* [B] pose of a diagonal block, -1 otherwise */
+    double* d_part_H;            /* [n_slots][36] scratch */
+    double* d_part_b;            /* [n_rhs][6] scratch */
 } cugo_hsc_struct;
+
+/* Builds the landmark-major plan of a flattened edge set on the host and uploads it (ref: the device
+ * structure set-up findHschureMulBlockIndices, src/cuda/cuda_block_solver.cu:1347-1378,1606-1634).
+ * h_* are HOST arrays: the edge slots (pose index, landmark index, flags; landmark-major) and the
+ * Hsc pattern.  Fills the plan fields of *hs (the pattern / contribution-list fields are left
+ * alone).  Returns CUGO_ERR_INVALID, with the plan fields cleared, when a landmark's active edges
+ * straddle two 256-slot groups: cugo_compute_schur then takes the gather kernels. */
+typedef struct cugo_hsc_plan cugo_hsc_plan;
+int cugo_hsc_plan_create(cugo_ctx* ctx, int n_edges, int n_poses_free, const int32_t* h_pose,
+                         const int32_t* h_lm, const uint8_t* h_flags, const int32_t* h_rowptr,
+                         const int32_t* h_colind, cugo_hsc_struct* hs, cugo_hsc_plan** out);
+void cugo_hsc_plan_destroy(cugo_hsc_plan* plan);
 
 /* ref: gpu::addLambda(Hll) + gpu::computeBschure + gpu::computeHschure
  * (cuda_block_solver.h:83-109; .cu:1256-1345).  Damping is applied on the fly (Hpp/Hll are
@@ -150,7 +179,9 @@ typedef struct cugo_hsc_struct
  *   d_invHll [Lfree][9] = (Hll + lambda I)^-1,  d_T [E][18] = Hpl * invHll,
  *   d_bsc [Pfree][6] = bp - sum T bl,
  *   d_Hsc [B][36] = Hpp(diag) - sum T Hpl^T            (+ lambda I on diagonal blocks when
- *   damp_hsc_diag != 0, which reproduces the reference's damped Hsc exactly). */
+ *   damp_hsc_diag != 0, which reproduces the reference's damped Hsc exactly).
+ * With a landmark-major plan in *hs (cugo_hsc_plan_create) the products are formed inside the edge
+ * pass and d_T may be NULL (T is then never written). */
 int cugo_compute_schur(cugo_ctx* ctx, const cugo_edges* ev, const cugo_hsc_struct* hs,
                        double lambda, int damp_hsc_diag, const double* d_Hpp, const double* d_bp,
                        const double* d_Hll, const double* d_bl, const void* d_Hpl,

@@ -92,7 +92,7 @@ def hsc_structure(f):
     """upper block CSR pattern + off-diagonal contribution lists (numpy restatement of
     ref src/sparse_block_matrix.cpp:63-156 and findHschureMulBlockIndices)."""
     P = f["P"]
-    ff = (f["flags"] & 3) == 0
+    ff = (f["flags"] & 11) == 0  # free-free and active
     rows = [set([p]) for p in range(P)]
     per_lm = []
     for l in range(f["L"]):
@@ -122,3 +122,51 @@ def hsc_structure(f):
     ei = np.array([a for x in lists for a, _ in x], np.int32)
     ej = np.array([b for x in lists for _, b in x], np.int32)
     return rowptr, colind, off_ptr, ei, ej
+
+
+def pad_to_groups(f, group=256):
+    """the engine's slot layout (csrc/host/engine.cpp): INACTIVE padding slots are inserted so that
+    no landmark with <= `group` edges straddles a `group`-slot boundary; a padding slot belongs to
+    the landmark before it.  Returns a new flattened dict (same keys as flatten())."""
+    E0 = f["E"]
+    src_of = []  # per new slot: old slot or -1
+    lm_of = []
+    pos = 0
+    last_lm = -1
+    for l in range(f["Lall"]):
+        a, b = int(f["lm_ptr"][l]), int(f["lm_ptr"][l + 1])
+        k = b - a
+        if k > 0 and k <= group and pos % group + k > group and last_lm >= 0:
+            npad = group - pos % group
+            src_of += [-1] * npad
+            lm_of += [last_lm] * npad
+            pos += npad
+        src_of += list(range(a, b))
+        lm_of += [l] * k
+        pos += k
+        if k > 0:
+            last_lm = l
+    src_of = np.array(src_of, np.int64)
+    real = src_of >= 0
+    E = len(src_of)
+    g = dict(f)
+    g["E"] = E
+    take = np.where(real, src_of, 0)
+    g["pose"] = np.where(real, f["pose"][take], 0).astype(np.int32)
+    g["lm"] = np.array(lm_of, np.int32)
+    g["flags"] = np.where(real, f["flags"][take], 8).astype(np.uint8)
+    g["meas"] = np.ascontiguousarray(np.where(real[None, :], f["meas"][:, take], 0.0))
+    g["omega"] = np.ascontiguousarray(np.where(real, f["omega"][take], 0.0))
+    g["cam_id"] = np.where(real, f["cam_id"][take], 0).astype(np.uint16)
+    g["src"] = np.where(real, f["src"][take], -1)
+    lm_ptr = np.zeros(f["Lall"] + 1, np.int32)
+    np.add.at(lm_ptr, g["lm"] + 1, 1)
+    g["lm_ptr"] = np.cumsum(lm_ptr).astype(np.int32)
+    slots = np.flatnonzero(real)
+    order = np.lexsort((g["lm"][slots], g["pose"][slots]))
+    g["pose_edge"] = np.concatenate([slots[order], np.zeros(E - len(slots), np.int64)]).astype(np.int32)
+    pose_ptr = np.zeros(f["Pall"] + 1, np.int32)
+    np.add.at(pose_ptr, g["pose"][slots] + 1, 1)
+    g["pose_ptr"] = np.cumsum(pose_ptr).astype(np.int32)
+    assert E >= E0 and int(real.sum()) == E0
+    return g

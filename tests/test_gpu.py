@@ -154,6 +154,81 @@ def test_schur_complement_and_backsubst_vs_oracle(ctx, oracle_lib):
     cugo.lib().cugo_chol_destroy(s)
 
 
+@pytest.mark.parametrize("f32", [False, True])
+def test_schur_landmark_major_plan_vs_gather_and_oracle(ctx, oracle_lib, f32):
+    """cugo_hsc_plan_create + cugo_compute_schur: the landmark-major form of the Schur complement
+    (products formed from LDS inside the edge pass, per-group partial slots, ordered reduction)
+    against the destination-major gather kernels on the same padded layout and against the
+    oracle's dense Schur complement; also the optional T output and the refusal of layouts in
+    which a landmark straddles two 256-slot groups."""
+    import devmem
+    prob = mixed_problem(oracle_lib, seed=8, n_poses=40, n_landmarks=900, mean_obs=4.2)
+    f0 = devmem.flatten(prob)
+    L = cugo.lib()
+    # un-padded layout: some landmark straddles a group boundary -> the plan is refused
+    rowptr, colind, off_ptr, ei, ej = devmem.hsc_structure(f0)
+    hs0 = cugo.HscStruct()
+    plan0 = C.c_void_p()
+    as_p = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    rc = L.cugo_hsc_plan_create(ctx.h, f0["E"], f0["P"], as_p(f0["pose"], C.c_int32), as_p(f0["lm"], C.c_int32),
+                                as_p(f0["flags"], C.c_uint8), as_p(rowptr, C.c_int32), as_p(colind, C.c_int32),
+                                C.byref(hs0), C.byref(plan0))
+    assert rc == -3 and not plan0 and not hs0.d_grp_ptr   # CUGO_ERR_INVALID
+    f = devmem.pad_to_groups(f0)
+    assert f["E"] > f0["E"]
+    ev = devmem.upload_edges(ctx, f)
+    ev.block_f32 = int(f32)
+    rowptr, colind, off_ptr, ei, ej = devmem.hsc_structure(f)
+    B, P, Lf, E = len(colind), f["P"], f["L"], f["E"]
+    blk = np.float32 if f32 else np.float64
+    d = dict(poses=ctx.to_dev(f["poses"]), lms=ctx.to_dev(f["lms"]), Hpp=ctx.empty(36 * P), bp=ctx.empty(6 * P),
+             Hll=ctx.empty(9 * Lf), bl=ctx.empty(3 * Lf), Hpl=ctx.empty(18 * E, blk), chi=ctx.empty(4))
+    cugo.check(L.cugo_construct_quadratic_form(ctx.h, C.byref(ev), d["poses"], d["lms"], RK0, d["Hpp"], d["bp"],
+                                               d["Hll"], d["bl"], d["Hpl"], d["chi"]))
+    lam = 2.25
+    out = {}
+    for mode in ("gather", "plan"):
+        hs = cugo.HscStruct(B, ctx.to_dev(rowptr), ctx.to_dev(colind), ctx.to_dev(off_ptr), ctx.to_dev(ei),
+                            ctx.to_dev(ej))
+        plan = C.c_void_p()
+        if mode == "plan":
+            cugo.check(L.cugo_hsc_plan_create(ctx.h, E, P, as_p(f["pose"], C.c_int32), as_p(f["lm"], C.c_int32),
+                                              as_p(f["flags"], C.c_uint8), as_p(rowptr, C.c_int32),
+                                              as_p(colind, C.c_int32), C.byref(hs), C.byref(plan)))
+            assert hs.d_grp_ptr and hs.n_groups == (E + 255) // 256 and hs.n_slots >= hs.n_rhs > 0
+        inv, T, bsc, Hsc = ctx.empty(9 * Lf), ctx.empty(18 * E, blk), ctx.empty(6 * P), ctx.empty(36 * B)
+        cugo.check(L.cugo_compute_schur(ctx.h, C.byref(ev), C.byref(hs), C.c_double(lam), 1, d["Hpp"], d["bp"],
+                                        d["Hll"], d["bl"], d["Hpl"], inv, T, bsc, Hsc))
+        out[mode] = dict(H=ctx.to_host(Hsc, (B, 36)), b=ctx.to_host(bsc, 6 * P), T=ctx.to_host(T, (E, 18), blk),
+                         inv=ctx.to_host(inv, (Lf, 9)))
+        if mode == "plan":
+            # without a T array (what the engine does): same Hsc / bsc
+            Hsc2, bsc2 = ctx.empty(36 * B), ctx.empty(6 * P)
+            cugo.check(L.cugo_compute_schur(ctx.h, C.byref(ev), C.byref(hs), C.c_double(lam), 1, d["Hpp"], d["bp"],
+                                            d["Hll"], d["bl"], d["Hpl"], inv, None, bsc2, Hsc2))
+            assert np.array_equal(ctx.to_host(Hsc2, (B, 36)), out["plan"]["H"])
+            assert np.array_equal(ctx.to_host(bsc2, 6 * P), out["plan"]["b"])
+            L.cugo_hsc_plan_destroy(plan)
+    scale = np.abs(out["gather"]["H"]).max()
+    # float block storage: the gather kernels read T rounded to float, the plan keeps it in fp64
+    tol = 2e-6 if f32 else 1e-13
+    np.testing.assert_allclose(out["plan"]["H"], out["gather"]["H"], rtol=0, atol=tol * scale)
+    np.testing.assert_allclose(out["plan"]["b"], out["gather"]["b"], rtol=0, atol=tol * np.abs(out["gather"]["b"]).max())
+    assert np.array_equal(out["plan"]["T"], out["gather"]["T"]) and np.array_equal(out["plan"]["inv"], out["gather"]["inv"])
+    if not f32:
+        Href, bref = prob.schur_dense(lam)
+        dense = np.zeros_like(Href)
+        for r in range(P):
+            for k in range(rowptr[r], rowptr[r + 1]):
+                c = colind[k]
+                b6 = out["plan"]["H"][k].reshape(6, 6).T
+                dense[6 * r:6 * r + 6, 6 * c:6 * c + 6] = b6
+                if c != r:
+                    dense[6 * c:6 * c + 6, 6 * r:6 * r + 6] = b6.T
+        np.testing.assert_allclose(dense, Href, rtol=0, atol=1e-11 * np.abs(Href).max())
+        np.testing.assert_allclose(out["plan"]["b"], bref, rtol=0, atol=1e-11 * np.abs(bref).max())
+
+
 def test_float32_block_kernels_vs_oracle(ctx, oracle_lib):
     """cugo_edges.block_f32 = 1 (fp32-internal mode, BASELINE config 5): Hpl and T = Hpl invHll are
     float arrays, everything else stays fp64.  Stated tolerance at kernel level: the stored blocks
@@ -324,6 +399,21 @@ def test_medium_synthetic_vs_oracle(oracle_lib, subtree_stage, monkeypatch):
     assert rmse(out["lm"], prob.lm) < 1e-9
     assert out["nedges"] == 33000
     assert out["stats"][-1]["chi2"] < out["stats"][0]["chi2"]
+
+
+def test_landmark_major_schur_plan_end_to_end(oracle_lib, monkeypatch):
+    """CUGO_SCHUR_PLAN=1: the engine takes the landmark-major form of the Schur complement
+    (k_schur_fused + k_hsc_reduce, no T array) — same trajectory as the oracle, sharded too"""
+    monkeypatch.setenv("CUGO_SCHUR_PLAN", "1")
+    d, prob = synth_problem(oracle_lib, 400, 8000, 33000, seed=11, lc=200)
+    out = run_graph(d, 10)
+    ref = prob.optimize(10)
+    assert out["sstats"]["schur_slots"] > 0
+    assert_trajectories_match(out["stats"], ref, 1e-10)
+    assert rmse(out["pose"], prob.pose) < 1e-9 and rmse(out["lm"], prob.lm) < 1e-9
+    res = run_sharded_in_threads(d, 2, 6)
+    for r in range(2):
+        assert_trajectories_match(res[r]["stats"], ref[:6], 1e-10)
 
 
 def test_outlier_rejection_matches_oracle(oracle_lib):

@@ -247,6 +247,10 @@ class Graph:
     def initialize(self):
         check(lib().cugo_graph_initialize(self._g))
 
+    def flatten_reuses(self):
+        """initialize() calls that found the graph unchanged and only refreshed the estimates"""
+        return lib().cugo_graph_flatten_reuses(self._g)
+
     def optimize(self, n):
         check(lib().cugo_graph_optimize(self._g, int(n)))
 

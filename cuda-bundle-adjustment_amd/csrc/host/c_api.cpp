@@ -548,6 +548,7 @@ int cugo_graph_initialize(cugo_graph* g)
         g->opt->initialize();
     });
 }
+int cugo_graph_flatten_reuses(cugo_graph* g) { return g->opt->flattenReuses(); }
 int cugo_graph_optimize(cugo_graph* g, int n_iters)
 {
     return guarded([&] { g->opt->optimize(n_iters); });

@@ -739,6 +739,29 @@ void Engine::fill_structure_stats(int B, double products, double offdiag_product
     sstats_.backward_bytes = m.chol.plan.backward_bytes;
 }
 
+void Engine::refresh_estimates(const FlatGraph& g)
+{
+    const auto t0 = Clock::now();
+    Impl& m = *impl_;
+    if ((int)(g.poses.size() / 7) != m.Pall || (int)(g.lms.size() / 3) != m.Lall)
+        throw std::runtime_error("cugo: refresh_estimates on another graph");
+    m.last_err_buf = 0;
+    m.xchg_bytes = 0, m.xchg_calls = 0;
+    m.cur = 0;
+    if (!m.plan_only)
+    {
+        hipStream_t s = m.ctx.stream;
+        for (int k = 0; k < 2; k++)
+        {
+            m.d_poses[k].upload(g.poses, s);
+            m.d_lms[k].upload(g.lms, s);
+        }
+        m.d_x.zero(s);
+        CUGO_HIP(hipStreamSynchronize(s)); // the staging vectors may change after return
+    }
+    prof_[PROF_INITIALIZE] += ms_since(t0);
+}
+
 // Hsc pattern from landmark co-visibility + contribution lists + Cholesky analysis
 // (ref: buildStructure, block_solver.cpp:139-248)
 void Engine::build_structure()

@@ -86,6 +86,9 @@ public:
     // effect at the next initialize().  The environment variable CUGO_FLOAT32=1 forces it on.
     void set_float32_blocks(bool on);
     void initialize(FlatGraph& g);
+    // same graph as at the last initialize(), new estimates (g.poses / g.lms): the flattened edge
+    // arrays, the structure and the symbolic factor on the device stay as they are
+    void refresh_estimates(const FlatGraph& g);
     // a FlatGraph owned by the engine whose buffers survive between initialize() calls
     FlatGraph& staging();
     // ref: optimize(); appends to records. verbose prints one line per iteration.

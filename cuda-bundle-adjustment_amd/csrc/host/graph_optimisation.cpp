@@ -117,6 +117,40 @@ void CudaGraphOptimisationImpl::initialize()
     };
     engine_->set_float32_blocks(options.useFloat32);
     FlatGraph& g = engine_->staging();
+    // ---- unchanged graph: only the estimates are refreshed -------------------------------
+    // If no vertex set or edge set has counted a change since the last full flattening (see
+    // "change tracking" in optimisable_graph.h: everything except vertex estimates counts), the
+    // flattened, landmark-major graph on the device still is the graph held by these objects.
+    // This is the reference fork's isDirty idea (src/block_solver.cpp:151-216 skips the structure
+    // rebuild for clean edge sets) carried over to the flattening itself: SLAM back ends — and the
+    // reference's own sample, main.cpp:168-190 — call initialize() again on an unchanged graph.
+    // CUGO_NO_FLATTEN_REUSE=1 turns it off.
+    {
+        bool same = flattenValid_ && !std::getenv("CUGO_NO_FLATTEN_REUSE") && !std::getenv("CUGO_NO_STRUCTURE_REUSE") &&
+                    flattenOptions_[0] == options.perEdgeInformation && flattenOptions_[1] == options.perEdgeCamera &&
+                    flattenOptions_[2] == options.useFloat32 &&
+                    flattenCounts_.size() == vertexSets.size() + edgeSets.size();
+        size_t q = 0;
+        for (size_t i = 0; same && i < vertexSets.size(); i++, q++)
+            same = flattenCounts_[q].first == vertexSets[i] && flattenCounts_[q].second == vertexSets[i]->changeCount();
+        for (size_t i = 0; same && i < edgeSets.size(); i++, q++)
+            same = flattenCounts_[q].first == edgeSets[i] && flattenCounts_[q].second == edgeSets[i]->changeCount();
+        if (same)
+        {
+            for (BaseVertexSet* vs : vertexSets)
+                vs->gatherEstimates(vs->isMarginilised() ? g.lms.data() : g.poses.data());
+            lap("graph: estimates only");
+            for (BaseEdgeSet* es : edgeSets)
+                es->setOutlierCount(0);
+            engine_->refresh_estimates(g);
+            flattenReuses_++;
+            lap("graph: engine refresh");
+            stats_.clear();
+            trace_.clear();
+            return;
+        }
+        flattenValid_ = false;
+    }
     g.cams.clear();
     // ---- vertex indices: free first (ascending id), fixed after -------------------------
     int nPfree = 0, nLfree = 0, nP = 0, nL = 0;
@@ -185,7 +219,7 @@ void CudaGraphOptimisationImpl::initialize()
         if (dim != 2 && dim != 3)
             throw std::runtime_error("cugo: only 2-d (mono) and 3-d (stereo) BA edge sets are supported");
         const uint8_t stereo_bit = dim == 3 ? CUGO_EDGE_STEREO : 0;
-        const RobustKernel& k = es->getRobustKernel();
+        const RobustKernel& k = es->robustKernelData();
         if (dim == 3)
             rk.type_stereo = rk_code(k.type()), rk.delta_stereo = k.delta();
         else
@@ -193,8 +227,8 @@ void CudaGraphOptimisationImpl::initialize()
         const double set_threshold = es->getOutlierThreshold();
         any_threshold = any_threshold || set_threshold > 0.0;
         es->setOutlierCount(0);
-        const double set_info = es->getInformation();
-        const Camera set_cam = es->getCamera();
+        const double set_info = es->informationValue();
+        const Camera set_cam = es->cameraData();
         const EdgeContainer& ec = es->get();
         const size_t n = ec.size();
         const unsigned nthreads = n < 20000 ? 1u : hw;
@@ -233,15 +267,15 @@ void CudaGraphOptimisationImpl::initialize()
                 g.e_pose[o] = vp->getIndex();
                 g.e_lm[o] = vl->getIndex();
                 g.e_flags[o] = (uint8_t)((fl ? CUGO_EDGE_FIXED_L : 0) | (fp ? CUGO_EDGE_FIXED_P : 0) | stereo_bit);
-                const double* mz = static_cast<const double*>(e->getMeasurement());
+                const double* mz = static_cast<const double*>(e->measurementData());
                 g.e_meas[3 * o] = mz[0];
                 g.e_meas[3 * o + 1] = mz[1];
                 g.e_meas[3 * o + 2] = dim == 3 ? mz[2] : 0.0;
-                const double w = perInfo ? (double)e->getInformation() : set_info;
+                const double w = perInfo ? (double)e->informationValue() : set_info;
                 if (o > c.begin && w != g.e_omega[c.begin])
                     c.uniform = false;
                 g.e_omega[o] = w;
-                const Camera& cm = perCam ? e->getCamera() : set_cam;
+                const Camera& cm = perCam ? e->cameraData() : set_cam;
                 const double cv[5] = {cm.fx, cm.fy, cm.cx, cm.cy, cm.bf};
                 // deduplicate cameras: last-hit fast path, then a short linear scan
                 int ci = -1;
@@ -351,6 +385,15 @@ void CudaGraphOptimisationImpl::initialize()
     lap("graph: engine initialize");
     stats_.clear();
     trace_.clear();
+    // what this flattening was made from (compared by the next initialize())
+    flattenCounts_.clear();
+    for (BaseVertexSet* vs : vertexSets)
+        flattenCounts_.emplace_back(vs, vs->changeCount());
+    for (BaseEdgeSet* es : edgeSets)
+        flattenCounts_.emplace_back(es, es->changeCount());
+    flattenOptions_[0] = options.perEdgeInformation, flattenOptions_[1] = options.perEdgeCamera;
+    flattenOptions_[2] = options.useFloat32;
+    flattenValid_ = true;
 }
 
 void CudaGraphOptimisationImpl::optimize(int niterations)

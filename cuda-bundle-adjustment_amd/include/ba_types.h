@@ -15,14 +15,24 @@ namespace cugo
 class CUGO_API MonoEdge : public Edge<2, Vec2d, PoseVertex, LandmarkVertex>
 {
 public:
-    void* getMeasurement() noexcept override { return static_cast<void*>(measurement.data); }
+    void* getMeasurement() noexcept override
+    {
+        touchOwner(); // mutable pointer: counts as a change (optimisable_graph.h, change tracking)
+        return static_cast<void*>(measurement.data);
+    }
+    const void* measurementData() const noexcept override { return static_cast<const void*>(measurement.data); }
 };
 
 /** stereo observation: measurement (u, v, u_right) */
 class CUGO_API StereoEdge : public Edge<3, Vec3d, PoseVertex, LandmarkVertex>
 {
 public:
-    void* getMeasurement() noexcept override { return static_cast<void*>(measurement.data); }
+    void* getMeasurement() noexcept override
+    {
+        touchOwner();
+        return static_cast<void*>(measurement.data);
+    }
+    const void* measurementData() const noexcept override { return static_cast<const void*>(measurement.data); }
 };
 
 class CUGO_API MonoEdgeSet : public EdgeSet<2, Vec2d, PoseVertex, LandmarkVertex>

@@ -116,8 +116,16 @@ public:
     BatchStatistics& batchStatistics() override { return stats_; }
     const TimeProfile& timeProfile() override;
     size_t nVertices(const int id) override { return vertexSets.at(id)->size(); }
-    void clearEdgeSets() override { edgeSets.clear(); }
-    void clearVertexSets() override { vertexSets.clear(); }
+    void clearEdgeSets() override
+    {
+        edgeSets.clear();
+        flattenValid_ = false;
+    }
+    void clearVertexSets() override
+    {
+        vertexSets.clear();
+        flattenValid_ = false;
+    }
     void setVerbose(bool status) override { verbose = status; }
     void setProfile(bool status) override { shouldProfile_ = status; }
 
@@ -137,6 +145,8 @@ public:
     void kernelTimes(std::vector<std::string>& names, std::vector<double>& ms, std::vector<int>& launches) const;
     /** GraphOptimisationOptions::useFloat32 after construction; takes effect at the next initialize() */
     void setUseFloat32(bool on) { options.useFloat32 = on; }
+    /** initialize() calls that found the graph unchanged and refreshed only the estimates */
+    int flattenReuses() const { return flattenReuses_; }
     bool useFloat32() const { return options.useFloat32; }
 
 private:
@@ -149,6 +159,12 @@ private:
     BatchStatistics stats_;
     std::vector<LmTrace> trace_;
     TimeProfile timeProfile_;
+    // change counts of the sets at the last full flattening (initialize() refreshes only the
+    // estimates while they stand)
+    std::vector<std::pair<const void*, unsigned long long>> flattenCounts_;
+    bool flattenOptions_[3] = {false, false, false};
+    bool flattenValid_ = false;
+    int flattenReuses_ = 0;
     // edges handed to the engine at initialize(), in that order (outlier rejection maps back)
     std::vector<BaseEdge*> flatEdges_;
     std::vector<BaseEdgeSet*> flatEdgeSets_;

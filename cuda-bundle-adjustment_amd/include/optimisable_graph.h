@@ -49,11 +49,39 @@ private:
     std::vector<BaseEdge*> v_;
 };
 
+// ------------------------------------------------------------------ change tracking ----
+// Extension (not in the reference): every vertex set and edge set counts the changes made to it or
+// to its members — anything except a vertex ESTIMATE: adding / removing members, fixing a vertex,
+// a new measurement / information / camera / vertex of an edge, (in)activating an edge, a set-wide
+// information / camera / robust kernel / outlier threshold.  initialize() compares the counts with
+// those of its last full flattening: if none moved, the graph on the device is still the graph in
+// these objects and only the estimates are refreshed (csrc/host/graph_optimisation.cpp).  Members
+// reach their set through an owner pointer that addVertex / addEdge set.
+class ChangeCounted
+{
+public:
+    void touch() noexcept { ++changes_; }
+    unsigned long long changeCount() const noexcept { return changes_; }
+
+private:
+    unsigned long long changes_ = 0;
+};
+class BaseVertexSet;
+class BaseEdgeSet;
+
 // ------------------------------------------------------------------ vertices -----------
 class BaseVertex
 {
 public:
     virtual ~BaseVertex() {}
+    void setOwnerSet(BaseVertexSet* s) noexcept { owner_ = s; }
+    BaseVertexSet* ownerSet() const noexcept { return owner_; }
+
+protected:
+    inline void touchOwner() noexcept; // defined behind BaseVertexSet
+    BaseVertexSet* owner_ = nullptr;
+
+public:
     virtual int getId() const noexcept = 0;
     virtual void setId(const int id) noexcept = 0;
     virtual EdgeContainer& getEdges() noexcept = 0;
@@ -85,9 +113,18 @@ public:
     EdgeContainer& getEdges() noexcept override { return edges; }
     void addEdge(BaseEdge* e) override { edges.insert(e); }
     void removeEdge(BaseEdge* e) override { edges.erase(e); }
-    void setFixed(bool s) noexcept override { fixed = s; }
+    void setFixed(bool s) noexcept override
+    {
+        if (s != fixed)
+            touchOwner();
+        fixed = s;
+    }
     bool isFixed() const noexcept override { return fixed; }
-    void setId(const int i) noexcept override { id = i; }
+    void setId(const int i) noexcept override
+    {
+        touchOwner();
+        id = i;
+    }
     int getId() const noexcept override { return id; }
     int getIndex() const noexcept override { return idx; }
     void setIndex(const int i) noexcept override { idx = i; }
@@ -105,7 +142,7 @@ protected:
 using PoseVertex = Vertex<Se3D, false>;
 using LandmarkVertex = Vertex<Vec3d, true>;
 
-class BaseVertexSet
+class BaseVertexSet : public ChangeCounted
 {
 public:
     virtual ~BaseVertexSet() {}
@@ -125,6 +162,12 @@ public:
     virtual void scatterEstimates(const double* in) = 0;        // ref: finalise() hpp:137-154
     virtual int countFree() const noexcept = 0;
 };
+
+inline void BaseVertex::touchOwner() noexcept
+{
+    if (owner_)
+        owner_->touch();
+}
 
 namespace detail
 {
@@ -175,6 +218,8 @@ public:
     void addVertex(T* vertex)
     {
         vertexMap.emplace(vertex->getId(), vertex);
+        vertex->setOwnerSet(this);
+        touch();
         byIdStale = true;
     }
     T* getVertex(const int id) const { return vertexMap.at(id); }
@@ -192,7 +237,10 @@ public:
     }
     void clearVertices() noexcept override
     {
+        for (auto& kv : vertexMap)
+            kv.second->setOwnerSet(nullptr);
         vertexMap.clear();
+        touch();
         byIdStale = true;
     }
 
@@ -313,12 +361,25 @@ class BaseEdge
 public:
     using Information = Scalar;
     virtual ~BaseEdge() {}
+    void setOwnerSet(BaseEdgeSet* s) noexcept { owner_ = s; }
+    BaseEdgeSet* ownerSet() const noexcept { return owner_; }
+
+protected:
+    inline void touchOwner() noexcept; // defined behind BaseEdgeSet
+    BaseEdgeSet* owner_ = nullptr;
+
+public:
     virtual BaseVertex* getVertex(const int index) = 0;
     virtual void setVertex(BaseVertex* vertex, const int index) = 0;
     virtual bool allVerticesFixed() const noexcept = 0;
     virtual bool anyVerticesNotFixed() const noexcept = 0;
     virtual bool allVerticesNotFixed() const noexcept = 0;
     virtual void* getMeasurement() noexcept { return nullptr; }
+    // read-only views for the optimiser's flattening (the accessors of the reference's API hand out
+    // mutable references / pointers, so they count as a change of the edge)
+    virtual const void* measurementData() const noexcept { return nullptr; }
+    virtual const Camera& cameraData() const noexcept = 0;
+    virtual Information informationValue() const noexcept = 0;
     virtual int dim() const noexcept = 0;
     virtual void setInformation(const Information info) noexcept = 0;
     virtual Information getInformation() noexcept = 0;
@@ -344,7 +405,11 @@ public:
     }
 
     BaseVertex* getVertex(const int index) override { return vertices[index]; }
-    void setVertex(BaseVertex* vertex, const int index) override { vertices[index] = vertex; }
+    void setVertex(BaseVertex* vertex, const int index) override
+    {
+        touchOwner();
+        vertices[index] = vertex;
+    }
     bool allVerticesFixed() const noexcept override
     {
         for (auto* v : vertices)
@@ -361,13 +426,39 @@ public:
         return true;
     }
     int dim() const noexcept override { return DIM; }
-    void setMeasurement(const Measurement& m) noexcept { measurement = m; }
-    void setInformation(const Information info) noexcept override { info_ = info; }
+    void setMeasurement(const Measurement& m) noexcept
+    {
+        touchOwner();
+        measurement = m;
+    }
+    void setInformation(const Information info) noexcept override
+    {
+        touchOwner();
+        info_ = info;
+    }
     Information getInformation() noexcept override { return info_; }
-    void setCamera(const Camera& camera) noexcept override { camera_ = camera; }
-    Camera& getCamera() noexcept override { return camera_; }
-    void inactivate() noexcept override { isActive_ = false; }
-    void setActive() noexcept override { isActive_ = true; }
+    Information informationValue() const noexcept override { return info_; }
+    void setCamera(const Camera& camera) noexcept override
+    {
+        touchOwner();
+        camera_ = camera;
+    }
+    Camera& getCamera() noexcept override
+    {
+        touchOwner(); // a mutable reference leaves the object: assume it is written through
+        return camera_;
+    }
+    const Camera& cameraData() const noexcept override { return camera_; }
+    void inactivate() noexcept override
+    {
+        touchOwner();
+        isActive_ = false;
+    }
+    void setActive() noexcept override
+    {
+        touchOwner();
+        isActive_ = true;
+    }
     bool isActive() const noexcept override { return isActive_; }
 
 protected:
@@ -378,7 +469,7 @@ protected:
     bool isActive_;
 };
 
-class BaseEdgeSet
+class BaseEdgeSet : public ChangeCounted
 {
 public:
     using Information = Scalar;
@@ -392,6 +483,11 @@ public:
     virtual void clearEdges() noexcept = 0;
     virtual void setRobustKernel(const RobustKernelType type, Scalar delta) noexcept = 0;
     virtual RobustKernel& getRobustKernel() noexcept = 0;
+    // read-only views for the optimiser's flattening (the reference's getters above and below hand
+    // out mutable references and therefore count as a change of the set)
+    virtual const RobustKernel& robustKernelData() const noexcept = 0;
+    virtual const Camera& cameraData() const noexcept = 0;
+    virtual Information informationValue() const noexcept = 0;
     virtual void setInformation(const Information info) noexcept = 0;
     virtual Information getInformation() noexcept = 0;
     virtual void setCamera(const Camera& camera) noexcept = 0;
@@ -407,6 +503,12 @@ public:
     virtual void setOutlierCount(uint32_t n) noexcept = 0;
 };
 
+inline void BaseEdge::touchOwner() noexcept
+{
+    if (owner_)
+        owner_->touch();
+}
+
 // ref: EdgeSet<DIM, E, VertexTypes...> src/optimisable_graph.h:688-816
 template <int DIM, typename E, typename... VertexTypes>
 class EdgeSet : public BaseEdgeSet
@@ -420,6 +522,8 @@ public:
         for (int i = 0; i < (int)VertexSize; ++i)
             edge->getVertex(i)->addEdge(edge);
         edges.insert(edge);
+        edge->setOwnerSet(this);
+        touch();
         isDirty_ = true;
     }
     void removeEdge(BaseEdge* edge) override
@@ -427,6 +531,8 @@ public:
         for (int i = 0; i < (int)VertexSize; ++i)
             edge->getVertex(i)->removeEdge(edge);
         edges.erase(edge);
+        edge->setOwnerSet(nullptr);
+        touch();
         isDirty_ = true;
     }
     size_t nedges() const noexcept override { return edges.size(); }
@@ -435,20 +541,47 @@ public:
     const int dim() const noexcept override { return DIM; }
     void setRobustKernel(const RobustKernelType type, Scalar delta) noexcept override
     {
+        touch();
         kernel.create(type, delta);
     }
-    RobustKernel& getRobustKernel() noexcept override { return kernel; }
+    RobustKernel& getRobustKernel() noexcept override
+    {
+        touch();
+        return kernel;
+    }
+    const RobustKernel& robustKernelData() const noexcept override { return kernel; }
+    const Camera& cameraData() const noexcept override { return camera_; }
+    Information informationValue() const noexcept override { return info_; }
     void clearEdges() noexcept override
     {
+        for (BaseEdge* e : edges)
+            e->setOwnerSet(nullptr);
         edges.clear();
         activeEdgeSize_ = 0;
+        touch();
         isDirty_ = true;
     }
-    void setInformation(const Information info) noexcept override { info_ = info; }
+    void setInformation(const Information info) noexcept override
+    {
+        touch();
+        info_ = info;
+    }
     Information getInformation() noexcept override { return info_; }
-    void setCamera(const Camera& camera) noexcept override { camera_ = camera; }
-    Camera& getCamera() noexcept override { return camera_; }
-    void setOutlierThreshold(const Scalar t) noexcept { outlierThreshold = t; }
+    void setCamera(const Camera& camera) noexcept override
+    {
+        touch();
+        camera_ = camera;
+    }
+    Camera& getCamera() noexcept override
+    {
+        touch();
+        return camera_;
+    }
+    void setOutlierThreshold(const Scalar t) noexcept
+    {
+        touch();
+        outlierThreshold = t;
+    }
     Scalar getOutlierThreshold() const noexcept override { return outlierThreshold; }
     uint32_t getOutlierCount() const noexcept override { return currOutlierCount_; }
     uint32_t getInlierCount() const noexcept override { return (uint32_t)activeEdgeSize_ - currOutlierCount_; }
@@ -479,7 +612,9 @@ bool VertexSet<T, E>::removeVertex(BaseVertex* v, BaseEdgeSet* edgeSet)
     const std::vector<BaseEdge*> es(it->second->getEdges().begin(), it->second->getEdges().end());
     for (BaseEdge* e : es)
         edgeSet->removeEdge(e);
+    it->second->setOwnerSet(nullptr);
     vertexMap.erase(it);
+    touch();
     byIdStale = true;
     return true;
 }

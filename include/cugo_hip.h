@@ -290,7 +290,12 @@ int cugo_set_device(int device);
  * of active edges of every landmark (host only; the rule cugo_graph_initialize applies) */
 int cugo_shard_range(int n_landmarks_total, const int32_t* edges_per_landmark, int rank, int world,
                      int* l0, int* l1);
-int cugo_graph_initialize(cugo_graph* g);             /* ref: initialize() :147 */
+/* ref: initialize() :147.  When nothing but vertex estimates changed since the last call (no vertex /
+ * edge added or removed, no fixed flag, measurement, information, camera, robust kernel or threshold
+ * touched) the flattened graph on the device is kept and only the estimates are uploaded; the
+ * counter below says how often that happened (CUGO_NO_FLATTEN_REUSE=1 disables it). */
+int cugo_graph_initialize(cugo_graph* g);
+int cugo_graph_flatten_reuses(cugo_graph* g);
 int cugo_graph_optimize(cugo_graph* g, int n_iters);  /* ref: optimize(n)  :153 */
 int cugo_graph_n_stats(cugo_graph* g);                /* ref: batchStatistics() :158 */
 int cugo_graph_get_stats(cugo_graph* g, int32_t* iteration, double* chi2, int cap);

@@ -55,24 +55,25 @@ def lib():
     return _LIB
 
 
-_FAST = None
+_FAST = {}
 
 
-def fast_lib():
-    """Timing-only variant of the same source for bench.py's cpu_baseline leg: -O3 -march=native
-    -fopenmp -DBA_OMP (OpenMP over edges / landmarks; the summation order is then not fixed, so it
-    is never the parity checker).  Compiled on the machine that runs it (-march=native) into a
-    temporary directory; OMP_NUM_THREADS selects 1 thread or all cores."""
-    global _FAST
-    if _FAST is None:
+def fast_lib(openmp=True):
+    """Timing-only variants of the same source for bench.py's cpu_baseline leg: -O3 -march=native,
+    and with openmp also -fopenmp -DBA_OMP (OpenMP over edges / landmarks; the summation order is then
+    not fixed, so it is never the parity checker).  Compiled on the machine that runs it
+    (-march=native) into a temporary directory; omp_set_num_threads selects the thread count."""
+    if openmp not in _FAST:
         import tempfile
         out = os.path.join(tempfile.mkdtemp(prefix="ba_oracle_fast_"), "libba_oracle_fast.so")
-        subprocess.check_call(["gcc", "-O3", "-march=native", "-fopenmp", "-DBA_OMP", "-fPIC", "-std=c99",
-                               "-shared", "-o", out, os.path.join(ORACLE_DIR, "ba_oracle.c"), "-lm"])
-        _FAST = C.CDLL(out)
-        _FAST.ba_compute_errors.restype = C.c_double
-        _FAST.ba_build_system.restype = C.c_double
-    return _FAST
+        flags = ["-fopenmp", "-DBA_OMP"] if openmp else []
+        subprocess.check_call(["gcc", "-O3", "-march=native"] + flags + ["-fPIC", "-std=c99", "-shared", "-o", out,
+                               os.path.join(ORACLE_DIR, "ba_oracle.c"), "-lm"])
+        L = C.CDLL(out)
+        L.ba_compute_errors.restype = C.c_double
+        L.ba_build_system.restype = C.c_double
+        _FAST[openmp] = L
+    return _FAST[openmp]
 
 
 def _p(a, t):

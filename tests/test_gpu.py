@@ -643,6 +643,51 @@ def kitti00(oracle_lib):
     return dict(d=d, ref=ref, pose=prob.pose.copy(), lm=prob.lm.copy())
 
 
+def test_reinitialize_on_an_unchanged_graph_refreshes_estimates_only(oracle_lib):
+    """initialize() on a graph in which only vertex estimates changed keeps the flattened graph on
+    the device (change tracking of the vertex / edge sets) — bitwise the result of a full
+    flattening; any other change (set-wide information, new edges, a newly fixed vertex through a
+    re-added vertex set) takes the full path again and is seen."""
+    d, prob = synth_problem(oracle_lib, 120, 1500, 6200, seed=5, lc=0)
+    d["e_omega"][:] = 0.75
+    ids_p, ids_l = np.arange(120, dtype=np.int32), np.arange(1500, dtype=np.int32)
+    g = cugo.graph_from_arrays(d, per_edge_information=False)
+    g.initialize(); g.optimize(4)
+    first, pose1 = g.stats(), g.poses()
+    assert g.flatten_reuses() == 0
+    g.set_poses(ids_p, d["pose"]); g.set_landmarks(ids_l, d["lm"])
+    g.initialize(); g.optimize(4)                      # estimates only
+    assert g.flatten_reuses() == 1
+    assert [s["chi2"] for s in g.stats()] == [s["chi2"] for s in first] and np.array_equal(g.poses(), pose1)
+    g.initialize(); g.optimize(2)                      # continues from the optimised estimates
+    assert g.flatten_reuses() == 2
+    prob.e_omega[:] = 0.75
+    ref = prob.optimize(4)
+    assert_trajectories_match(first, ref, 1e-10)
+    cont = prob.optimize(2)
+    assert_trajectories_match(g.stats(), cont, 1e-10)
+    # a set-wide information value is a change: full flattening, new weights in effect
+    for dim in (2, 3):
+        g.set_information(dim, 0.25)
+    g.set_poses(ids_p, d["pose"]); g.set_landmarks(ids_l, d["lm"])
+    g.initialize(); g.optimize(3)
+    assert g.flatten_reuses() == 2
+    p2 = oracle_lib.Problem(*[d[k] for k in PROBLEM_KEYS])
+    p2.e_omega[:] = 0.25
+    assert_trajectories_match(g.stats(), p2.optimize(3), 1e-10)
+    # new edges are a change too
+    extra = cugo.synth(120, 1500, 6200, seed=6)
+    sel = np.flatnonzero(extra["e_stereo"] == 0)[:50]
+    have = set(zip(d["e_pose"].tolist(), d["e_lm"].tolist()))
+    sel = np.array([i for i in sel if (int(extra["e_pose"][i]), int(extra["e_lm"][i])) not in have], np.int64)
+    g.add_edges(2, extra["e_pose"][sel], extra["e_lm"][sel], extra["e_meas"][sel], extra["e_omega"][sel],
+                extra["e_cam"][sel])
+    g.set_poses(ids_p, d["pose"]); g.set_landmarks(ids_l, d["lm"])
+    g.initialize()
+    assert g.flatten_reuses() == 2 and g.n_active_edges() == 6200 + len(sel)
+    g.close()
+
+
 def test_kitti00_shape_full_size(kitti00):
     """BASELINE config 2 shape (1322 / 133 383 / 561 116): parity with the oracle plus
     size-independent properties (monotone chi2, bitwise reproducibility)."""

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-kernel HBM traffic from two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
-    python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE > profiles/r01_pmc_traffic.json
+    python tools/pmc_traffic.py gpurun_out/pmc_kitti00_FETCH_SIZE gpurun_out/pmc_kitti00_WRITE_SIZE kitti00 > profiles/r02_pmc_traffic.json
 Units and corrections as in MI355X_MICROARCH.md (HBM / rocprofv3 section): both counters are in
 KB; on gfx950 FETCH_SIZE under-counts wide coalesced reads by 2x, so the raw and the x2 sums are
 both given (gather patterns are uncalibrated)."""
@@ -27,10 +27,11 @@ def per_kernel(d, counter):
 def main():
     fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
+    shape = sys.argv[3] if len(sys.argv) > 3 else "kitti00"
     out = {
         "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on: "
-                  "python bench.py --steps 1 --warmup 1 --no-cpu-baseline, kitti00 shape, round 1 "
-                  "(tools/refresh_profiles.sh)",
+                  "python bench.py --workload %s --steps 1 --warmup 1 --no-cpu-baseline --no-extras, round 2 "
+                  "(tools/refresh_profiles.sh)" % shape,
         "note": "FETCH_SIZE on gfx950 under-counts wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM); "
                 "both the raw and the x2-corrected sums are given; gather/scatter patterns are uncalibrated",
         "kernels": {},

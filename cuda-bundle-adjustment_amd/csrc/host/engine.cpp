@@ -19,6 +19,7 @@
 #include "hip_util.h"
 #include "rccl_comm.h"
 #include "schur_plan.h"
+#include "structure_gpu.h"
 #include "thread_pool.h"
 
 namespace cugo_host
@@ -106,6 +107,7 @@ struct Engine::Impl : cugo_k::LaunchHook
     cugo_hsc_struct hs{};
     SchurPlanDevice splan; // landmark-major product plan of the Schur complement (schur_plan.h)
     bool splan_on = false;
+    GpuStructure gstruct;  // Hsc pattern + contribution lists built on the device (structure_gpu.h)
     bool structure_dirty = true;
     uint64_t structure_sig = 0; // hash of the flattened topology the structure was built for
     // ... and the topology itself (compared on a hash hit), saved by build_structure()
@@ -771,6 +773,38 @@ void Engine::build_structure()
     InitLaps laps;
     hipStream_t s = m.ctx.stream;
     const int P = m.P, L = m.L;
+    // ---- device-side build (single-process graphs): pairs per landmark -> stable radix sort by pose
+    // pair -> runs = off-diagonal blocks; the same lists, in the same order, as the host passes below
+    // (which remain for shards — they need the GLOBAL pattern — and for plan-only / forced runs)
+    if (m.world == 1 && !m.plan_only && m.E > 0 && !std::getenv("CUGO_SCHUR_PLAN") && !std::getenv("CUGO_HOST_STRUCTURE"))
+    {
+        if (build_structure_gpu(s, m.E, P, m.Lall, m.d_e_pose.data(), m.d_flags.data(), m.d_lm_ptr.data(), m.gstruct))
+        {
+            laps.lap("structure: device build (pairs, sort, runs)");
+            m.gstruct.scratch.release();
+            m.hsc_rowptr = m.gstruct.h_rowptr, m.hsc_colind = m.gstruct.h_colind;
+            const int B = m.gstruct.B;
+            m.d_sys.resize(36 * (size_t)B + 6 * (size_t)P + 16);
+            m.hs = cugo_hsc_struct{};
+            m.hs.n_blocks = B;
+            m.hs.d_rowptr = m.gstruct.rowptr.data(), m.hs.d_colind = m.gstruct.colind.data();
+            m.hs.d_off_ptr = m.gstruct.off_ptr.data(), m.hs.d_off_ei = m.gstruct.off_ei.data();
+            m.hs.d_off_ej = m.gstruct.off_ej.data();
+            m.splan_on = false;
+            double nff = 0;
+            for (int e = 0; e < m.E; e++)
+                nff += (m.h_flags[e] & (CUGO_EDGE_FIXED_L | CUGO_EDGE_FIXED_P | CUGO_EDGE_INACTIVE)) == 0;
+            prof_[PROF_BUILD_STRUCTURE] += ms_since(t0);
+            const auto t1g = Clock::now();
+            m.chol.analyze(P, m.hsc_rowptr.data(), m.hsc_colind.data());
+            prof_[PROF_SYMBOLIC] += ms_since(t1g);
+            laps.lap("structure: symbolic + plan upload");
+            fill_structure_stats(B, (double)m.gstruct.Moff + nff, (double)m.gstruct.Moff);
+            sstats_.schur_slots = 0;
+            m.structure_dirty = false;
+            return;
+        }
+    }
     // pose-major view of the global co-visibility
     std::vector<int32_t> pc_ptr(P + 1, 0), pc_lm(m.cov_pose.size());
     for (int32_t p : m.cov_pose)

@@ -1,0 +1,43 @@
+// Device-side build of the Hsc block pattern + off-diagonal contribution lists (structure_gpu.cpp).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "../../../include/cugo_hip.h"
+#include "hip_util.h"
+
+namespace cugo_host
+{
+
+struct GpuStructureScratch
+{
+    DevBuf<uint64_t> npairs, pair_off, keys_a, keys_b, vals_a, vals_b;
+    DevBuf<uint32_t> head, rank;
+    DevBuf<int32_t> run_pa, run_pb, run_start, row_first;
+    DevBuf<char> temp;
+    void release()
+    {
+        npairs.release(), pair_off.release(), keys_a.release(), keys_b.release(), vals_a.release(), vals_b.release();
+        head.release(), rank.release(), run_pa.release(), run_pb.release(), run_start.release(), row_first.release();
+        temp.release();
+    }
+};
+
+struct GpuStructure
+{
+    // results on the device: upper block CSR of Hsc (diagonal block first in every row) and the
+    // contribution lists of its off-diagonal blocks (cugo_hsc_struct of include/cugo_hip.h)
+    DevBuf<int32_t> rowptr, colind, off_ptr, off_ei, off_ej;
+    // the pattern on the host (symbolic analysis)
+    std::vector<int32_t> h_rowptr, h_colind;
+    int B = 0;
+    size_t Moff = 0;
+    GpuStructureScratch scratch; // transient; released by the caller when memory matters
+};
+
+// d_e_pose / d_flags: the flattened landmark-major edge slots, d_lm_ptr [Lall + 1].  Returns false
+// (nothing built) when the problem is empty or the lists would not fit int32 indices.
+bool build_structure_gpu(hipStream_t s, int E, int P, int Lall, const int32_t* d_e_pose, const uint8_t* d_flags,
+                         const int32_t* d_lm_ptr, GpuStructure& out);
+
+} // namespace cugo_host

@@ -401,6 +401,29 @@ def test_medium_synthetic_vs_oracle(oracle_lib, subtree_stage, monkeypatch):
     assert out["stats"][-1]["chi2"] < out["stats"][0]["chi2"]
 
 
+@pytest.mark.parametrize("shape", ["mixed_fixed", "medium", "dense_ring", "all_landmarks_fixed"])
+def test_device_structure_build_equals_host_build(oracle_lib, shape, monkeypatch):
+    """the Hsc pattern and the contribution lists built on the device (pairs per landmark, stable
+    radix sort by pose pair, runs; csrc/host/structure_gpu.cpp — ref: findHschureMulBlockIndices +
+    thrust::sort, .cu:1347-1378,1606-1634) are the host build's, entry for entry: the two runs are
+    bitwise identical and report the same structure"""
+    if shape == "mixed_fixed":
+        d = synth.make_problem(n_poses=30, n_landmarks=400, mean_obs=5.0, seed=9, fixed_poses=(0, 7, 8),
+                               fixed_landmarks=tuple(range(0, 400, 7)), loop_closure=True)
+    elif shape == "medium":
+        d = cugo.synth(400, 8000, 33000, seed=11, n_loop_closures=200)
+    elif shape == "dense_ring":
+        d = dense_ring_problem(300, 12, seed=3)  # 300 edges per landmark
+    else:
+        d = synth.make_problem(n_poses=9, n_landmarks=80, seed=2, fixed_landmarks=tuple(range(80)))
+    dev = run_graph(d, 5)
+    monkeypatch.setenv("CUGO_HOST_STRUCTURE", "1")
+    host = run_graph(d, 5)
+    assert dev["sstats"] == host["sstats"]
+    assert [s["chi2"] for s in dev["stats"]] == [s["chi2"] for s in host["stats"]]
+    assert np.array_equal(dev["pose"], host["pose"]) and np.array_equal(dev["lm"], host["lm"])
+
+
 def test_landmark_major_schur_plan_end_to_end(oracle_lib, monkeypatch):
     """CUGO_SCHUR_PLAN=1: the engine takes the landmark-major form of the Schur complement
     (k_schur_fused + k_hsc_reduce, no T array) — same trajectory as the oracle, sharded too"""

@@ -8,9 +8,13 @@
 #include "chol_symbolic.h"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <numeric>
 #include <stdexcept>
+#include <thread>
 
 namespace cugo_host
 {
@@ -82,12 +86,17 @@ struct ND
 {
     const Graph& g;
     const CholOptions& opt;
-    std::vector<int> setid, level, order;
-    int next_id = 1;
+    // setid / level are indexed by node: the two halves of a dissection own disjoint nodes, so they
+    // can be ordered by different threads (the top levels are: see run()).  A thread only ever
+    // compares the setid of a foreign node with its own id, hence the relaxed atomic accesses.
+    std::vector<int> setid, level;
+    std::atomic<int> next_id{1};
     ND(const Graph& g_, const CholOptions& o) : g(g_), opt(o), setid(g_.n, 0), level(g_.n, -1) {}
+    int sid(int v) const { return __atomic_load_n(&setid[v], __ATOMIC_RELAXED); }
+    void set_sid(int v, int id) { __atomic_store_n(&setid[v], id, __ATOMIC_RELAXED); }
 
     // exact minimum degree on the subgraph induced by `nodes` (small sets only)
-    void leaf_order(const std::vector<int>& nodes)
+    void leaf_order(const std::vector<int>& nodes, std::vector<int>& order)
     {
         const int m = (int)nodes.size();
         if (m > 512)
@@ -96,10 +105,10 @@ struct ND
                 order.push_back(v);
             return;
         }
-        const int id = next_id++;
+        const int id = next_id.fetch_add(1);
         std::vector<int> local(m);
         for (int i = 0; i < m; i++)
-            setid[nodes[i]] = id;
+            set_sid(nodes[i], id);
         // local adjacency
         std::vector<std::vector<int>> adj(m);
         {
@@ -113,37 +122,52 @@ struct ND
                 for (int k = g.ptr[nodes[i]]; k < g.ptr[nodes[i] + 1]; k++)
                 {
                     const int u = g.adj[k];
-                    if (setid[u] == id)
+                    if (sid(u) == id)
                         adj[i].push_back(
                             where[std::lower_bound(sorted.begin(), sorted.end(), u) - sorted.begin()]);
                 }
         }
+        // exact minimum degree (ties: lowest local index) on a bit matrix: eliminating `best` ORs its
+        // row into the rows of its neighbours — O(m) words per step instead of O(deg^2) list edits
+        const int W = (m + 63) >> 6;
+        std::vector<uint64_t> bits((size_t)m * W, 0);
+        for (int i = 0; i < m; i++)
+            for (int u : adj[i])
+                bits[(size_t)i * W + (u >> 6)] |= 1ull << (u & 63);
+        std::vector<int> deg(m);
+        for (int i = 0; i < m; i++)
+            deg[i] = (int)adj[i].size();
         std::vector<char> done(m, 0);
-        std::vector<int> mark(m, -1);
         for (int step = 0; step < m; step++)
         {
             int best = -1;
             for (int i = 0; i < m; i++)
-                if (!done[i] && (best < 0 || adj[i].size() < adj[best].size()))
+                if (!done[i] && (best < 0 || deg[i] < deg[best]))
                     best = i;
             done[best] = 1;
             order.push_back(nodes[best]);
-            const std::vector<int> nb = adj[best];
-            for (int u : nb)
+            const uint64_t* rb = &bits[(size_t)best * W];
+            for (int w = 0; w < W; w++)
             {
-                auto& au = adj[u];
-                au.erase(std::remove(au.begin(), au.end(), best), au.end());
-                for (int w : au)
-                    mark[w] = u;
-                mark[u] = u;
-                for (int v : nb)
-                    if (mark[v] != u)
+                uint64_t nb = rb[w];
+                while (nb)
+                {
+                    const int u = (w << 6) + __builtin_ctzll(nb);
+                    nb &= nb - 1;
+                    uint64_t* ru = &bits[(size_t)u * W];
+                    int d = 0;
+                    for (int q = 0; q < W; q++)
                     {
-                        au.push_back(v);
-                        mark[v] = u;
+                        ru[q] |= rb[q];
+                        if (q == (u >> 6))
+                            ru[q] &= ~(1ull << (u & 63));       // no self loop
+                        if (q == (best >> 6))
+                            ru[q] &= ~(1ull << (best & 63));    // best leaves the graph
+                        d += __builtin_popcountll(ru[q]);
                     }
+                    deg[u] = d;
+                }
             }
-            adj[best].clear();
         }
     }
 
@@ -159,7 +183,7 @@ struct ND
             for (int k = g.ptr[v]; k < g.ptr[v + 1]; k++)
             {
                 const int u = g.adj[k];
-                if (setid[u] == id && level[u] < 0)
+                if (sid(u) == id && level[u] < 0)
                 {
                     level[u] = level[v] + 1;
                     out.push_back(u);
@@ -168,17 +192,20 @@ struct ND
         }
     }
 
-    void run(std::vector<int> nodes)
+    // appends the ordering of `nodes` to `order`; depth < kParallelDepth: the two halves run on
+    // two threads (the result does not depend on it: A's order, then B's, then the separator)
+    const int kParallelDepth = std::getenv("CUGO_ND_PAR") ? std::atoi(std::getenv("CUGO_ND_PAR")) : 4; // 0: one thread
+    void run(std::vector<int> nodes, std::vector<int>& order, int depth = 0)
     {
         if ((int)nodes.size() <= opt.nd_leaf)
         {
-            leaf_order(nodes);
+            leaf_order(nodes, order);
             return;
         }
-        const int id = next_id++;
+        const int id = next_id.fetch_add(1);
         for (int v : nodes)
         {
-            setid[v] = id;
+            set_sid(v, id);
             level[v] = -1;
         }
         // connected components
@@ -195,7 +222,7 @@ struct ND
                     comps.push_back(comp);
                 }
             for (auto& c : comps)
-                run(c);
+                run(c, order, depth + 1);
             return;
         }
         // pseudo-peripheral start: repeat BFS from the last-visited node
@@ -215,7 +242,7 @@ struct ND
         const int h = level[comp.back()];
         if (h < 2)
         {
-            leaf_order(nodes);
+            leaf_order(nodes, order);
             return;
         }
         std::vector<int> cnt(h + 1, 0);
@@ -258,14 +285,37 @@ struct ND
                 for (int k = g.ptr[v]; k < g.ptr[v + 1] && !touches_B; k++)
                 {
                     const int u = g.adj[k];
-                    if (setid[u] == id && level[u] == best + 1)
+                    if (sid(u) == id && level[u] == best + 1)
                         touches_B = true;
                 }
                 (touches_B ? S : A).push_back(v);
             }
         }
-        run(A);
-        run(B);
+        if (depth < kParallelDepth && A.size() + B.size() > 2000)
+        {
+            std::vector<int> orderB;
+            std::exception_ptr err;
+            std::thread tb([&] {
+                try
+                {
+                    run(std::move(B), orderB, depth + 1);
+                }
+                catch (...)
+                {
+                    err = std::current_exception();
+                }
+            });
+            run(std::move(A), order, depth + 1);
+            tb.join();
+            if (err)
+                std::rethrow_exception(err);
+            order.insert(order.end(), orderB.begin(), orderB.end());
+        }
+        else
+        {
+            run(std::move(A), order, depth + 1);
+            run(std::move(B), order, depth + 1);
+        }
         for (int v : S)
             order.push_back(v);
     }
@@ -276,11 +326,23 @@ struct ND
 void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const CholOptions& opt,
                   CholPlan& P)
 {
+    // CUGO_INIT_TIMING=1: per-phase host times on stderr (diagnosis only)
+    const bool timing = std::getenv("CUGO_INIT_TIMING") != nullptr;
+    auto lap_t = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing)
+            return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[cugo symbolic] %-26s %8.3f ms\n", what,
+                     std::chrono::duration<double, std::milli>(now - lap_t).count());
+        lap_t = now;
+    };
     P = CholPlan();
     P.n = n;
     if (n == 0)
         return;
     const Graph g = build_graph(n, rowptr, colind);
+    lap("0 adjacency graph");
 
     // ---- 1. fill-reducing, parallelism-exposing ordering --------------------------------
     std::vector<int> perm;
@@ -288,8 +350,8 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
         ND nd(g, opt);
         std::vector<int> all(n);
         std::iota(all.begin(), all.end(), 0);
-        nd.run(all);
-        perm = nd.order;
+        perm.reserve(n);
+        nd.run(std::move(all), perm);
         if ((int)perm.size() != n)
             throw std::runtime_error("cugo: ordering lost nodes");
     }
@@ -297,6 +359,7 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
     for (int i = 0; i < n; i++)
         iperm[perm[i]] = i;
 
+    lap("1 ordering");
     // ---- 2. elimination tree (Liu, path compression) + postorder -----------------------
     auto etree = [&](const std::vector<int>& ip, const std::vector<int>& pm, std::vector<int>& parent) {
         parent.assign(n, -1);
@@ -362,6 +425,7 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
         etree(iperm, perm, parent);
     }
 
+    lap("2 etree + postorder");
     // ---- 3. column structures of L (block level) ---------------------------------------
     std::vector<int> cptr(n + 1, 0);
     std::vector<int> cidx; // struct(j): rows > j, sorted
@@ -408,6 +472,7 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
     }
     auto csize = [&](int j) { return cptr[j + 1] - cptr[j]; };
 
+    lap("3 column structures");
     // ---- 4. fundamental supernodes, then relaxed amalgamation --------------------------
     std::vector<int> sfirst; // first column of each supernode (ascending)
     for (int j = 0; j < n; j++)
@@ -490,6 +555,7 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
         for (int j = sfirst[s]; j < sfirst[s + 1]; j++)
             P.col_front[j] = s;
 
+    lap("4 supernodes");
     // ---- 5. fronts: boundary rows, parents, relative indices ---------------------------
     P.rows_ptr.assign(ns + 1, 0);
     P.ncb.resize(ns), P.nb.resize(ns), P.col0.resize(ns), P.off.resize(ns), P.sparent.assign(ns, -1);
@@ -569,6 +635,7 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
         }
     }
 
+    lap("5 fronts");
     // ---- 5b. storage: single-child chains share memory --------------------------------------
     // A front whose only child has exactly the front's rows as its boundary (the pieces of a wide
     // supernode, and most single-child links of the etree) would receive that child's update
@@ -609,6 +676,7 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
         P.front_doubles = o;
     }
 
+    lap("5b storage");
     // ---- 6. assembly map of the Hsc blocks ---------------------------------------------
     const int B = rowptr[n];
     P.blk_front.resize(B), P.blk_row.resize(B), P.blk_col.resize(B), P.blk_trans.resize(B);
@@ -636,6 +704,7 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
             P.blk_trans[k] = (a < b) ? 1 : 0; // stored block is A(a,b); lower needs A(hi,lo)
         }
 
+    lap("6 assembly map");
     // ---- 7. schedule: bottom subtrees -> one task each (stage 0), the rest by level ----
     std::vector<double> work(ns), sub(ns);
     for (int s = 0; s < ns; s++)
@@ -735,6 +804,7 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
         if (lower[s])
             P.has_subtree_stage = true;
 
+    lap("7 schedule");
     // ---- 8. work items of the batched upper-stage kernels ------------------------------
     P.nc_max = 6;
     for (int s = 0; s < ns; s++)
@@ -848,6 +918,7 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
         v += (int)(ea.size() + eab.size()) / 3;
     for (auto& v : P.bwg_ptr)
         v += (int)(ea.size() + eab.size() + sy.size()) / 3;
+    lap("8 work items");
 }
 
 } // namespace cugo_host

@@ -29,7 +29,7 @@ void cugo_chol::upload(hipStream_t s)
         return o;
     };
     const size_t o_ncb = put32(P.ncb), o_nb = put32(P.nb), o_col0 = put32(P.col0);
-    const size_t o_alias = put32(P.alias_of), o_bwnp = put32(P.bw_np);
+    const size_t o_alias = put32(P.alias_of), o_bwnp = put32(P.bw_np), o_lanp = put32(P.la_np);
     const size_t o_rows_ptr = put32(P.rows_ptr), o_rows = put32(P.rows);
     const size_t o_child_ptr = put32(P.child_ptr), o_child = put32(P.child);
     const size_t o_rel_ptr = put32(P.rel_ptr), o_rel = put32(P.rel);
@@ -66,7 +66,7 @@ void cugo_chol::upload(hipStream_t s)
     D.junk = d_junk.data();
     D.woff = b64 + o_woff, D.winv = d_winv.data(), D.nc_max = P.nc_max;
     D.l21off = b64 + o_l21off, D.l21 = d_l21.data();
-    D.ldf = b64 + o_ldf, D.alias_of = b32 + o_alias, D.bw_np = b32 + o_bwnp;
+    D.ldf = b64 + o_ldf, D.alias_of = b32 + o_alias, D.bw_np = b32 + o_bwnp, D.la_np = b32 + o_lanp;
     d_wl_ptr = b32 + o_wl;
     lds_factor = cugo_k::chol_lds_factor_bytes(P.nc_max);
     lds_backward = cugo_k::chol_lds_backward_bytes(P.nc_max, P.ld_max);
@@ -75,6 +75,7 @@ void cugo_chol::upload(hipStream_t s)
 void cugo_chol::analyze(int n, const int32_t* rowptr, const int32_t* colind)
 {
     chol_analyze(n, rowptr, colind, CholOptions::from_env(), plan);
+    lookahead = std::getenv("CUGO_LOOKAHEAD") && std::atoi(std::getenv("CUGO_LOOKAHEAD")) != 0;
     trans32.assign(plan.blk_trans.begin(), plan.blk_trans.end());
     if (plan.nc_max > cugo_k::chol_max_pivot_cols() ||
         cugo_k::chol_lds_factor_bytes(plan.nc_max) > 160 * 1024 ||
@@ -100,11 +101,22 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
     }
     cugo_k::launch_chol_assemble(s, dev, d_fronts.data(), (size_t)plan.front_doubles, d_Hsc, lambda,
                                  d_bsc, d_fail, false);
+    int pend0 = 0, npend = 0, pend_tile = 64; // update tiles of the previous level, not launched yet
     for (int st = 0; st < plan.n_stages; st++)
     {
         const int t0 = plan.stage_task_ptr[st], t1 = plan.stage_task_ptr[st + 1];
         if (plan.has_subtree_stage && st == 0)
             cugo_k::launch_chol_subtree_stage(s, dev, d_fronts.data(), t0, t1 - t0, lds_factor, d_fail);
+        else if (lookahead)
+        {
+            cugo_k::launch_chol_potrf_la(s, dev, d_fronts.data(), t0, t1 - t0, d_wl_ptr + 3L * pend0, npend,
+                                         pend_tile, d_fail);
+            cugo_k::launch_chol_lead(s, dev, d_fronts.data(), d_wl_ptr + 3L * plan.lead_ptr[st],
+                                     plan.lead_ptr[st + 1] - plan.lead_ptr[st], d_wl_ptr + 3L * plan.ea_ptr[st],
+                                     plan.ea_ptr[st + 1] - plan.ea_ptr[st], d_wl_ptr + 3L * plan.eab_ptr[st],
+                                     plan.eab_ptr[st + 1] - plan.eab_ptr[st]);
+            pend0 = plan.sb_ptr[st], npend = plan.sb_ptr[st + 1] - plan.sb_ptr[st], pend_tile = plan.stage_tile[st];
+        }
         else
             cugo_k::launch_chol_upper_stage(
                 s, dev, d_fronts.data(), t0, t1 - t0, d_wl_ptr, plan.ea_ptr[st],
@@ -112,6 +124,8 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
                 plan.eab_ptr[st + 1] - plan.eab_ptr[st], plan.syrk_ptr[st],
                 plan.syrk_ptr[st + 1] - plan.syrk_ptr[st], plan.stage_tile[st], lds_factor, d_fail);
     }
+    if (npend > 0) // the last level's tiles (the rhs rows of the roots)
+        cugo_k::launch_chol_potrf_la(s, dev, d_fronts.data(), 0, 0, d_wl_ptr + 3L * pend0, npend, pend_tile, d_fail);
     for (int st = plan.n_stages - 1; st >= 0; st--)
     {
         const int t0 = plan.stage_task_ptr[st], t1 = plan.stage_task_ptr[st + 1];

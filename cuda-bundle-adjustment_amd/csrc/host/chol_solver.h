@@ -12,6 +12,11 @@ struct cugo_chol
     std::vector<int32_t> trans32; // blk_trans widened for cugo_chol_plan_array
     cugo_k::CholPlanDev dev{};
     size_t lds_factor = 0, lds_backward = 0;
+    // CUGO_LOOKAHEAD=1 at analyze(): the bulk of a level's update matrix is computed while the next level
+    // factors (k_up_potrf_la / k_up_lead).  Measured slower than the level-synchronous default on MI355X
+    // (kitti_00 shape: 17.5 vs 14.7 ms per step, profiles/r02_lookahead_timeline.txt): the lead workgroup
+    // that the next potrf waits for costs as much as a whole single-round tile launch.  Kept under test.
+    bool lookahead = false;
 
     // the plan's index arrays, packed (chol_solver.cpp: upload)
     cugo_host::DevBuf<int32_t> d_pack32;

@@ -810,7 +810,20 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
     for (int s = 0; s < ns; s++)
         P.nc_max = std::max(P.nc_max, 6 * P.ncb[s]);
     P.ea_ptr.assign(1, 0), P.eab_ptr.assign(1, 0), P.syrk_ptr.assign(1, 0), P.bwg_ptr.assign(1, 0);
+    P.lead_ptr.assign(1, 0), P.sb_ptr.assign(1, 0);
     P.bw_np.assign(ns, -1);
+    // lead rows of a front: its leading boundary block rows inside the parent's pivot columns
+    P.la_np.assign(ns, 0);
+    for (int c = 0; c < ns; c++)
+        if (P.sparent[c] >= 0)
+        {
+            const int nbr = P.nb[c] - P.ncb[c], ncbp = P.ncb[P.sparent[c]];
+            int np = 0;
+            while (np < nbr && P.rel[P.rel_ptr[c] + np] < ncbp)
+                np++;
+            P.la_np[c] = np;
+        }
+    std::vector<int32_t> lead, sb;
     P.l21off.assign(ns, -1);
     P.l21_doubles = 0;
     std::vector<int32_t> ea, eab, sy, bwg;
@@ -878,6 +891,23 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
                 {
                     sy.push_back(f), sy.push_back(ti), sy.push_back(-1);
                 }
+                // look-ahead schedule: one lead workgroup per front that has lead rows, and the same
+                // tiles without those that lie wholly inside the lead block
+                const int q = 6 * P.la_np[f];
+                if (q > 0)
+                {
+                    lead.push_back(f), lead.push_back(0), lead.push_back(0);
+                }
+                for (int tj = 0; tj < ntj; tj++)
+                    for (int ti = tj; ti < nti; ti++)
+                        if (TS * (ti + 1) > q)
+                        {
+                            sb.push_back(f), sb.push_back(ti), sb.push_back(tj);
+                        }
+                for (int ti = ntj; ti < nti; ti++)
+                {
+                    sb.push_back(f), sb.push_back(ti), sb.push_back(-1);
+                }
                 P.l21off[f] = P.l21_doubles;
                 P.l21_doubles += (int64_t)6 * ncb * nbelow;
                 // backward mat-vec items of this front's CHILDREN (upper-stage ones): rows beyond
@@ -905,8 +935,11 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
         P.eab_ptr.push_back((int)eab.size() / 3);
         P.syrk_ptr.push_back((int)sy.size() / 3);
         P.bwg_ptr.push_back((int)bwg.size() / 3);
+        P.lead_ptr.push_back((int)lead.size() / 3);
+        P.sb_ptr.push_back((int)sb.size() / 3);
     }
-    // one array: [ea | eab | trsyrk | backward mat-vec]; the ptr arrays index items within their own section
+    // one array: [ea | eab | trsyrk | backward mat-vec | lead | trsyrk without the lead tiles]; the ptr arrays
+    // index items within their own section
     P.wl.clear();
     P.wl.insert(P.wl.end(), ea.begin(), ea.end());
     P.wl.insert(P.wl.end(), eab.begin(), eab.end());
@@ -918,6 +951,12 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
         v += (int)(ea.size() + eab.size()) / 3;
     for (auto& v : P.bwg_ptr)
         v += (int)(ea.size() + eab.size() + sy.size()) / 3;
+    for (auto& v : P.lead_ptr)
+        v += (int)P.wl.size() / 3;
+    P.wl.insert(P.wl.end(), lead.begin(), lead.end());
+    for (auto& v : P.sb_ptr)
+        v += (int)P.wl.size() / 3;
+    P.wl.insert(P.wl.end(), sb.begin(), sb.end());
     lap("8 work items");
 }
 

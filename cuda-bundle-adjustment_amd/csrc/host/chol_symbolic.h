@@ -63,6 +63,11 @@ struct CholPlan
     //   syrk        : 64x64 tile (row tile a, col tile b), a >= b
     std::vector<int32_t> wl;
     std::vector<int32_t> ea_ptr, eab_ptr, syrk_ptr, bwg_ptr; // [n_stages+1] item ranges per stage
+    // look-ahead schedule (chol_kernels.hip, k_up_potrf_la / k_up_lead): la_np = lead rows of a front
+    // (leading boundary block rows inside the parent's pivot columns), items lead: (front, -, -) per
+    // front with lead rows, sb: the syrk tiles that are not wholly inside the lead block
+    std::vector<int32_t> la_np;
+    std::vector<int32_t> lead_ptr, sb_ptr;
     // edge of the syrk tiles of each stage: 64, or 32 where a level has so few 64-tiles that the
     // launch would leave most CUs idle (its duration is then one tile's, and a 32-tile is shorter)
     std::vector<int32_t> stage_tile;

@@ -166,13 +166,18 @@ __device__ __forceinline__ void ea_chunk(const double* __restrict__ U, long ldc,
 // `part`: 0 = all rows; 1 = only the child rows that map into the parent's PIVOT rows (the parent's
 // F11: what its potrf needs); 2 = only the rows below them (F21 / F22).  Parts 1 and 2 touch
 // disjoint parent entries, so they may run in different workgroups of one launch.
+// The look-ahead schedule cuts part 2 once more at the parent's LEAD rows (its first la_np boundary
+// block rows: the ones inside the pivot columns of ITS parent): 3 = the rows that map into the lead
+// rows (what the lead block of the parent's update matrix needs), 4 = the rows below them.
 constexpr int EA_BATCH = 32;
 __device__ __forceinline__ void dev_extend_add(const CholPlanDev& p, double* __restrict__ fronts, int f, int cb0,
                                int cb1, int part)
 {
-    __shared__ int s_child[EA_BATCH][4]; // child front, first / past-last matching update block column,
-                                         // number of child rows (blocks) inside the parent's pivot block
+    __shared__ int s_child[EA_BATCH][5]; // child front, first / past-last matching update block column,
+                                         // number of child rows (blocks) inside the parent's pivot block,
+                                         // ... inside its pivot block or lead rows
     const int ncbp = p.ncb[f];
+    const int nlead = ncbp + (part >= 3 ? p.la_np[f] : 0);
     const long ldp = p.ldf[f], rhs_row = 6L * p.nb[f];
     double* Fp = fronts + p.off[f];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
@@ -189,7 +194,7 @@ __device__ __forceinline__ void dev_extend_add(const CholPlanDev& p, double* __r
             const int c = p.child[cbase + k];
             const int nbr = p.nb[c] - p.ncb[c];
             const int32_t* rel = p.rel + p.rel_ptr[c];
-            int jlo = 0, jhi = 0, nsp = 0;
+            int jlo = 0, jhi = 0, nsp = 0, nsl = 0;
             for (int base = 0; base < nbr; base += 64)
             {
                 const int i = base + lane;
@@ -197,9 +202,10 @@ __device__ __forceinline__ void dev_extend_add(const CholPlanDev& p, double* __r
                 jlo += __popcll(__ballot(i < nbr && rv < cb0));
                 jhi += __popcll(__ballot(i < nbr && rv < cb1));
                 nsp += __popcll(__ballot(i < nbr && rv < ncbp));
+                nsl += __popcll(__ballot(i < nbr && rv < nlead));
             }
             if (lane == 0)
-                s_child[k][0] = c, s_child[k][1] = jlo, s_child[k][2] = jhi, s_child[k][3] = nsp;
+                s_child[k][0] = c, s_child[k][1] = jlo, s_child[k][2] = jhi, s_child[k][3] = nsp, s_child[k][4] = nsl;
         }
         __syncthreads();
         for (int k = 0; k < nchild; k++)
@@ -213,11 +219,12 @@ __device__ __forceinline__ void dev_extend_add(const CholPlanDev& p, double* __r
             const int32_t* rel = p.rel + p.rel_ptr[c];
             const int nru = 6 * nbr + 1;
             const int isplit = 6 * s_child[k][3]; // child rows below this index map into parent pivot rows
+            const int isplit2 = 6 * s_child[k][4]; // ... into its pivot or lead rows
             int u = wv;
             for (int jb = jlo; jb < jhi; jb++)
             {
-                const int rbeg = part == 2 ? max(6 * jb, isplit) : 6 * jb;
-                const int rend = part == 1 ? min(nru, isplit) : nru;
+                const int rbeg = part == 4 ? max(6 * jb, isplit2) : part >= 2 ? max(6 * jb, isplit) : 6 * jb;
+                const int rend = part == 1 ? min(nru, isplit) : part == 3 ? min(nru, isplit2) : nru;
                 const int nch = rend > rbeg ? (rend - rbeg + 63) >> 6 : 0;
                 for (; u < nch; u += nwv)
                     ea_chunk(U, ldc, nru, nbr, rel, Fp, ldp, rhs_row, jb, u, lane, sink, rbeg, rend);
@@ -826,10 +833,16 @@ __device__ __forceinline__ void dev_syrk_tiles(double* __restrict__ F, long ld, 
 // with tj == ti (or tj < 0: a tile row that has no diagonal tile) stores X_i to the compact
 // L21 buffer that the backward substitution reads.
 // LDS: Pi | Pj, k-major panels (stride PST) that first hold B and then, in place, X.
+// qmask (look-ahead schedule): the leading qmask x qmask block of U and the first qmask rows of
+// L21 belong to the front's lead workgroup (LEAD = true, called as tile (0,0) with nt = nrs = q, or
+// as tile (1,0) when 64 < q <= 96: that one then also does the two diagonal tiles from the X panels
+// it has in LDS anyway and stores the L21 rows of both) and are not stored by the other tiles.
+template <bool LEAD>
 __device__ __forceinline__ void dev_trsyrk_tile(double* __restrict__ F, long ld, int ncs, int nt, int nrs,
                                                 int ti, int tj, const double* __restrict__ Wg,
                                                 double* __restrict__ L21, long ld2,
-                                                double* __restrict__ lds, double* __restrict__ junk)
+                                                double* __restrict__ lds, double* __restrict__ junk,
+                                                int qmask)
 {
     constexpr int KC = KC_SYRK;
     constexpr int PST = TPST; // panel stride of this kernel (leaves LDS room for W)
@@ -898,6 +911,21 @@ __device__ __forceinline__ void dev_trsyrk_tile(double* __restrict__ F, long ld,
             const double* src = ok ? U + ((long)j * ld + i) : sink;
             uold[q] = *src;
         }
+        double uold2[2][4]; // LEAD, two panels: the diagonal tiles (tj,tj) and (ti,ti)
+        if (LEAD && two)
+        {
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                {
+                    const int tb = h == 0 ? tj : ti;
+                    const int i = 64 * tb + 16 * wr + ln, j = 64 * tb + 16 * wc + lk + 4 * q;
+                    const bool ok = i < nt && j < nrs && i >= j;
+                    const double* src = ok ? U + ((long)j * ld + i) : sink;
+                    uold2[h][q] = *src;
+                }
+        }
 #pragma unroll
         for (int u = 0; u < 6; u++)
         {
@@ -959,8 +987,10 @@ __device__ __forceinline__ void dev_trsyrk_tile(double* __restrict__ F, long ld,
                     Pi[c * PST + 16 * rg + ln] = xi[h][q];
                     if (two)
                         Pj[c * PST + 16 * rg + ln] = xj[h][q];
-                    if (!two && c < ncs && row < nt) // diag or solo: this tile owns L21 rows ti
+                    if ((!two || LEAD) && c < ncs && row < nt && row >= qmask) // diag or solo: this tile owns L21 rows ti
                         L21[(long)c * ld2 + row] = xi[h][q];
+                    if (LEAD && two && c < ncs) // rows tj (all below nt: ti > tj)
+                        L21[(long)c * ld2 + 64 * tj + 16 * rg + ln] = xj[h][q];
                 }
             }
         }
@@ -982,9 +1012,38 @@ __device__ __forceinline__ void dev_trsyrk_tile(double* __restrict__ F, long ld,
             for (int q = 0; q < 4; q++)
             { // branch-free: masked lanes store into their sink slot
                 const int i = 64 * ti + 16 * wr + ln, j = 64 * tj + 16 * wc + lk + 4 * q;
-                const bool ok = i < nt && j < nrs && i >= j;
+                const bool ok = i < nt && j < nrs && i >= j && !(i < qmask && j < qmask);
                 double* dst = ok ? U + ((long)j * ld + i) : sink;
                 *dst = uold[q] - acc[q];
+            }
+            if (LEAD && two)
+            { // the diagonal tiles of both panels: U(tb,tb) -= X_tb X_tb^T
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+                {
+                    const int tb = h == 0 ? tj : ti;
+                    const double* Pd = h == 0 ? Pj : Pi;
+                    if (wr >= wc && 64 * tb + 16 * wr < nt) // else: above the diagonal or past the end (uniform per wave)
+                    {
+                        double4_t a2 = {0, 0, 0, 0};
+                        for (int k0 = 0; k0 < ncs; k0 += 4)
+                        {
+                            const int k = min(k0 + lk, ncs - 1);
+                            const bool kok = k0 + lk < ncs;
+                            const double av = Pd[k * PST + 16 * wc + ln];
+                            const double bv = Pd[k * PST + 16 * wr + ln];
+                            a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(kok ? av : 0.0, bv, a2, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                        {
+                            const int i = 64 * tb + 16 * wr + ln, j = 64 * tb + 16 * wc + lk + 4 * q;
+                            const bool ok = i < nt && j < nrs && i >= j;
+                            double* dst = ok ? U + ((long)j * ld + i) : sink;
+                            *dst = uold2[h][q] - a2[q];
+                        }
+                    }
+                }
             }
         }
     }
@@ -1002,7 +1061,8 @@ constexpr int TPST32 = 48; // panel stride: the two 16-lane halves of a ds_read_
 __device__ __forceinline__ void dev_trsyrk_tile32(double* __restrict__ F, long ld, int ncs, int nt, int nrs,
                                                   int ti, int tj, const double* __restrict__ Wg,
                                                   double* __restrict__ L21, long ld2,
-                                                  double* __restrict__ lds, double* __restrict__ junk)
+                                                  double* __restrict__ lds, double* __restrict__ junk,
+                                                  int qmask)
 {
     constexpr int KC = KC_SYRK;
     constexpr int PST = TPST32;
@@ -1110,7 +1170,7 @@ __device__ __forceinline__ void dev_trsyrk_tile32(double* __restrict__ F, long l
             Pi[c * PST + 16 * rg + ln] = xi[q];
             if (two)
                 Pj[c * PST + 16 * rg + ln] = xj[q];
-            if (!two && c < ncs && row < nt) // diag or solo: this tile owns L21 rows ti
+            if (!two && c < ncs && row < nt && row >= qmask) // diag or solo: this tile owns L21 rows ti
                 L21[(long)c * ld2 + row] = xi[q];
         }
     }
@@ -1131,7 +1191,7 @@ __device__ __forceinline__ void dev_trsyrk_tile32(double* __restrict__ F, long l
         for (int q = 0; q < 4; q++)
         {
             const int i = 32 * ti + 16 * wr + ln, j = 32 * tj + 16 * wc + lk + 4 * q;
-            const bool ok = i < nt && j < nrs && i >= j;
+            const bool ok = i < nt && j < nrs && i >= j && !(i < qmask && j < qmask);
             double* dst = ok ? U + ((long)j * ld + i) : sink;
             *dst = uold[q] - acc[q];
         }
@@ -1327,8 +1387,8 @@ __global__ __launch_bounds__(BIG) void k_up_trsyrk(CholPlanDev p, double* __rest
     const int32_t* it = wl + 3 * blockIdx.x;
     const int f = it[0];
     const int ncs = 6 * p.ncb[f], nrs = 6 * (p.nb[f] - p.ncb[f]);
-    dev_trsyrk_tile(fronts + p.off[f], p.ldf[f], ncs, nrs + 1, nrs, it[1], it[2],
-                    p.winv + p.woff[f], p.l21 + p.l21off[f], nrs + 1, lds, p.junk);
+    dev_trsyrk_tile<false>(fronts + p.off[f], p.ldf[f], ncs, nrs + 1, nrs, it[1], it[2],
+                           p.winv + p.woff[f], p.l21 + p.l21off[f], nrs + 1, lds, p.junk, 0);
     stamp(4, 7);
     stamp_value(4, 6, 1000000L * (it[1] * 10 + it[2] + 1) + 1000L * ncs + nrs);
 }
@@ -1341,7 +1401,88 @@ __global__ __launch_bounds__(BIG) void k_up_trsyrk32(CholPlanDev p, double* __re
     const int f = it[0];
     const int ncs = 6 * p.ncb[f], nrs = 6 * (p.nb[f] - p.ncb[f]);
     dev_trsyrk_tile32(fronts + p.off[f], p.ldf[f], ncs, nrs + 1, nrs, it[1], it[2], p.winv + p.woff[f],
-                      p.l21 + p.l21off[f], nrs + 1, lds, p.junk);
+                      p.l21 + p.l21off[f], nrs + 1, lds, p.junk, 0);
+}
+
+// ---- look-ahead schedule (CUGO_LOOKAHEAD=1; off by default, see chol_solver.h): two launches per level, the bulk of the update matrix of level
+// k-1 computed WHILE level k factors its pivot blocks:
+//   k_up_potrf_la : workgroups [0, npotrf)  F11 += children (extend-add part 1), L11, W   of level k
+//                   the others              update tiles of level k-1 outside the lead blocks
+//   k_up_lead     : workgroups [0, nlead)   per front of level k: extend-add part 3 (its lead rows),
+//                                           then X and the lead block of U — all that the PARENT's
+//                                           potrf waits for
+//                   the others              extend-add part 4 (everything below the lead rows)
+// A front's lead rows are its first la_np boundary block rows (<= 16: the ones inside the parent's
+// pivot columns).  The dependent chain of a level is potrf + one lead workgroup instead of potrf +
+// the whole trsm/syrk launch; sums keep their fixed order (every entry has one writer per phase).
+__device__ __forceinline__ void dev_potrf_front(const CholPlanDev& p, double* __restrict__ fronts, int f,
+                                                double* __restrict__ lds, int32_t* __restrict__ fail)
+{
+    const int ncs = 6 * p.ncb[f];
+    if (p.alias_of[f] < 0 && p.child_ptr[f + 1] > p.child_ptr[f])
+    {
+        dev_extend_add(p, fronts, f, 0, p.ncb[f], 1);
+        __threadfence_block();
+        __syncthreads();
+    }
+    const int ncp = pad16(ncs);
+    double* Ls = lds;
+    double* dinv = lds + NC_MAX * LLD;
+    double* Vs = dinv + NC_MAX;
+    dev_potrf(fronts + p.off[f], p.ldf[f], ncs, Ls, dinv, fail);
+    __syncthreads();
+    if ((threadIdx.x & 63) < 16 && (int)(threadIdx.x >> 6) < (ncp >> 4))
+        inv_diag16_block(Ls, dinv, threadIdx.x >> 6, threadIdx.x & 15, Vs, nullptr, ncp);
+    __syncthreads();
+    dev_winv(Ls, ncp, Vs, p.winv + p.woff[f]);
+}
+
+__global__ __launch_bounds__(BIG) void k_up_potrf_la(CholPlanDev p, double* __restrict__ fronts,
+                                                     int task0, int npotrf,
+                                                     const int32_t* __restrict__ wl_tiles, int tile,
+                                                     int32_t* __restrict__ fail)
+{
+    extern __shared__ double lds[];
+    if ((int)blockIdx.x < npotrf)
+    {
+        dev_potrf_front(p, fronts, p.task_fronts[p.task_ptr[task0 + blockIdx.x]], lds, fail);
+        return;
+    }
+    const int32_t* it = wl_tiles + 3 * (blockIdx.x - npotrf);
+    const int f = it[0];
+    const int ncs = 6 * p.ncb[f], nrs = 6 * (p.nb[f] - p.ncb[f]), q = 6 * p.la_np[f];
+    if (tile == 32)
+        dev_trsyrk_tile32(fronts + p.off[f], p.ldf[f], ncs, nrs + 1, nrs, it[1], it[2], p.winv + p.woff[f],
+                          p.l21 + p.l21off[f], nrs + 1, lds, p.junk, q);
+    else
+        dev_trsyrk_tile<false>(fronts + p.off[f], p.ldf[f], ncs, nrs + 1, nrs, it[1], it[2],
+                               p.winv + p.woff[f], p.l21 + p.l21off[f], nrs + 1, lds, p.junk, q);
+}
+
+__global__ __launch_bounds__(BIG) void k_up_lead(CholPlanDev p, double* __restrict__ fronts,
+                                                 const int32_t* __restrict__ wl_lead, int nlead,
+                                                 const int32_t* __restrict__ wl_eap, int neap,
+                                                 const int32_t* __restrict__ wl_eab)
+{
+    extern __shared__ double lds[];
+    if ((int)blockIdx.x >= nlead)
+    {
+        const int b = blockIdx.x - nlead;
+        const int32_t* it = b < neap ? wl_eap + 3 * b : wl_eab + 3 * (b - neap);
+        dev_extend_add(p, fronts, it[0], it[1], it[2], 4);
+        return;
+    }
+    const int f = wl_lead[3 * blockIdx.x];
+    const int ncb = p.ncb[f], np = p.la_np[f];
+    const int ncs = 6 * ncb, nrs = 6 * (p.nb[f] - ncb), q = 6 * np;
+    if (p.alias_of[f] < 0 && p.child_ptr[f + 1] > p.child_ptr[f])
+    {
+        dev_extend_add(p, fronts, f, 0, ncb + np, 3);
+        __threadfence_block();
+        __syncthreads();
+    }
+    dev_trsyrk_tile<true>(fronts + p.off[f], p.ldf[f], ncs, q, q, q > 64 ? 1 : 0, 0, p.winv + p.woff[f],
+                          p.l21 + p.l21off[f], nrs + 1, lds, p.junk, 0);
 }
 
 // the ancestor part of a front's backward mat-vec, one launch ahead of the front itself:
@@ -1493,6 +1634,29 @@ void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fron
         CUGO_LAUNCH(k_up_trsyrk, dim3(nsy), dim3(BIG), trsyrk_lds() * sizeof(double), s, p, d_fronts,
                            d_wl + 3L * sy0);
     }
+}
+
+void launch_chol_potrf_la(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0, int ntasks,
+                          const int32_t* d_tiles, int ntiles, int tile, int32_t* d_fail)
+{
+    if (ntasks + ntiles <= 0)
+        return;
+    const size_t lds32 = (2 * KC_SYRK * TPST32 + 21 * 256) * sizeof(double);
+    const size_t bytes = std::max(chol_lds_potrf_bytes(),
+                                  ntiles > 0 ? (tile == 32 ? lds32 : trsyrk_lds() * sizeof(double)) : size_t(0));
+    ensure_lds(reinterpret_cast<const void*>(k_up_potrf_la), std::max(chol_lds_potrf_bytes(), trsyrk_lds() * sizeof(double)));
+    CUGO_LAUNCH(k_up_potrf_la, dim3(ntasks + ntiles), dim3(BIG), bytes, s, p, d_fronts, task0, ntasks,
+                d_tiles, tile, d_fail);
+}
+
+void launch_chol_lead(hipStream_t s, const CholPlanDev& p, double* d_fronts, const int32_t* d_lead,
+                      int nlead, const int32_t* d_eap, int neap, const int32_t* d_eab, int neab)
+{
+    if (nlead + neap + neab <= 0)
+        return;
+    ensure_lds(reinterpret_cast<const void*>(k_up_lead), trsyrk_lds() * sizeof(double));
+    CUGO_LAUNCH(k_up_lead, dim3(nlead + neap + neab), dim3(BIG), trsyrk_lds() * sizeof(double), s, p,
+                d_fronts, d_lead, nlead, d_eap, neap, d_eab);
 }
 
 void launch_chol_backward_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,

@@ -95,6 +95,8 @@ struct CholPlanDev
     const int32_t* alias_of;   // that child, or -1
     const int32_t* bw_np;      // backward: leading boundary block rows owned by the parent when the
                                // rest of the front's mat-vec is done ahead of time, else -1
+    const int32_t* la_np;      // look-ahead: leading boundary block rows inside the parent's pivot columns
+                               // (the front's "lead rows"; 0 for a root)
     const int64_t* woff;       // offset (doubles) of W = L11^-1 (pad16(6*ncb)^2, column-major) in winv
     double* winv;
     const int64_t* l21off;     // offset of the front's L21 (+ rhs row) in l21, or -1: in the front itself
@@ -138,6 +140,14 @@ void launch_chol_subtree_stage(hipStream_t s, const CholPlanDev& p, double* d_fr
 void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,
                              int ntasks, const int32_t* d_wl, int eap0, int neap, int ea0, int nea,
                              int sy0, int nsy, int tile, size_t lds_bytes, int32_t* d_fail);
+// look-ahead schedule, two launches per level (see k_up_potrf_la / k_up_lead):
+//   potrf of level k (ntasks fronts from task0) together with the non-lead update tiles of level k-1
+//   (items front, ti, tj of edge `tile`); then the lead workgroups of level k (items front,-,-)
+//   together with the extend-add below the lead rows (items front, first, past-last block column)
+void launch_chol_potrf_la(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0, int ntasks,
+                          const int32_t* d_tiles, int ntiles, int tile, int32_t* d_fail);
+void launch_chol_lead(hipStream_t s, const CholPlanDev& p, double* d_fronts, const int32_t* d_lead,
+                      int nlead, const int32_t* d_eap, int neap, const int32_t* d_eab, int neab);
 // backward substitution of one level: ntasks workgroups solve the level's fronts; ngemv more
 // workgroups (items d_wl_gemv: front, first column, -) do the ancestor part of the mat-vec of
 // the CHILDREN of these fronts, which the next launch then does not have to wait for

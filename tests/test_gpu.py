@@ -291,7 +291,12 @@ def test_float32_block_kernels_vs_oracle(ctx, oracle_lib):
                                  {"CUGO_MAX_SUPER_COLS": "24", "CUGO_ZERO_FRAC": "0.9", "CUGO_MIN_SUBTREE_TASKS": "0"},
                                  # every level cut into 64x64 tiles (small problems otherwise take the 32x32 form)
                                  {"CUGO_TILE32_MAX_TILES": "0"},
-                                 {"CUGO_TILE32_MAX_TILES": "0", "CUGO_ALIAS_CHAINS": "0", "CUGO_MAX_SUPER_COLS": "5"}])
+                                 {"CUGO_TILE32_MAX_TILES": "0", "CUGO_ALIAS_CHAINS": "0", "CUGO_MAX_SUPER_COLS": "5"},
+                                 # the look-ahead schedule (opt-in): a level's update tiles run with the next
+                                 # level's potrf, only the lead block of each front is computed in between
+                                 {"CUGO_LOOKAHEAD": "1"},
+                                 {"CUGO_LOOKAHEAD": "1", "CUGO_TILE32_MAX_TILES": "0", "CUGO_ALIAS_CHAINS": "0"},
+                                 {"CUGO_LOOKAHEAD": "1", "CUGO_MIN_SUBTREE_TASKS": "0", "CUGO_MAX_SUPER_COLS": "5"}])
 def test_sparse_cholesky_vs_numpy(ctx, env, monkeypatch):
     from test_host import covis_pattern, patterns, random_spd_bsr
     for k, v in env.items():

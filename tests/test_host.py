@@ -292,7 +292,7 @@ def _expected_structure(d):
     return len(pairs), products, offdiag
 
 
-@pytest.mark.parametrize("shape", ["small_mixed", "fixed_heavy", "medium", "all_landmarks_fixed"])
+@pytest.mark.parametrize("shape", ["small_mixed", "fixed_heavy", "medium", "all_landmarks_fixed", "threads"])
 def test_plan_only_graph_runs_the_whole_host_side(lib, shape):
     """a plan-only graph (no GPU) drives flattening, index assignment, landmark-major layout, Hsc
     pattern, product lists, ordering and symbolic factorisation; its statistics match the
@@ -306,6 +306,11 @@ def test_plan_only_graph_runs_the_whole_host_side(lib, shape):
                                fixed_landmarks=tuple(range(0, 400, 3)), loop_closure=True, stereo_frac=1.0)
     elif shape == "medium":
         d = cugo.synth(248, 26127, 95037, seed=7, n_loop_closures=500)
+    elif shape == "threads":
+        # large enough for every threaded host pass: chunked edge sort, per-row structure build
+        # (>= 200k co-visibility entries), nested dissection halves on two threads (> 2000 nodes);
+        # `tools/run_san.sh thread` runs this under ThreadSanitizer
+        d = cugo.synth(2600, 60000, 262000, seed=12, n_loop_closures=1500)
     else:
         d = synth.make_problem(n_poses=9, n_landmarks=80, seed=2, fixed_landmarks=tuple(range(80)))
     B, products, offdiag = _expected_structure(d)

@@ -58,7 +58,9 @@ def main():
     pl = plan_arrays(lib, s)
     stp, tp, tf = pl["stage_task_ptr"], pl["task_ptr"], pl["task_fronts"]
     ncb, nb, cp = pl["ncb"], pl["nb"], pl["child_ptr"]
-    print("stages", len(stp) - 1, "fronts", len(ncb))
+    nz, fl, ns_, nst, fb = C.c_double(), C.c_double(), C.c_int(), C.c_int(), C.c_double()
+    lib.cugo_chol_stats(s, C.byref(nz), C.byref(fl), C.byref(ns_), C.byref(nst), C.byref(fb))
+    print("stages", len(stp) - 1, "fronts", len(ncb), "nnzL %.3g flops %.3g front bytes %.3g" % (nz.value, fl.value, fb.value))
     for st in range(len(stp) - 1):
         fr = [f for t in range(stp[st], stp[st + 1]) for f in tf[tp[t]:tp[t + 1]]]
         w = [int(ncb[f]) for f in fr]

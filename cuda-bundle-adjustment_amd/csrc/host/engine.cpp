@@ -773,12 +773,14 @@ void Engine::build_structure()
     InitLaps laps;
     hipStream_t s = m.ctx.stream;
     const int P = m.P, L = m.L;
-    // ---- device-side build (single-process graphs): pairs per landmark -> stable radix sort by pose
-    // pair -> runs = off-diagonal blocks; the same lists, in the same order, as the host passes below
-    // (which remain for shards — they need the GLOBAL pattern — and for plan-only / forced runs)
-    if (m.world == 1 && !m.plan_only && m.E > 0 && !std::getenv("CUGO_SCHUR_PLAN") && !std::getenv("CUGO_HOST_STRUCTURE"))
+    // ---- device-side build: pairs per landmark -> stable radix sort by pose pair -> runs = off-diagonal
+    // blocks; the same lists, in the same order, as the host passes below (which remain for plan-only
+    // and forced runs).  A shard builds the pattern from the global co-visibility lists.
+    const bool shard = m.world > 1 || m.comm; // local slots are a subset: the pattern comes from the global lists
+    if (!m.plan_only && (m.E > 0 || shard) && !std::getenv("CUGO_SCHUR_PLAN") && !std::getenv("CUGO_HOST_STRUCTURE"))
     {
-        if (build_structure_gpu(s, m.E, P, m.Lall, m.d_e_pose.data(), m.d_flags.data(), m.d_lm_ptr.data(), m.gstruct))
+        if (build_structure_gpu(s, m.E, P, m.Lall, m.d_e_pose.data(), m.d_flags.data(), m.d_lm_ptr.data(), m.gstruct,
+                                shard ? L : 0, shard ? m.cov_ptr.data() : nullptr, shard ? m.cov_pose.data() : nullptr))
         {
             laps.lap("structure: device build (pairs, sort, runs)");
             m.gstruct.scratch.release();
@@ -799,7 +801,9 @@ void Engine::build_structure()
             m.chol.analyze(P, m.hsc_rowptr.data(), m.hsc_colind.data());
             prof_[PROF_SYMBOLIC] += ms_since(t1g);
             laps.lap("structure: symbolic + plan upload");
-            fill_structure_stats(B, (double)m.gstruct.Moff + nff, (double)m.gstruct.Moff);
+            // all products of the graph (every free-free edge also has its diagonal one) / local off-diagonal ones
+            fill_structure_stats(B, (double)m.gstruct.Mglobal + (shard ? (double)m.cov_pose.size() : nff),
+                                 (double)m.gstruct.Moff);
             sstats_.schur_slots = 0;
             m.structure_dirty = false;
             return;

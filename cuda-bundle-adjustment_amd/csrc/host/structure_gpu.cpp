@@ -13,8 +13,10 @@
 //   4. run heads + scan -> one run per off-diagonal block; rows by binary search; the diagonal
 //      block of every free pose is inserted in front of its row
 // The pattern (rowptr / colind, ~1 MB) goes back to the host for the symbolic analysis.
-// Single-process graphs only: a shard needs the GLOBAL pattern, which its local edges do not give
-// (the host build handles that case).
+// A shard needs the GLOBAL pattern (the all-reduce payload has one layout on every rank), which its
+// local edges do not give: it runs steps 1-4 twice — over the global co-visibility lists (keys only)
+// for the pattern, over its local slots for the lists — and finds the list of every global block by
+// binary search among its local runs (most blocks of a shard have few or no local products).
 #include "structure_gpu.h"
 
 #include <rocprim/rocprim.hpp>
@@ -26,9 +28,10 @@ namespace
 {
 constexpr int TB = 256;
 
+// flags == nullptr: every entry counts (the global co-visibility lists hold free-free edges only)
 __device__ __forceinline__ bool slot_ff(const uint8_t* __restrict__ flags, int s)
 {
-    return (flags[s] & (CUGO_EDGE_FIXED_L | CUGO_EDGE_FIXED_P | CUGO_EDGE_INACTIVE)) == 0;
+    return !flags || (flags[s] & (CUGO_EDGE_FIXED_L | CUGO_EDGE_FIXED_P | CUGO_EDGE_INACTIVE)) == 0;
 }
 
 __global__ __launch_bounds__(TB) void k_count_pairs(int Lall, const int32_t* __restrict__ lm_ptr,
@@ -64,7 +67,8 @@ __global__ __launch_bounds__(TB) void k_emit_pairs(int Lall, const int32_t* __re
             if (slot_ff(flags, b))
             {
                 keys[o] = pa | (uint64_t)pose[b];
-                vals[o] = ((uint64_t)a << 32) | (uint32_t)b;
+                if (vals)
+                    vals[o] = ((uint64_t)a << 32) | (uint32_t)b;
                 o++;
             }
     }
@@ -84,22 +88,55 @@ __global__ __launch_bounds__(TB) void k_runs(size_t M, const uint64_t* __restric
                                              const uint32_t* __restrict__ rank, int bits,
                                              int32_t* __restrict__ run_pa, int32_t* __restrict__ run_pb,
                                              int32_t* __restrict__ run_start, int32_t* __restrict__ off_ei,
-                                             int32_t* __restrict__ off_ej)
+                                             int32_t* __restrict__ off_ej, uint64_t* __restrict__ run_key)
 {
     const size_t i = (size_t)blockIdx.x * TB + threadIdx.x;
     if (i >= M)
         return;
-    const uint64_t v = vals[i];
-    off_ei[i] = (int32_t)(v >> 32);
-    off_ej[i] = (int32_t)(v & 0xffffffffu);
+    if (vals)
+    {
+        const uint64_t v = vals[i];
+        off_ei[i] = (int32_t)(v >> 32);
+        off_ej[i] = (int32_t)(v & 0xffffffffu);
+    }
     if (head[i])
     {
         const uint32_t r = rank[i];
         const uint64_t k = keys[i];
-        run_pa[r] = (int32_t)(k >> bits);
-        run_pb[r] = (int32_t)(k & ((1ull << bits) - 1));
-        run_start[r] = (int32_t)i;
+        if (run_pa)
+        {
+            run_pa[r] = (int32_t)(k >> bits);
+            run_pb[r] = (int32_t)(k & ((1ull << bits) - 1));
+        }
+        if (run_key)
+            run_key[r] = k;
+        if (run_start)
+            run_start[r] = (int32_t)i;
     }
+}
+
+// sharded build: start of the local list of every global run = start of the first local run whose
+// key is not smaller (an equal key: that run IS the block's list; a larger one: empty list)
+__global__ __launch_bounds__(TB) void k_match_runs(int n_runs, const int32_t* __restrict__ run_pa,
+                                                   const int32_t* __restrict__ run_pb, int bits, int n_lruns,
+                                                   const uint64_t* __restrict__ lrun_key,
+                                                   const int32_t* __restrict__ lrun_start, int32_t Mlocal,
+                                                   int32_t* __restrict__ run_start)
+{
+    const int t = blockIdx.x * TB + threadIdx.x;
+    if (t >= n_runs)
+        return;
+    const uint64_t key = ((uint64_t)run_pa[t] << bits) | (uint64_t)run_pb[t];
+    int lo = 0, hi = n_lruns;
+    while (lo < hi)
+    {
+        const int mid = (lo + hi) >> 1;
+        if (lrun_key[mid] < key)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    run_start[t] = lo < n_lruns ? lrun_start[lo] : Mlocal;
 }
 
 // rowptr[p] = (first run whose row is >= p) + p : every earlier row has one diagonal block in front
@@ -149,65 +186,125 @@ __global__ __launch_bounds__(TB) void k_blocks(int P, int n_runs, size_t M, cons
 }
 } // namespace
 
-bool build_structure_gpu(hipStream_t s, int E, int P, int Lall, const int32_t* d_e_pose, const uint8_t* d_flags,
-                         const int32_t* d_lm_ptr, GpuStructure& out)
+// steps 1-3 + run detection over one set of per-landmark lists; leaves the sorted keys (and values)
+// in w.keys_b / w.vals_b, the run heads and ranks in w.head / w.rank.  Returns false on int32 overflow.
+static bool sorted_pairs(hipStream_t s, int nlists, const int32_t* d_ptr, const uint8_t* d_flags, const int32_t* d_pose,
+                         int bits, bool with_vals, GpuStructureScratch& w, size_t& M, int& n_runs)
 {
-    out.B = 0, out.Moff = 0;
-    if (P <= 0 || Lall <= 0 || E <= 0)
-        return false;
-    int bits = 1;
-    while ((1ll << bits) < (long long)P + 1)
-        bits++;
-    GpuStructureScratch& w = out.scratch;
-    w.npairs.resize((size_t)Lall + 1), w.pair_off.resize((size_t)Lall + 1);
-    CUGO_HIP(hipMemsetAsync(w.npairs.data() + Lall, 0, sizeof(uint64_t), s));
-    hipLaunchKernelGGL(k_count_pairs, dim3((Lall + TB - 1) / TB), dim3(TB), 0, s, Lall, d_lm_ptr, d_flags,
+    w.npairs.resize((size_t)nlists + 1), w.pair_off.resize((size_t)nlists + 1);
+    CUGO_HIP(hipMemsetAsync(w.npairs.data() + nlists, 0, sizeof(uint64_t), s));
+    hipLaunchKernelGGL(k_count_pairs, dim3((nlists + TB - 1) / TB), dim3(TB), 0, s, nlists, d_ptr, d_flags,
                        w.npairs.data());
     size_t tb = 0;
-    CUGO_HIP(rocprim::exclusive_scan(nullptr, tb, w.npairs.data(), w.pair_off.data(), (uint64_t)0, (size_t)Lall + 1,
+    CUGO_HIP(rocprim::exclusive_scan(nullptr, tb, w.npairs.data(), w.pair_off.data(), (uint64_t)0, (size_t)nlists + 1,
                                      rocprim::plus<uint64_t>(), s));
     w.temp.resize(tb + 16);
     CUGO_HIP(rocprim::exclusive_scan(w.temp.data(), tb, w.npairs.data(), w.pair_off.data(), (uint64_t)0,
-                                     (size_t)Lall + 1, rocprim::plus<uint64_t>(), s));
+                                     (size_t)nlists + 1, rocprim::plus<uint64_t>(), s));
     uint64_t M64 = 0;
-    CUGO_HIP(hipMemcpyAsync(&M64, w.pair_off.data() + Lall, sizeof M64, hipMemcpyDeviceToHost, s));
+    CUGO_HIP(hipMemcpyAsync(&M64, w.pair_off.data() + nlists, sizeof M64, hipMemcpyDeviceToHost, s));
     CUGO_HIP(hipStreamSynchronize(s));
     if (M64 >= (1ull << 31) - 1)
         return false; // the lists are indexed with int32 (as the host build's are)
-    const size_t M = (size_t)M64;
+    M = (size_t)M64;
+    n_runs = 0;
+    if (M == 0)
+        return true;
     const int nM = (int)((M + TB - 1) / TB);
-    out.off_ei.resize(M + 16), out.off_ej.resize(M + 16);
-    int n_runs = 0;
-    if (M > 0)
+    w.keys_a.resize(M), w.keys_b.resize(M);
+    if (with_vals)
+        w.vals_a.resize(M), w.vals_b.resize(M);
+    hipLaunchKernelGGL(k_emit_pairs, dim3((nlists + TB - 1) / TB), dim3(TB), 0, s, nlists, d_ptr, d_flags, d_pose, bits,
+                       w.pair_off.data(), w.keys_a.data(), with_vals ? w.vals_a.data() : nullptr);
+    tb = 0;
+    if (with_vals)
     {
-        w.keys_a.resize(M), w.keys_b.resize(M), w.vals_a.resize(M), w.vals_b.resize(M);
-        hipLaunchKernelGGL(k_emit_pairs, dim3((Lall + TB - 1) / TB), dim3(TB), 0, s, Lall, d_lm_ptr, d_flags, d_e_pose,
-                           bits, w.pair_off.data(), w.keys_a.data(), w.vals_a.data());
-        tb = 0;
         CUGO_HIP(rocprim::radix_sort_pairs(nullptr, tb, w.keys_a.data(), w.keys_b.data(), w.vals_a.data(),
                                            w.vals_b.data(), M, 0u, (unsigned)(2 * bits), s));
         w.temp.resize(tb + 16);
         CUGO_HIP(rocprim::radix_sort_pairs(w.temp.data(), tb, w.keys_a.data(), w.keys_b.data(), w.vals_a.data(),
                                            w.vals_b.data(), M, 0u, (unsigned)(2 * bits), s));
-        w.head.resize(M + 1), w.rank.resize(M + 1);
-        hipLaunchKernelGGL(k_heads, dim3(nM), dim3(TB), 0, s, M, w.keys_b.data(), w.head.data());
-        CUGO_HIP(hipMemsetAsync(w.head.data() + M, 0, sizeof(uint32_t), s));
-        tb = 0;
-        CUGO_HIP(rocprim::exclusive_scan(nullptr, tb, w.head.data(), w.rank.data(), 0u, M + 1, rocprim::plus<uint32_t>(), s));
-        w.temp.resize(tb + 16);
-        CUGO_HIP(rocprim::exclusive_scan(w.temp.data(), tb, w.head.data(), w.rank.data(), 0u, M + 1,
-                                         rocprim::plus<uint32_t>(), s));
-        uint32_t nr = 0;
-        CUGO_HIP(hipMemcpyAsync(&nr, w.rank.data() + M, sizeof nr, hipMemcpyDeviceToHost, s));
-        CUGO_HIP(hipStreamSynchronize(s));
-        n_runs = (int)nr;
-        w.run_pa.resize((size_t)n_runs + 1), w.run_pb.resize((size_t)n_runs + 1), w.run_start.resize((size_t)n_runs + 1);
-        hipLaunchKernelGGL(k_runs, dim3(nM), dim3(TB), 0, s, M, w.keys_b.data(), w.vals_b.data(), w.head.data(),
-                           w.rank.data(), bits, w.run_pa.data(), w.run_pb.data(), w.run_start.data(),
-                           out.off_ei.data(), out.off_ej.data());
     }
     else
-        w.run_pa.resize(1), w.run_pb.resize(1), w.run_start.resize(1);
+    {
+        CUGO_HIP(rocprim::radix_sort_keys(nullptr, tb, w.keys_a.data(), w.keys_b.data(), M, 0u, (unsigned)(2 * bits), s));
+        w.temp.resize(tb + 16);
+        CUGO_HIP(rocprim::radix_sort_keys(w.temp.data(), tb, w.keys_a.data(), w.keys_b.data(), M, 0u,
+                                          (unsigned)(2 * bits), s));
+    }
+    w.head.resize(M + 1), w.rank.resize(M + 1);
+    hipLaunchKernelGGL(k_heads, dim3(nM), dim3(TB), 0, s, M, w.keys_b.data(), w.head.data());
+    CUGO_HIP(hipMemsetAsync(w.head.data() + M, 0, sizeof(uint32_t), s));
+    tb = 0;
+    CUGO_HIP(rocprim::exclusive_scan(nullptr, tb, w.head.data(), w.rank.data(), 0u, M + 1, rocprim::plus<uint32_t>(), s));
+    w.temp.resize(tb + 16);
+    CUGO_HIP(rocprim::exclusive_scan(w.temp.data(), tb, w.head.data(), w.rank.data(), 0u, M + 1,
+                                     rocprim::plus<uint32_t>(), s));
+    uint32_t nr = 0;
+    CUGO_HIP(hipMemcpyAsync(&nr, w.rank.data() + M, sizeof nr, hipMemcpyDeviceToHost, s));
+    CUGO_HIP(hipStreamSynchronize(s));
+    n_runs = (int)nr;
+    return true;
+}
+
+bool build_structure_gpu(hipStream_t s, int E, int P, int Lall, const int32_t* d_e_pose, const uint8_t* d_flags,
+                         const int32_t* d_lm_ptr, GpuStructure& out, int L, const int32_t* h_cov_ptr,
+                         const int32_t* h_cov_pose)
+{
+    out.B = 0, out.Moff = 0, out.Mglobal = 0;
+    if (P <= 0 || Lall <= 0 || E < 0)
+        return false;
+    const bool sharded = h_cov_ptr != nullptr;
+    if (!sharded && E == 0)
+        return false;
+    int bits = 1;
+    while ((1ll << bits) < (long long)P + 1)
+        bits++;
+    GpuStructureScratch& w = out.scratch;
+    // ---- the local slots: contribution lists (and, single process, the pattern)
+    size_t M = 0;
+    int n_lruns = 0;
+    if (E > 0 && !sorted_pairs(s, Lall, d_lm_ptr, d_flags, d_e_pose, bits, true, w, M, n_lruns))
+        return false;
+    const int nM = (int)((M + TB - 1) / TB);
+    out.off_ei.resize(M + 16), out.off_ej.resize(M + 16);
+    int n_runs = n_lruns;
+    size_t Mg = M;
+    if (!sharded)
+    {
+        w.run_pa.resize((size_t)n_runs + 1), w.run_pb.resize((size_t)n_runs + 1), w.run_start.resize((size_t)n_runs + 1);
+        if (M > 0)
+            hipLaunchKernelGGL(k_runs, dim3(nM), dim3(TB), 0, s, M, w.keys_b.data(), w.vals_b.data(), w.head.data(),
+                               w.rank.data(), bits, w.run_pa.data(), w.run_pb.data(), w.run_start.data(),
+                               out.off_ei.data(), out.off_ej.data(), (uint64_t*)nullptr);
+    }
+    else
+    {
+        w.lrun_key.resize((size_t)n_lruns + 1), w.lrun_start.resize((size_t)n_lruns + 1);
+        if (M > 0)
+            hipLaunchKernelGGL(k_runs, dim3(nM), dim3(TB), 0, s, M, w.keys_b.data(), w.vals_b.data(), w.head.data(),
+                               w.rank.data(), bits, (int32_t*)nullptr, (int32_t*)nullptr, w.lrun_start.data(),
+                               out.off_ei.data(), out.off_ej.data(), w.lrun_key.data());
+        // ---- the global co-visibility lists: the pattern
+        const size_t ncov = (size_t)h_cov_ptr[L];
+        w.cov_ptr.resize((size_t)L + 1), w.cov_pose.resize(ncov + 1);
+        CUGO_HIP(hipMemcpyAsync(w.cov_ptr.data(), h_cov_ptr, sizeof(int32_t) * ((size_t)L + 1), hipMemcpyHostToDevice, s));
+        if (ncov > 0)
+            CUGO_HIP(hipMemcpyAsync(w.cov_pose.data(), h_cov_pose, sizeof(int32_t) * ncov, hipMemcpyHostToDevice, s));
+        if (!sorted_pairs(s, L, w.cov_ptr.data(), nullptr, w.cov_pose.data(), bits, false, w, Mg, n_runs))
+            return false;
+        w.run_pa.resize((size_t)n_runs + 1), w.run_pb.resize((size_t)n_runs + 1), w.run_start.resize((size_t)n_runs + 1);
+        if (Mg > 0)
+        {
+            hipLaunchKernelGGL(k_runs, dim3((unsigned)((Mg + TB - 1) / TB)), dim3(TB), 0, s, Mg, w.keys_b.data(),
+                               (const uint64_t*)nullptr, w.head.data(), w.rank.data(), bits, w.run_pa.data(),
+                               w.run_pb.data(), (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr,
+                               (uint64_t*)nullptr);
+            hipLaunchKernelGGL(k_match_runs, dim3((n_runs + TB - 1) / TB), dim3(TB), 0, s, n_runs, w.run_pa.data(),
+                               w.run_pb.data(), bits, n_lruns, w.lrun_key.data(), w.lrun_start.data(), (int32_t)M,
+                               w.run_start.data());
+        }
+    }
     const int B = n_runs + P;
     out.rowptr.resize((size_t)P + 1), out.colind.resize((size_t)B + 1), out.off_ptr.resize((size_t)B + 1);
     w.row_first.resize((size_t)P + 1);
@@ -222,7 +319,7 @@ bool build_structure_gpu(hipStream_t s, int E, int P, int Lall, const int32_t* d
     CUGO_HIP(hipMemcpyAsync(out.h_colind.data(), out.colind.data(), sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, s));
     CUGO_HIP(hipStreamSynchronize(s));
     CUGO_HIP(hipGetLastError());
-    out.B = B, out.Moff = M;
+    out.B = B, out.Moff = M, out.Mglobal = Mg;
     return true;
 }
 

@@ -14,11 +14,14 @@ struct GpuStructureScratch
     DevBuf<uint64_t> npairs, pair_off, keys_a, keys_b, vals_a, vals_b;
     DevBuf<uint32_t> head, rank;
     DevBuf<int32_t> run_pa, run_pb, run_start, row_first;
+    DevBuf<uint64_t> lrun_key;          // sharded build: pose-pair key of every LOCAL run
+    DevBuf<int32_t> lrun_start, cov_ptr, cov_pose;
     DevBuf<char> temp;
     void release()
     {
         npairs.release(), pair_off.release(), keys_a.release(), keys_b.release(), vals_a.release(), vals_b.release();
         head.release(), rank.release(), run_pa.release(), run_pb.release(), run_start.release(), row_first.release();
+        lrun_key.release(), lrun_start.release(), cov_ptr.release(), cov_pose.release();
         temp.release();
     }
 };
@@ -31,13 +34,18 @@ struct GpuStructure
     // the pattern on the host (symbolic analysis)
     std::vector<int32_t> h_rowptr, h_colind;
     int B = 0;
-    size_t Moff = 0;
+    size_t Moff = 0;   // products in the (local) lists
+    size_t Mglobal = 0; // off-diagonal products of the whole graph (= Moff for a single process)
     GpuStructureScratch scratch; // transient; released by the caller when memory matters
 };
 
 // d_e_pose / d_flags: the flattened landmark-major edge slots, d_lm_ptr [Lall + 1].  Returns false
 // (nothing built) when the problem is empty or the lists would not fit int32 indices.
+// A shard passes the GLOBAL co-visibility as well (host arrays: free landmark -> its free poses over
+// all shards, cov_ptr [L + 1]): the pattern then comes from those lists, the contribution lists from
+// the local slots, and a block without local products gets an empty list.
 bool build_structure_gpu(hipStream_t s, int E, int P, int Lall, const int32_t* d_e_pose, const uint8_t* d_flags,
-                         const int32_t* d_lm_ptr, GpuStructure& out);
+                         const int32_t* d_lm_ptr, GpuStructure& out, int L = 0, const int32_t* h_cov_ptr = nullptr,
+                         const int32_t* h_cov_pose = nullptr);
 
 } // namespace cugo_host

@@ -753,7 +753,26 @@ def test_kitti00_float32_full_size(kitti00):
           % (rel, np.abs(pose - kitti00["pose"]).max(), np.abs(lm - kitti00["lm"]).max()))
 
 
-def run_sharded_in_threads(d, world, niter):
+def test_sharded_device_structure_build_equals_host_build(monkeypatch):
+    """a shard builds the GLOBAL Hsc pattern on the device from the global co-visibility lists and
+    its contribution lists from its local slots (structure_gpu.cpp, sharded form): same structure
+    statistics and bitwise the same trajectory as with the host build, for 2 and 3 shards, and a
+    graph whose last shard owns fixed landmarks only"""
+    cases = [(cugo.synth(160, 2500, 10500, seed=3, n_loop_closures=80), 2),
+             (synth.make_problem(n_poses=30, n_landmarks=400, mean_obs=5.0, seed=9, fixed_poses=(0, 7, 8),
+                                 fixed_landmarks=tuple(range(300, 400)), loop_closure=True), 3)]
+    for d, world in cases:
+        dev = run_sharded_in_threads(d, world, 4, want_sstats=True)
+        monkeypatch.setenv("CUGO_HOST_STRUCTURE", "1")
+        host = run_sharded_in_threads(d, world, 4, want_sstats=True)
+        monkeypatch.delenv("CUGO_HOST_STRUCTURE")
+        for r in range(world):
+            assert dev[r]["sstats"] == host[r]["sstats"], (r, dev[r]["sstats"], host[r]["sstats"])
+            assert [s["chi2"] for s in dev[r]["stats"]] == [s["chi2"] for s in host[r]["stats"]]
+            assert np.array_equal(dev[r]["pose"], host[r]["pose"]) and np.array_equal(dev[r]["lm"], host[r]["lm"])
+
+
+def run_sharded_in_threads(d, world, niter, want_sstats=False):
     """landmark-sharded run with `world` shards emulated in ONE process on one GPU: one optimiser
     per shard in its own thread, the all-reduce goes through host memory (the callback form of the
     exchange; the RCCL form needs one GPU per rank).  Returns the per-rank results."""
@@ -783,7 +802,7 @@ def run_sharded_in_threads(d, world, niter):
         g.initialize()
         g.optimize(niter)
         results[rank] = dict(stats=g.stats(), pose=g.poses(), lm=g.landmarks(), xstats=g.exchange_stats(),
-                             nedges=g.n_active_edges())
+                             nedges=g.n_active_edges(), sstats=g.structure_stats() if want_sstats else None)
         g.close()
 
     ts = [threading.Thread(target=worker, args=(r,)) for r in range(world)]

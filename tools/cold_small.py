@@ -1,19 +1,14 @@
-"""cold-call cost on a local-BA sized graph: a NEW optimiser per call, as ORB-SLAM2 does"""
-import importlib, os, sys, time
-import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+"""GPU box: per-section host times (CUGO_INIT_TIMING) of a full re-flatten + structure rebuild on the
+kitti_00 shape.   python tools/cold_small.py"""
+import importlib, sys, time, os
+sys.path.insert(0, os.getcwd())
 cugo = importlib.import_module("cuda-bundle-adjustment_amd")
-d = cugo.synth(30, 3000, 12600, seed=1, n_loop_closures=0, stereo_fraction=0.7)
-ti, to, tc, tb = [], [], [], []
-for c in range(60):
-    t0 = time.perf_counter(); g = cugo.graph_from_arrays(d); t1 = time.perf_counter()
-    g.initialize(); t2 = time.perf_counter()
-    g.optimize(5); t3 = time.perf_counter()
-    g.close(); t4 = time.perf_counter()
-    tb.append(t1 - t0); ti.append(t2 - t1); to.append(t3 - t2); tc.append(t4 - t3)
-f = lambda v: 1e3 * float(np.median(v[10:]))
-print("build graph %.2f ms | initialize %.2f ms | optimize(5) %.2f ms | destroy %.2f ms" % (f(tb), f(ti), f(to), f(tc)))
-g = cugo.graph_from_arrays(d); g.initialize(); g.optimize(5)
-t0 = time.perf_counter(); g.initialize(); t1 = time.perf_counter(); g.optimize(5); t2 = time.perf_counter()
-print("same optimiser again: initialize %.2f ms | optimize(5) %.2f ms" % (1e3 * (t1 - t0), 1e3 * (t2 - t1)))
-print(g.time_profile())
+d = cugo.synth(1322, 133383, 561116, seed=0, n_loop_closures=4000, stereo_fraction=0.7)
+g = cugo.graph_from_arrays(d)
+g.initialize(); g.optimize(1)
+os.environ["CUGO_NO_STRUCTURE_REUSE"] = "1"; os.environ["CUGO_NO_FLATTEN_REUSE"] = "1"
+for rep in range(3):
+    if rep == 2:
+        os.environ["CUGO_INIT_TIMING"] = "1"
+    t = time.time(); g.initialize(); t1 = time.time(); g.optimize(1); t2 = time.time()
+    print("init %.2f ms, optimize(1) incl structure %.2f ms" % ((t1 - t) * 1e3, (t2 - t1) * 1e3), flush=True)

@@ -49,6 +49,14 @@ def main():
             os.environ["CUGO_MIN_SUBTREE_TASKS"] = "0"
         else:
             os.environ.pop("CUGO_MIN_SUBTREE_TASKS", None)
+        # optional code paths: look-ahead Cholesky schedule, host-side structure build, 64x64 tiles
+        # everywhere, landmark-major Schur plan
+        for k, one_in in (("CUGO_LOOKAHEAD", 3), ("CUGO_HOST_STRUCTURE", 3), ("CUGO_SCHUR_PLAN", 4)):
+            if rng.integers(0, one_in) == 0:
+                os.environ[k] = "1"
+            else:
+                os.environ.pop(k, None)
+        os.environ["CUGO_TILE32_MAX_TILES"] = str(int(rng.choice([0, 64])))
         prob = oracle.Problem(*synth.problem_fields(d))
         prob.rk_type, prob.rk_delta = rk
         ref = prob.optimize(6)

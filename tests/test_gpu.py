@@ -390,9 +390,11 @@ def rmse(a, b):
     return float(np.sqrt(np.mean((a - b) ** 2)))
 
 
-@pytest.mark.parametrize("subtree_stage", [False, True])
+@pytest.mark.parametrize("subtree_stage", [False, True, "lookahead"])
 def test_medium_synthetic_vs_oracle(oracle_lib, subtree_stage, monkeypatch):
-    if subtree_stage:
+    if subtree_stage == "lookahead":  # the opt-in Cholesky schedule, end to end
+        monkeypatch.setenv("CUGO_LOOKAHEAD", "1")
+    elif subtree_stage:
         monkeypatch.setenv("CUGO_MIN_SUBTREE_TASKS", "0")
     d, prob = synth_problem(oracle_lib, 400, 8000, 33000, seed=11, lc=200)
     out = run_graph(d, 10)

@@ -43,6 +43,7 @@ void cugo_chol::upload(hipStream_t s)
     const size_t o_off = put64(P.off), o_woff = put64(P.woff), o_l21off = put64(P.l21off), o_ldf = put64(P.ldf);
     d_pack32.upload(pack32, s), d_pack64.upload(pack64, s);
     d_fronts.resize((size_t)P.front_doubles + 16);
+    d_fronts.zero(s); // once: afterwards only the lower triangles are cleared (k_clear_fronts)
     d_xnew.resize((size_t)6 * P.n + 16);
     d_junk.resize(64 * 1024);
     d_winv.resize((size_t)P.winv_doubles + 16);
@@ -99,8 +100,8 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
         CUGO_HIP(hipMemset(d_stamps, 0, 64 * sizeof(long long)));
         cugo_k::set_debug_stamps(d_stamps);
     }
-    cugo_k::launch_chol_assemble(s, dev, d_fronts.data(), (size_t)plan.front_doubles, d_Hsc, lambda,
-                                 d_bsc, d_fail, false);
+    cugo_k::launch_chol_assemble(s, dev, d_fronts.data(), (size_t)plan.front_doubles, d_Hsc, lambda, d_bsc, d_fail,
+                                 d_wl_ptr + 3L * plan.clr0, plan.nclr);
     int pend0 = 0, npend = 0, pend_tile = 64; // update tiles of the previous level, not launched yet
     for (int st = 0; st < plan.n_stages; st++)
     {

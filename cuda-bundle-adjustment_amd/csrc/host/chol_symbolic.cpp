@@ -951,6 +951,18 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
         v += (int)(ea.size() + eab.size()) / 3;
     for (auto& v : P.bwg_ptr)
         v += (int)(ea.size() + eab.size() + sy.size()) / 3;
+    // clearing the fronts before every assembly: only their lower triangles are ever written or read
+    // for their value, so only those are cleared (items: front, first column, past-last column);
+    // a front stored inside its child's update block has no storage of its own
+    P.clr0 = (int)P.wl.size() / 3;
+    P.nclr = 0;
+    for (int f = 0; f < ns; f++)
+        if (P.alias_of[f] < 0)
+            for (int c0 = 0; c0 < 6 * P.nb[f]; c0 += 16)
+            {
+                P.wl.push_back(f), P.wl.push_back(c0), P.wl.push_back(std::min(6 * P.nb[f], c0 + 16));
+                P.nclr++;
+            }
     for (auto& v : P.lead_ptr)
         v += (int)P.wl.size() / 3;
     P.wl.insert(P.wl.end(), lead.begin(), lead.end());

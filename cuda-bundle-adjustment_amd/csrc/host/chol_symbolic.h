@@ -66,6 +66,7 @@ struct CholPlan
     // look-ahead schedule (chol_kernels.hip, k_up_potrf_la / k_up_lead): la_np = lead rows of a front
     // (leading boundary block rows inside the parent's pivot columns), items lead: (front, -, -) per
     // front with lead rows, sb: the syrk tiles that are not wholly inside the lead block
+    int clr0 = 0, nclr = 0; // items (front, first column, past-last column) of the lower-triangle clear
     std::vector<int32_t> la_np;
     std::vector<int32_t> lead_ptr, sb_ptr;
     // edge of the syrk tiles of each stage: 64, or 32 where a level has so few 64-tiles that the

@@ -1105,25 +1105,36 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
             sync_prof(PROF_NUMERIC, tn);
             auto tu = Clock::now();
             const int nxt = m.cur ^ 1;
+            // single process: the two reductions that end a trial (scale of the update pass, chi2 of
+            // the error pass) share one launch, which also drops F-hat, scale and the factorisation flag
+            // (slot 4) into the pinned block — no copy is queued behind it.  A shard has to all-reduce
+            // the two sums first and keeps the separate launches and the read-back.
+            int n_scale_part = 0;
             m.timed("backsubst_update", [&] {
-                cugo_k::launch_backsubst_update(
+                n_scale_part = cugo_k::launch_backsubst_update(
                     s, m.ev, lambda, (m.rank == 0 ? lambda : 0.0), m.d_invHll.data(), m.bl(), m.bp(),
                     m.d_Hpl.data(), m.xp(), m.xl(), m.d_poses[m.cur].data(), m.d_lms[m.cur].data(),
-                    m.d_poses[nxt].data(), m.d_lms[nxt].data(), m.rs(), m.d_scal.data() + 3);
+                    m.d_poses[nxt].data(), m.d_lms[nxt].data(), m.rs(), sharded ? m.d_scal.data() + 3 : nullptr);
             });
             sync_prof(PROF_UPDATE, tu);
             auto te = Clock::now();
             m.timed("errors", [&] {
-                cugo_k::launch_errors(s, m.ev, m.d_poses[nxt].data(), m.d_lms[nxt].data(), m.rk,
-                                      m.rs(), m.d_scal.data() + 2);
+                if (sharded)
+                    cugo_k::launch_errors(s, m.ev, m.d_poses[nxt].data(), m.d_lms[nxt].data(), m.rk,
+                                          m.rs(), m.d_scal.data() + 2);
+                else
+                    cugo_k::launch_errors_tail(s, m.ev, m.d_poses[nxt].data(), m.d_lms[nxt].data(), m.rk, m.rs(),
+                                               n_scale_part, m.d_scal.data() + 2, m.d_scal.data() + 4,
+                                               m.h_scal.data() + 2);
             });
             m.last_err_buf = nxt;
             sync_prof(PROF_COMPUTE_ERROR, te);
             if (sharded)
+            {
                 m.exchange(m.d_scal.data() + 2, 2, 0);
-            // F-hat, scale and the factorisation flag (slot 4) in one read-back
-            CUGO_HIP(hipMemcpyAsync(m.h_scal.data() + 2, m.d_scal.data() + 2, 3 * sizeof(double),
-                                    hipMemcpyDeviceToHost, s));
+                CUGO_HIP(hipMemcpyAsync(m.h_scal.data() + 2, m.d_scal.data() + 2, 3 * sizeof(double),
+                                        hipMemcpyDeviceToHost, s));
+            }
             CUGO_HIP(hipStreamSynchronize(s));
             int32_t fail_flag;
             std::memcpy(&fail_flag, m.h_scal.data() + 4, sizeof fail_flag);

@@ -176,6 +176,40 @@ __global__ __launch_bounds__(SP_BS) void k_sum_partials(const double* __restrict
         out[0] = v;
 }
 
+// the two reductions at the end of an LM trial in ONE launch: workgroup 0 sums the chi2 partials of
+// the error pass, workgroup 1 the scale partials of the update pass — each exactly as k_sum_partials
+// does (same order, same result) — and both also deposit their value, workgroup 0 the factorisation
+// flag too, in a pinned host block: no device-to-host copy is queued behind them
+__global__ __launch_bounds__(SP_BS) void k_sum_partials2(const double* __restrict__ partA, int nA,
+                                                         const double* __restrict__ partB, int nB,
+                                                         double* __restrict__ out, const double* __restrict__ flag,
+                                                         double* __restrict__ host_out)
+{
+    __shared__ double sm[SP_BS / 64];
+    const double* part = blockIdx.x == 0 ? partA : partB;
+    const int n = blockIdx.x == 0 ? nA : nB;
+    double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+    int i = threadIdx.x;
+    for (; i + 3 * SP_BS < n; i += 4 * SP_BS)
+    {
+        const double a = part[i], b = part[i + SP_BS], c = part[i + 2 * SP_BS], d = part[i + 3 * SP_BS];
+        v0 += a, v1 += b, v2 += c, v3 += d;
+    }
+    for (; i < n; i += SP_BS)
+        v0 += part[i];
+    const double v = block_sum((v0 + v1) + (v2 + v3), sm);
+    if (threadIdx.x == 0)
+    {
+        out[blockIdx.x] = v;
+        if (host_out)
+        {
+            host_out[blockIdx.x] = v;
+            if (blockIdx.x == 0)
+                host_out[2] = *flag; // 8 bytes holding the int32 zero-pivot flag
+        }
+    }
+}
+
 __global__ __launch_bounds__(BS) void k_max_partials(const double* __restrict__ part, int n,
                                                      double* __restrict__ out)
 {
@@ -1383,6 +1417,22 @@ void launch_errors(hipStream_t s, const cugo_edges& e, const double* d_poses, co
     CUGO_LAUNCH(k_sum_partials, dim3(1), dim3(SP_BS), 0, s, rs.d_partials, nb, d_chi);
 }
 
+void launch_errors_tail(hipStream_t s, const cugo_edges& e, const double* d_poses, const double* d_lms,
+                        cugo_robust rk, ReduceScratch rs, int n_scale_partials, double* d_out,
+                        const double* d_flag, double* h_out)
+{
+    const EV ev = make_ev(e);
+    const int nb = div_up(ev.E, BS);
+    // the scale partials of the update pass sit at the start of the scratch: the error pass uses the
+    // record area behind the partial slots (free between two build passes)
+    double* d_chi_part = rs.d_partials + scratch_partials(ev.E, ev.P, ev.L);
+    if (nb > 0)
+        CUGO_LAUNCH(k_errors, dim3(nb), dim3(BS), 0, s, ev, d_poses, d_lms,
+                           Robust2{{rk.type, rk.delta}, {rk.type_stereo, rk.delta_stereo}}, d_chi_part);
+    CUGO_LAUNCH(k_sum_partials2, dim3(2), dim3(SP_BS), 0, s, d_chi_part, nb, rs.d_partials, n_scale_partials,
+                d_out, d_flag, h_out);
+}
+
 void launch_edge_chi(hipStream_t s, const cugo_edges& e, const double* d_poses, const double* d_lms,
                      cugo_robust rk, double* d_chi_e)
 {
@@ -1488,7 +1538,7 @@ void launch_schur(hipStream_t s, const cugo_edges& e, const cugo_hsc_struct& hs,
 }
 
 template <typename S>
-static void launch_backsubst_update_t(hipStream_t s, const cugo_edges& e, double lambda, double lambda_pose,
+static int launch_backsubst_update_t(hipStream_t s, const cugo_edges& e, double lambda, double lambda_pose,
                                       const double* d_invHll, const double* d_bl, const double* d_bp,
                                       const S* d_Hpl, const double* d_xp, double* d_xl,
                                       const double* d_poses_in, const double* d_lms_in, double* d_poses_out,
@@ -1500,20 +1550,21 @@ static void launch_backsubst_update_t(hipStream_t s, const cugo_edges& e, double
         CUGO_LAUNCH_T(k_backsubst_landmarks, S, dim3(nbl + nbp), dim3(BS), 0, s, ev, lambda, d_invHll,
                       d_bl, d_Hpl, d_xp, d_xl, d_lms_in, d_lms_out, rs.d_partials, nbl,
                       lambda_pose, d_bp, d_poses_in, d_poses_out);
-    CUGO_LAUNCH(k_sum_partials, dim3(1), dim3(SP_BS), 0, s, rs.d_partials, nbl + nbp, d_scale);
+    if (d_scale) // nullptr: the partials stay in the scratch for launch_errors_tail
+        CUGO_LAUNCH(k_sum_partials, dim3(1), dim3(SP_BS), 0, s, rs.d_partials, nbl + nbp, d_scale);
+    return nbl + nbp;
 }
 
-void launch_backsubst_update(hipStream_t s, const cugo_edges& e, double lambda, double lambda_pose,
-                             const double* d_invHll, const double* d_bl, const double* d_bp,
-                             const void* d_Hpl, const double* d_xp, double* d_xl,
-                             const double* d_poses_in, const double* d_lms_in, double* d_poses_out,
-                             double* d_lms_out, ReduceScratch rs, double* d_scale)
+int launch_backsubst_update(hipStream_t s, const cugo_edges& e, double lambda, double lambda_pose,
+                            const double* d_invHll, const double* d_bl, const double* d_bp,
+                            const void* d_Hpl, const double* d_xp, double* d_xl,
+                            const double* d_poses_in, const double* d_lms_in, double* d_poses_out,
+                            double* d_lms_out, ReduceScratch rs, double* d_scale)
 {
     if (e.block_f32)
-        launch_backsubst_update_t(s, e, lambda, lambda_pose, d_invHll, d_bl, d_bp, static_cast<const float*>(d_Hpl),
+        return launch_backsubst_update_t(s, e, lambda, lambda_pose, d_invHll, d_bl, d_bp, static_cast<const float*>(d_Hpl),
                                   d_xp, d_xl, d_poses_in, d_lms_in, d_poses_out, d_lms_out, rs, d_scale);
-    else
-        launch_backsubst_update_t(s, e, lambda, lambda_pose, d_invHll, d_bl, d_bp, static_cast<const double*>(d_Hpl),
+    return launch_backsubst_update_t(s, e, lambda, lambda_pose, d_invHll, d_bl, d_bp, static_cast<const double*>(d_Hpl),
                                   d_xp, d_xl, d_poses_in, d_lms_in, d_poses_out, d_lms_out, rs, d_scale);
 }
 

@@ -45,10 +45,27 @@ using cugo_k::CholPlanDev;
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------- assembly -------------
+// workgroups [0, nblk): the Hsc blocks (+lambda on the diagonal); the ones after them: the right-hand
+// side and the reset of the zero-pivot flag (one launch instead of two)
 __global__ __launch_bounds__(CBS) void k_assemble_blocks(CholPlanDev p, double* __restrict__ fronts,
                                                          const double* __restrict__ Hsc,
-                                                         double lambda)
+                                                         double lambda, const double* __restrict__ bsc,
+                                                         int32_t* __restrict__ fail, int nblk)
 {
+    if ((int)blockIdx.x >= nblk)
+    {
+        const int j = ((int)blockIdx.x - nblk) * CBS + threadIdx.x;
+        if (j == 0)
+            *fail = 0; // the zero-pivot flag of this factorisation
+        if (j >= 6 * p.n)
+            return;
+        const int jb = j / 6, comp = j % 6;
+        const int f = p.col_front[jb];
+        const long ld = p.ldf[f];
+        const long lc = 6L * (jb - p.col0[f]) + comp;
+        fronts[p.off[f] + lc * ld + 6L * p.nb[f]] = bsc[6L * p.perm[jb] + comp]; // rhs row = row 6*nb
+        return;
+    }
     const long idx = (long)blockIdx.x * CBS + threadIdx.x;
     if (idx >= 36L * p.n_hsc_blocks)
         return;
@@ -73,20 +90,22 @@ __global__ __launch_bounds__(CBS) void k_assemble_blocks(CholPlanDev p, double* 
         F[(6L * cb + r) * ld + 6L * rb + c] = v;
 }
 
-__global__ __launch_bounds__(CBS) void k_assemble_rhs(CholPlanDev p, double* __restrict__ fronts,
-                                                      const double* __restrict__ bsc,
-                                                      int32_t* __restrict__ fail)
+// lower triangle (rows >= column) of 16 columns of one front := 0.  The strict upper triangles are
+// cleared once, when the plan is uploaded, and never written afterwards (every global store of the
+// factorisation is masked to row >= column), so this is the whole-buffer memset at half the bytes.
+__global__ __launch_bounds__(CBS) void k_clear_fronts(CholPlanDev p, double* __restrict__ fronts,
+                                                      const int32_t* __restrict__ items)
 {
-    const int j = blockIdx.x * CBS + threadIdx.x;
-    if (j == 0)
-        *fail = 0; // the zero-pivot flag of this factorisation (a 4-byte memset is a 4 us launch)
-    if (j >= 6 * p.n)
-        return;
-    const int jb = j / 6, comp = j % 6;
-    const int f = p.col_front[jb];
+    const int32_t* it = items + 3 * blockIdx.x;
+    const int f = it[0], c0 = it[1], c1 = it[2];
     const long ld = p.ldf[f];
-    const long lc = 6L * (jb - p.col0[f]) + comp;
-    fronts[p.off[f] + lc * ld + 6L * p.nb[f]] = bsc[6L * p.perm[jb] + comp]; // rhs row = row 6*nb
+    const int nrows = 6 * p.nb[f] + 1;
+    double* F = fronts + p.off[f];
+    for (int r = c0 + threadIdx.x; r < nrows; r += CBS)
+#pragma unroll 4
+        for (int c = c0; c < c1; c++)
+            if (r >= c)
+                F[(long)c * ld + r] = 0.0;
 }
 
 // Diagnostic phase stamps: only in a build with -DCUGO_STAMPS (make STAMPS=1) and run with
@@ -1590,16 +1609,16 @@ void set_debug_stamps(long long* d_buf)
 
 void launch_chol_assemble(hipStream_t s, const CholPlanDev& p, double* d_fronts,
                           size_t front_doubles, const double* d_Hsc, double lambda,
-                          const double* d_bsc, int32_t* d_fail, bool fronts_are_zero)
+                          const double* d_bsc, int32_t* d_fail, const int32_t* d_clear_items, int nclear)
 {
-    if (!fronts_are_zero)
+    if (nclear > 0)
+        CUGO_LAUNCH(k_clear_fronts, dim3(nclear), dim3(CBS), 0, s, p, d_fronts, d_clear_items);
+    else
         (void)hipMemsetAsync(d_fronts, 0, front_doubles * sizeof(double), s);
     const long n = 36L * p.n_hsc_blocks;
-    if (n > 0)
-        CUGO_LAUNCH(k_assemble_blocks, dim3((unsigned)((n + CBS - 1) / CBS)), dim3(CBS), 0, s,
-                           p, d_fronts, d_Hsc, lambda);
-    CUGO_LAUNCH(k_assemble_rhs, dim3(std::max(1, (6 * p.n + CBS - 1) / CBS)), dim3(CBS), 0, s, p,
-                       d_fronts, d_bsc, d_fail);
+    const int nblk = (int)((n + CBS - 1) / CBS), nrhs = std::max(1, (6 * p.n + CBS - 1) / CBS);
+    CUGO_LAUNCH(k_assemble_blocks, dim3(nblk + nrhs), dim3(CBS), 0, s, p, d_fronts, d_Hsc, lambda, d_bsc, d_fail,
+                nblk);
 }
 
 void launch_chol_subtree_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,

@@ -69,11 +69,19 @@ void launch_schur(hipStream_t s, const cugo_edges& ev, const cugo_hsc_struct& hs
 
 // lambda_pose: damping used in the pose part of the scale sum (0 on ranks > 0 of a sharded run
 // so that the all-reduced scale counts lambda*|xp|^2 once)
-void launch_backsubst_update(hipStream_t s, const cugo_edges& ev, double lambda, double lambda_pose,
-                             const double* d_invHll, const double* d_bl, const double* d_bp,
-                             const void* d_Hpl, const double* d_xp, double* d_xl,
-                             const double* d_poses_in, const double* d_lms_in, double* d_poses_out,
-                             double* d_lms_out, ReduceScratch rs, double* d_scale);
+// d_scale == nullptr: the scale partials are left in the scratch (launch_errors_tail sums them);
+// returns their number
+int launch_backsubst_update(hipStream_t s, const cugo_edges& ev, double lambda, double lambda_pose,
+                            const double* d_invHll, const double* d_bl, const double* d_bp,
+                            const void* d_Hpl, const double* d_xp, double* d_xl,
+                            const double* d_poses_in, const double* d_lms_in, double* d_poses_out,
+                            double* d_lms_out, ReduceScratch rs, double* d_scale);
+// error pass of an LM trial + BOTH final reductions in one launch: d_out[0] = chi2, d_out[1] = scale
+// (from the n_scale_partials left by launch_backsubst_update); h_out (pinned host memory, may be
+// null) receives {chi2, scale, the 8 bytes at d_flag}: readable after the stream has been waited for
+void launch_errors_tail(hipStream_t s, const cugo_edges& ev, const double* d_poses, const double* d_lms,
+                        cugo_robust rk, ReduceScratch rs, int n_scale_partials, double* d_out,
+                        const double* d_flag, double* h_out);
 
 size_t reduce_scratch_doubles(int n_edges, int n_poses, int n_landmarks);
 
@@ -128,10 +136,11 @@ struct CholPlanDev
     double* junk;              // 64 x 1024 doubles
 };
 
-// also resets *d_fail; fronts_are_zero: the caller has already cleared d_fronts
+// clears the fronts (their lower triangles through the nclear items front / first / past-last column;
+// nclear == 0: the whole buffer), scatters Hsc (+lambda) and bsc into them and resets *d_fail
 void launch_chol_assemble(hipStream_t s, const CholPlanDev& p, double* d_fronts, size_t front_doubles,
                           const double* d_Hsc, double lambda, const double* d_bsc, int32_t* d_fail,
-                          bool fronts_are_zero);
+                          const int32_t* d_clear_items, int nclear);
 void launch_chol_subtree_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,
                                int ntasks, size_t lds_bytes, int32_t* d_fail);
 // one etree level: extend-add(pivot columns) / potrf (+ extend-add of the boundary columns) /

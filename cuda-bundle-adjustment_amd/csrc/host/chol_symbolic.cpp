@@ -36,6 +36,8 @@ CholOptions CholOptions::from_env()
         o.min_subtree_tasks = std::max(0, std::atoi(s));
     if (const char* s = std::getenv("CUGO_MAX_FRONT_COLS"))
         o.max_front_cols = std::min(16, std::max(1, std::atoi(s)));
+    if (const char* s = std::getenv("CUGO_XCD_AFFINITY"))
+        o.xcd_affinity = std::atoi(s) != 0;
     if (const char* s = std::getenv("CUGO_TILE32_MAX_TILES"))
         o.tile32_max_tiles = std::max(0, std::atoi(s));
     return o;
@@ -827,6 +829,7 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
     P.l21off.assign(ns, -1);
     P.l21_doubles = 0;
     std::vector<int32_t> ea, eab, sy, bwg;
+    std::vector<int> sy_front_ntiles; // tiles per front of the level being listed
     P.stage_tile.assign(P.n_stages, 64);
     for (int st = 0; st < P.n_stages; st++)
     {
@@ -882,6 +885,7 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
                 // at all) still needs its L21 rows solved and stored
                 const int nrs = 6 * (nb - ncb), nbelow = nrs + 1;
                 const int nti = (nbelow + TS - 1) / TS, ntj = (nrs + TS - 1) / TS;
+                const size_t sy_front0 = sy.size();
                 for (int tj = 0; tj < ntj; tj++)
                     for (int ti = tj; ti < nti; ti++)
                     {
@@ -891,6 +895,7 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
                 {
                     sy.push_back(f), sy.push_back(ti), sy.push_back(-1);
                 }
+                sy_front_ntiles.push_back((int)((sy.size() - sy_front0) / 3));
                 // look-ahead schedule: one lead workgroup per front that has lead rows, and the same
                 // tiles without those that lie wholly inside the lead block
                 const int q = 6 * P.la_np[f];
@@ -931,6 +936,58 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
                     }
                 }
             }
+        // XCD affinity of the tile launch: workgroups whose index is congruent mod 8 share an XCD and
+        // its L2 (observed dispatch rule; a speed matter only), and all tiles of a front read the same W
+        // and the same L21 row panels.  So the fronts of the level are dealt to 8 groups (largest first,
+        // to the group with the fewest tiles) and the items are interleaved so that item i belongs to
+        // group i mod 8; a group that runs dry takes from the fullest one.
+        if (!subtree && opt.xcd_affinity && !sy_front_ntiles.empty())
+        {
+            const size_t base = (size_t)P.syrk_ptr.back() * 3;
+            const int nf = (int)sy_front_ntiles.size();
+            std::vector<int> first(nf + 1, 0);
+            for (int i = 0; i < nf; i++)
+                first[i + 1] = first[i] + sy_front_ntiles[i];
+            if (first[nf] > 8)
+            {
+                std::vector<int> byn(nf);
+                for (int i = 0; i < nf; i++)
+                    byn[i] = i;
+                std::stable_sort(byn.begin(), byn.end(), [&](int a, int b) { return sy_front_ntiles[a] > sy_front_ntiles[b]; });
+                std::vector<std::vector<int>> grp(8); // item indices (within the level) per group
+                std::vector<int> load(8, 0);
+                for (int i : byn)
+                {
+                    const int g = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+                    for (int t = first[i]; t < first[i + 1]; t++)
+                        grp[g].push_back(t);
+                    load[g] += sy_front_ntiles[i];
+                }
+                std::vector<int32_t> out;
+                out.reserve((size_t)first[nf] * 3);
+                std::vector<size_t> pos(8, 0);
+                for (int i = 0; i < first[nf]; i++)
+                {
+                    int g = i & 7;
+                    if (pos[g] >= grp[g].size())
+                    { // dry: the group with the most items left gives one (from its end)
+                        int best = -1;
+                        size_t left = 0;
+                        for (int h = 0; h < 8; h++)
+                            if (grp[h].size() - pos[h] > left)
+                                left = grp[h].size() - pos[h], best = h;
+                        const int t = grp[best].back();
+                        grp[best].pop_back();
+                        out.insert(out.end(), sy.begin() + base + 3 * (size_t)t, sy.begin() + base + 3 * (size_t)t + 3);
+                        continue;
+                    }
+                    const int t = grp[g][pos[g]++];
+                    out.insert(out.end(), sy.begin() + base + 3 * (size_t)t, sy.begin() + base + 3 * (size_t)t + 3);
+                }
+                std::copy(out.begin(), out.end(), sy.begin() + base);
+            }
+        }
+        sy_front_ntiles.clear();
         P.ea_ptr.push_back((int)ea.size() / 3);
         P.eab_ptr.push_back((int)eab.size() / 3);
         P.syrk_ptr.push_back((int)sy.size() / 3);

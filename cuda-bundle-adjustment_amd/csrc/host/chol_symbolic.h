@@ -20,6 +20,7 @@ struct CholOptions
     // CUGO_MIN_SUBTREE_TASKS=0 turns it on (kept under test).
     int min_subtree_tasks = 1 << 30;
     int max_front_cols = 16; // hard cap on pivot block columns of a front (LDS-resident L11)
+    bool xcd_affinity = true; // tile items of a front share an index class mod 8, i.e. an XCD and its L2 (CUGO_XCD_AFFINITY=0: listed front by front)
     int tile32_max_tiles = 64; // a level with at most this many 64x64 tiles is cut into 32x32 tiles (0: never)
     static CholOptions from_env();
 };

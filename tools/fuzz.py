@@ -6,7 +6,8 @@ through 11 landmarks: the Schur system is singular up to the damping); there a d
 bar is accepted only if the oracle ALONE moves by as much when it sums in another order
 (tests/oracle.self_sensitivity), and is printed.
 
-    python tools/fuzz.py [cases] [seed]           (needs an MI355X)
+    python tools/fuzz.py [cases] [seed] [medium]  (needs an MI355X; `medium`: 60-500 poses, many-level
+                                                   Cholesky plans with both tile sizes instead of tiny graphs)
 """
 import importlib
 import os
@@ -28,9 +29,10 @@ def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     worst, worst_excused, excused = 0.0, 0.0, 0
+    medium = len(sys.argv) > 3 and sys.argv[3] == "medium"
     for c in range(cases):
-        P = int(rng.integers(3, 48))
-        L = int(rng.integers(8, 500))
+        P = int(rng.integers(60, 500)) if medium else int(rng.integers(3, 48))
+        L = int(rng.integers(4 * P, 14 * P)) if medium else int(rng.integers(8, 500))
         nfix_p = int(rng.integers(1, max(2, P // 4)))
         fixed_p = tuple(sorted(rng.choice(P, nfix_p, replace=False).tolist()))
         nfix_l = int(rng.integers(0, max(1, L // 10)))
@@ -40,7 +42,7 @@ def main():
                                fixed_poses=fixed_p, fixed_landmarks=fixed_l,
                                loop_closure=bool(rng.integers(0, 2)), pose_noise=(0.005, 0.03))
         rk = [(0, 1.0), (1, 2.5), (2, 6.0), (3, 1.5)][int(rng.integers(0, 4))]
-        for k, v in (("CUGO_ND_LEAF", str(int(rng.choice([2, 4, 8, 96])))),
+        for k, v in (("CUGO_ND_LEAF", str(int(rng.choice([8, 24, 96] if medium else [2, 4, 8, 96])))),
                      ("CUGO_MAX_FRONT_COLS", str(int(rng.choice([2, 5, 16])))),
                      ("CUGO_ALIAS_CHAINS", str(int(rng.integers(0, 2)))),
                      ("CUGO_FLOAT32", "0")):
@@ -57,6 +59,7 @@ def main():
             else:
                 os.environ.pop(k, None)
         os.environ["CUGO_TILE32_MAX_TILES"] = str(int(rng.choice([0, 64])))
+        os.environ["CUGO_XCD_AFFINITY"] = str(int(rng.integers(0, 2)))
         prob = oracle.Problem(*synth.problem_fields(d))
         prob.rk_type, prob.rk_delta = rk
         ref = prob.optimize(6)
@@ -86,7 +89,18 @@ def main():
             assert rel <= 4.0 * sens[i], ("difference not explained by conditioning", c, P, L, rk, a, b, sens)
             excused += 1
             worst_excused = max(worst_excused, rel)
-        assert np.abs(pose - prob.pose).max() < 1e-6 and np.abs(lm - prob.lm).max() < 1e-5, c
+        dp, dl = np.abs(pose - prob.pose).max(), np.abs(lm - prob.lm).max()
+        if not (dp < 1e-6 and dl < 1e-5):
+            # estimates further apart than that with chi2 equal to 1e-10: a direction the problem barely
+            # constrains (e.g. the depth of a landmark seen twice from nearly the same place); accepted
+            # only if the oracle alone moves as much when it sums in another order
+            fresh = oracle.Problem(*synth.problem_fields(d))
+            fresh.rk_type, fresh.rk_delta = rk
+            probe = oracle.self_sensitivity(fresh, 6, with_estimates=True)
+            est = probe[1] if probe else float("inf")
+            print("case %d: P %d L %d: estimates gpu-vs-oracle %.2e (poses) %.2e (landmarks), "
+                  "oracle-vs-reordered-oracle %.2e" % (c, P, L, dp, dl, est))
+            assert max(dp, dl) <= 4.0 * est + 1e-6, ("estimates", c, dp, dl, est)
     print("fuzz ok: %d cases at the 1e-10 bar (worst %.2e); %d iteration(s) of ill-conditioned cases above it, "
           "each within 4x of the oracle's own order sensitivity (worst %.2e)" % (cases, worst, excused, worst_excused))
 

@@ -569,6 +569,62 @@ __device__ __forceinline__ void inv_diag16_block(const double* __restrict__ Ls, 
     }
 }
 
+// The same inverse by a WHOLE wave: four lanes per column (lane = 4 * column + r4), lane r4 of a quad
+// holds the rows i = r4 + 4m of its column.  A substitution step is bound by the instructions a
+// single wave can issue, not by its chain (16 lanes: 15 FMAs + 15 broadcast LDS loads per step for one
+// wave, ~340 cycles): split four ways a step is <= 4 FMAs + 4 loads per lane plus ONE cross-lane move,
+// the quad-broadcast of the scaled pivot-row entry (DPP quad_perm: two v_mov_dpp, no LDS).
+template <int Q>
+__device__ __forceinline__ double quad_bcast(double x)
+{
+    constexpr int ctrl = Q * 0x55; // quad_perm [Q, Q, Q, Q]
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), ctrl, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), ctrl, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+template <int K>
+__device__ __forceinline__ void inv_diag16_step(const double* __restrict__ Lb, const double* __restrict__ di, int r4,
+                                                double (&v)[4])
+{
+    constexpr int ko = K & 3, km = K >> 2;
+    const double vk = quad_bcast<ko>(v[km] * di[K]); // row K of this column, scaled: final
+    v[km] = (r4 == ko) ? vk : v[km];
+#pragma unroll
+    for (int m = km; m < 4; m++)
+    {
+        // rows below K only: for m == km that is r4 > ko (clamped address, zero coefficient otherwise)
+        const double l = Lb[K * LLD + r4 + 4 * m];
+        const double coef = (m > km || r4 > ko) ? l : 0.0;
+        v[m] -= coef * vk;
+    }
+}
+
+__device__ __forceinline__ void inv_diag16_wave(const double* __restrict__ Ls, const double* __restrict__ dinv,
+                                                int blk, double* __restrict__ Vs)
+{
+    const int lane = threadIdx.x & 63, r4 = lane & 3, c = lane >> 2;
+    const double* Lb = Ls + (16 * blk) * LLD + 16 * blk;
+    const double* di = dinv + 16 * blk;
+    double v[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+        v[m] = (r4 + 4 * m == c) ? 1.0 : 0.0;
+    inv_diag16_step<0>(Lb, di, r4, v), inv_diag16_step<1>(Lb, di, r4, v), inv_diag16_step<2>(Lb, di, r4, v);
+    inv_diag16_step<3>(Lb, di, r4, v), inv_diag16_step<4>(Lb, di, r4, v), inv_diag16_step<5>(Lb, di, r4, v);
+    inv_diag16_step<6>(Lb, di, r4, v), inv_diag16_step<7>(Lb, di, r4, v), inv_diag16_step<8>(Lb, di, r4, v);
+    inv_diag16_step<9>(Lb, di, r4, v), inv_diag16_step<10>(Lb, di, r4, v), inv_diag16_step<11>(Lb, di, r4, v);
+    inv_diag16_step<12>(Lb, di, r4, v), inv_diag16_step<13>(Lb, di, r4, v), inv_diag16_step<14>(Lb, di, r4, v);
+    inv_diag16_step<15>(Lb, di, r4, v);
+    double* V = Vs + blk * (16 * 17);
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+    {
+        const int i = r4 + 4 * m;
+        V[i * 17 + c] = (i >= c) ? v[m] : 0.0;
+    }
+}
+
 // all diagonal blocks at once, one 16-lane group per block
 __device__ __forceinline__ void dev_inv_diag16(const double* __restrict__ Ls, const double* __restrict__ dinv,
                                                int ncp, double* __restrict__ Vs)
@@ -1399,9 +1455,9 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
     dev_potrf(fronts + p.off[f], p.ldf[f], ncs, Ls, dinv, fail);
     __syncthreads();
     stamp(0, 5);
-    // one wave per diagonal block (16 lanes each): V_J = inverse of the 16x16 diagonal block
-    if ((threadIdx.x & 63) < 16 && (int)(threadIdx.x >> 6) < (ncp >> 4))
-        inv_diag16_block(Ls, dinv, threadIdx.x >> 6, threadIdx.x & 15, Vs, nullptr, ncp);
+    // one wave per diagonal block: V_J = inverse of the 16x16 diagonal block
+    if ((int)(threadIdx.x >> 6) < (ncp >> 4))
+        inv_diag16_wave(Ls, dinv, threadIdx.x >> 6, Vs);
     __syncthreads();
     dev_winv(Ls, ncp, Vs, p.winv + p.woff[f]);
     stamp_value(0, 6, ncs);
@@ -1461,8 +1517,8 @@ __device__ __forceinline__ void dev_potrf_front(const CholPlanDev& p, double* __
     double* Vs = dinv + NC_MAX;
     dev_potrf(fronts + p.off[f], p.ldf[f], ncs, Ls, dinv, fail);
     __syncthreads();
-    if ((threadIdx.x & 63) < 16 && (int)(threadIdx.x >> 6) < (ncp >> 4))
-        inv_diag16_block(Ls, dinv, threadIdx.x >> 6, threadIdx.x & 15, Vs, nullptr, ncp);
+    if ((int)(threadIdx.x >> 6) < (ncp >> 4))
+        inv_diag16_wave(Ls, dinv, threadIdx.x >> 6, Vs);
     __syncthreads();
     dev_winv(Ls, ncp, Vs, p.winv + p.woff[f]);
 }

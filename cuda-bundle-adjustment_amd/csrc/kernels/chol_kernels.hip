@@ -1310,60 +1310,77 @@ __device__ __forceinline__ void dev_backward(const CholPlanDev& p, const double*
     // front's own positions) — only the leading rows that belong to the parent
     const int npb = p.bw_np[f];
     const int nr_here = npb >= 0 ? 6 * npb : nrs;
-    for (int i = threadIdx.x; i < nr_here; i += blockDim.x)
+    // 8 lanes per pivot column: the 128 lane groups of the 1024-thread workgroup cover all (<= 96)
+    // columns at once, so every thread knows its column now and ALL its global loads — x of the
+    // boundary rows, its slice of the first 96 rows of L21, y, its slice of W, the permutation — are
+    // issued together and waited for once: the kernel is a chain of global round trips (~2 k cycles
+    // each: L21 and W were written by other XCDs), not of arithmetic
+    const int g = threadIdx.x >> 3, l8 = threadIdx.x & 7;
+    const bool colok = g < ncs;
+    const int j = min(g, ncs - 1);
+    const double* col = L + (long)j * ldl;
+    const double* wcol = Wg + (long)j * ncp;
+    const int k0 = (j & ~15) + l8;
+    const int jb = j / 6, comp = j - 6 * jb;
+    double xg = 0.0; // this thread's entry of x_R (nr_here <= blockDim on every front of an upper stage)
+    const int ig = threadIdx.x;
+    if (ig < nr_here)
+        xg = xnew[6L * rows[ig / 6] + (ig % 6)];
+    double a[12], wv[12];
+#pragma unroll
+    for (int u = 0; u < 12; u++)
+        a[u] = col[min(l8 + 8 * u, nrs - 1)];
+    const double y = npb >= 0 ? xnew[6L * c0 + j] : col[nrs];
+#pragma unroll
+    for (int u = 0; u < 12; u++)
+        wv[u] = wcol[min(k0 + 8 * u, ncp - 1)];
+    const int pj = p.perm[c0 + jb];
+    if (ig < nr_here)
+        xr[ig] = xg;
+    for (int i = ig + blockDim.x; i < nr_here; i += blockDim.x) // (subtree-stage fronts with > 1024 rows)
     {
         const int ib = i / 6;
         xr[i] = xnew[6L * rows[ib] + (i - 6 * ib)];
     }
-    for (int j = ncs + threadIdx.x; j < ncp; j += blockDim.x)
-        vs[j] = 0.0;
+    for (int jj = ncs + threadIdx.x; jj < ncp; jj += blockDim.x)
+        vs[jj] = 0.0;
     __syncthreads();
     stamp(3, 2);
-    const int g = threadIdx.x >> 4, l16 = threadIdx.x & 15, ng = blockDim.x >> 4;
-    // v_j = y_j - sum_i L21[i,j] x_R[i]: 16 lanes per column, lanes stride the rows
-    for (int j = g; j < ncs; j += ng)
+    // v_j = y_j - sum_i L21[i,j] x_R[i]
     {
-        const double* col = L + (long)j * ldl;
-        const double y = npb >= 0 ? xnew[6L * c0 + j] : col[nrs];
         double s = 0;
-        for (int i = l16; i < nr_here; i += 128)
-        { // eight independent loads in flight per lane
-            double a[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++)
-                a[u] = col[min(i + 16 * u, nrs - 1)];
+        for (int u = 0; u < 12; u++)
+            s += (l8 + 8 * u < nr_here) ? a[u] * xr[l8 + 8 * u] : 0.0;
+        for (int i = 96 + l8; i < nr_here; i += 96)
+        { // rows beyond the first 96 (a front that does its whole mat-vec itself)
+            double b[12];
 #pragma unroll
-            for (int u = 0; u < 8; u++)
-                s += (i + 16 * u < nr_here) ? a[u] * xr[i + 16 * u] : 0.0;
+            for (int u = 0; u < 12; u++)
+                b[u] = col[min(i + 8 * u, nrs - 1)];
+#pragma unroll
+            for (int u = 0; u < 12; u++)
+                s += (i + 8 * u < nr_here) ? b[u] * xr[i + 8 * u] : 0.0;
         }
 #pragma unroll
-        for (int off = 8; off > 0; off >>= 1)
-            s += __shfl_xor(s, off, 16);
-        if (l16 == 0)
+        for (int off = 4; off > 0; off >>= 1)
+            s += __shfl_xor(s, off, 8);
+        if (l8 == 0 && colok)
             vs[j] = y - s;
     }
     __syncthreads();
     stamp(3, 3);
     // x_j = sum_k W[k][j] v_k over k >= 16*floor(j/16) (W lower triangular, zeros above the
     // diagonal inside the diagonal block); Wg is column-major, so the sum runs along a column
-    for (int j = g; j < ncs; j += ng)
     {
-        const int k0 = (j & ~15) + l16;
-        const double* wcol = Wg + (long)j * ncp;
-        const int jb = j / 6, comp = j - 6 * jb;
-        const int pj = p.perm[c0 + jb];
-        double wv[6];
-#pragma unroll
-        for (int u = 0; u < 6; u++)
-            wv[u] = wcol[min(k0 + 16 * u, ncp - 1)];
         double s = 0;
 #pragma unroll
-        for (int u = 0; u < 6; u++)
-            s += (k0 + 16 * u < ncp) ? wv[u] * vs[k0 + 16 * u] : 0.0;
+        for (int u = 0; u < 12; u++)
+            s += (k0 + 8 * u < ncp) ? wv[u] * vs[k0 + 8 * u] : 0.0;
 #pragma unroll
-        for (int off = 8; off > 0; off >>= 1)
-            s += __shfl_xor(s, off, 16);
-        if (l16 == 0)
+        for (int off = 4; off > 0; off >>= 1)
+            s += __shfl_xor(s, off, 8);
+        if (l8 == 0 && colok)
         {
             xnew[6L * (c0 + jb) + comp] = s;
             xout[6L * pj + comp] = s;

@@ -36,6 +36,18 @@ void cugo_chol::upload(hipStream_t s)
     const size_t o_task_ptr = put32(P.task_ptr), o_task_fronts = put32(P.task_fronts);
     const size_t o_blk_front = put32(P.blk_front), o_blk_row = put32(P.blk_row), o_blk_col = put32(P.blk_col);
     const size_t o_perm = put32(P.perm), o_col_front = put32(P.col_front), o_wl = put32(P.wl);
+    // one 64-byte record per task (kernels.h: CholPlanDev::tmeta)
+    std::vector<int32_t> tmeta(16 * (P.task_ptr.size() - 1), 0);
+    for (size_t t = 0; t + 1 < P.task_ptr.size(); t++)
+    {
+        int32_t* m = tmeta.data() + 16 * t;
+        const int f = P.task_fronts[P.task_ptr[t]];
+        m[0] = P.task_ptr[t + 1] - P.task_ptr[t], m[1] = f, m[2] = P.ncb[f], m[3] = P.nb[f], m[4] = P.col0[f];
+        m[5] = P.bw_np[f], m[6] = P.rows_ptr[f];
+        const int64_t q[4] = {P.off[f], P.ldf[f], P.woff[f], P.l21off[f]};
+        std::memcpy(m + 8, q, sizeof q);
+    }
+    const size_t o_tmeta = put32(tmeta);
     const size_t o_trans = pack32.size(); // bytes
     pack32.resize(o_trans + (P.blk_trans.size() + 3) / 4 + 4, 0);
     if (!P.blk_trans.empty())
@@ -59,7 +71,7 @@ void cugo_chol::upload(hipStream_t s)
     D.child_ptr = b32 + o_child_ptr, D.child = b32 + o_child;
     D.rel_ptr = b32 + o_rel_ptr, D.rel = b32 + o_rel;
     D.n_stages = P.n_stages;
-    D.task_ptr = b32 + o_task_ptr, D.task_fronts = b32 + o_task_fronts;
+    D.task_ptr = b32 + o_task_ptr, D.task_fronts = b32 + o_task_fronts, D.tmeta = b32 + o_tmeta;
     D.n_hsc_blocks = (int)P.blk_front.size();
     D.blk_front = b32 + o_blk_front, D.blk_row = b32 + o_blk_row;
     D.blk_col = b32 + o_blk_col, D.blk_trans = reinterpret_cast<const uint8_t*>(b32 + o_trans);

@@ -119,6 +119,8 @@ struct CholPlanDev
     const int32_t* rel;        // position (block row in the parent front) of each boundary row
     // schedule
     int n_stages;
+    const int32_t* tmeta;      // [n_tasks_total][16]: {fronts in the task, first front, its ncb, nb, col0, bw_np,
+                               // rows_ptr, -, off, ldf, woff, l21off (four int64)} (backward substitution)
     const int32_t* task_ptr;   // [n_tasks_total+1] into task_fronts
     const int32_t* task_fronts;
     // assembly of A (one entry per Hsc block)

@@ -37,8 +37,9 @@ void cugo_chol::upload(hipStream_t s)
     const size_t o_blk_front = put32(P.blk_front), o_blk_row = put32(P.blk_row), o_blk_col = put32(P.blk_col);
     const size_t o_perm = put32(P.perm), o_col_front = put32(P.col_front), o_wl = put32(P.wl);
     // one 64-byte record per task (kernels.h: CholPlanDev::tmeta)
-    std::vector<int32_t> tmeta(16 * (P.task_ptr.size() - 1), 0);
-    for (size_t t = 0; t + 1 < P.task_ptr.size(); t++)
+    const size_t ntask = P.task_ptr.empty() ? 0 : P.task_ptr.size() - 1; // (no free pose: an empty plan)
+    std::vector<int32_t> tmeta(16 * ntask, 0);
+    for (size_t t = 0; t < ntask; t++)
     {
         int32_t* m = tmeta.data() + 16 * t;
         const int f = P.task_fronts[P.task_ptr[t]];

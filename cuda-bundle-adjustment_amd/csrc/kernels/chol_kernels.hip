@@ -15,9 +15,13 @@
 //                         in LDS, then W = L11^-1 on the matrix cores; extra workgroups of the
 //                         same launch do the extend-add of everything below F11
 //        k_up_trsyrk      per 64x64 tile of the update matrix: X = B W^T for its two L21 row
-//                         tiles, U -= X_i X_j^T, all v_mfma_f64_16x16x4_f64
+//                         tiles, U -= X_i X_j^T, all v_mfma_f64_16x16x4_f64 (k_up_trsyrk32: 32x32
+//                         tiles on the levels with few fronts); the items of a front share an XCD
+//        (k_up_potrf_la / k_up_lead: the opt-in look-ahead schedule, CUGO_LOOKAHEAD=1)
 //   backward            : k_backward_stage per level, x_J = W^T (y_J - L21^T x_R): two mat-vecs;
 //                         the ancestor part of L21^T x_R is done one launch ahead (extra workgroups)
+//   before every factorisation: k_clear_fronts (lower triangles only) and k_assemble_blocks
+//                         (Hsc blocks + lambda, right-hand side, reset of the zero-pivot flag)
 //
 // The right-hand side rides along as the last row of every front, so L y = b is a by-product
 // of the factorisation (y ends in the rhs row of the pivot columns); only the backward

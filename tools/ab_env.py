@@ -3,6 +3,7 @@
 box-to-box and run-to-run drift cancels.  Prints median and minimum of `initialize(); optimize(10)`.
 
     python tools/ab_env.py CUGO_XCD_AFFINITY 1 0 [--workload synth10k] [--reps 30]
+    (a value `unset` removes the variable: some switches only test for presence)
 """
 import importlib, os, statistics, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -25,15 +26,21 @@ def main():
     d = cugo.synth(P, L, E, seed=seed, n_loop_closures=lc, stereo_fraction=sf)
     ids_p, ids_l = np.arange(P, dtype=np.int32), np.arange(L, dtype=np.int32)
     graphs = []
+    def put(v):
+        if v == "unset":
+            os.environ.pop(var, None)
+        else:
+            os.environ[var] = v
+
     for v in vals:
-        os.environ[var] = v
+        put(v)
         g = cugo.graph_from_arrays(d)
         g.initialize(); g.optimize(10)
         graphs.append(g)
     times = [[] for _ in vals]
     for r in range(reps):
         for k, g in enumerate(graphs):
-            os.environ[var] = vals[k]
+            put(vals[k])
             g.set_poses(ids_p, d["pose"]); g.set_landmarks(ids_l, d["lm"])
             t = time.perf_counter()
             g.initialize(); g.optimize(10)

@@ -85,6 +85,7 @@ struct Engine::Impl : cugo_k::LaunchHook
     std::vector<uint16_t> st_cam;
     std::vector<double> slot_threshold; // slot -> outlier threshold (empty: rejection disabled)
     int last_err_buf = 0;               // estimate buffer of the last error pass
+    bool lm_in_one_group = false;       // no landmark's slots straddle two 256-slot groups
     int Etot = 0;
     std::vector<uint8_t> h_flags;
     // global co-visibility: free landmark -> sorted free poses (free-free active edges, all shards)
@@ -519,6 +520,12 @@ void Engine::initialize(FlatGraph& g)
         for (int l = l0 + 1; l <= l1; l++)
             m.h_lm_ptr[l] = std::max(m.h_lm_ptr[l], m.h_lm_ptr[l - 1]);
     }
+    // does every landmark's slot range lie inside one 256-slot group?  (not if a landmark has more
+    // edges than that; the build pass may then not form T = Hpl invHll on the side, see optimize())
+    m.lm_in_one_group = true;
+    for (int l = 0; l < m.Lall && m.lm_in_one_group; l++)
+        if (m.h_lm_ptr[l + 1] > m.h_lm_ptr[l] && m.h_lm_ptr[l] / kBlock != (m.h_lm_ptr[l + 1] - 1) / kBlock)
+            m.lm_in_one_group = false;
     laps.lap("engine: slot layout");
     const int E = (int)slot_src.size();
     m.E = E;
@@ -1044,11 +1051,21 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
         // computeErrors + buildSystem fused: chi2 at the current estimates comes out of the
         // build pass (ref: cuda_graph_optimisation.cpp:64-67)
         auto tb = Clock::now();
+        // T = Hpl invHll is only materialised for the gather kernels (the landmark-major plan keeps it
+        // in LDS).  From the second iteration on the damping of the first trial is known when the build
+        // is queued, and the build pass leaves invHll and T for it: that trial's Schur complement then
+        // does not read the Hpl stream a second time (CUGO_FUSE_T=0: always the separate edge kernel).
+        if (!m.splan_on && m.d_T.size() == 0)
+            m.d_T.resize((m.ev.block_f32 ? 9 : 18) * (size_t)m.E + 16);
+        const char* fuse_env = std::getenv("CUGO_FUSE_T");
+        const bool fuse_allowed = !(fuse_env && fuse_env[0] == '0');
+        const bool fused_T = fuse_allowed && !m.splan_on && iteration > 0 && m.lm_in_one_group;
         m.timed("build", [&] {
             // chi2 of the build pass is only consumed in the first iteration (see below)
             cugo_k::launch_build(s, m.ev, m.d_poses[m.cur].data(), m.d_lms[m.cur].data(), m.rk,
                                  m.d_Hpp.data(), m.bp(), m.d_Hll.data(), m.bl(), m.d_Hpl.data(),
-                                 m.rs(), iteration == 0 ? m.d_scal.data() : nullptr);
+                                 m.rs(), iteration == 0 ? m.d_scal.data() : nullptr, fused_T ? lambda : -1.0,
+                                 fused_T ? m.d_invHll.data() : nullptr, fused_T ? m.d_T.data() : nullptr);
         });
         sync_prof(PROF_BUILD_SYSTEM, tb);
         if (iteration == 0)
@@ -1087,13 +1104,9 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
         {
             auto ts = Clock::now();
             m.timed("schur", [&] {
-                // T = Hpl invHll is only materialised for the gather kernels (the landmark-major
-                // plan keeps it in LDS)
-                if (!m.splan_on && m.d_T.size() == 0)
-                    m.d_T.resize((m.ev.block_f32 ? 9 : 18) * (size_t)m.E + 16);
                 cugo_k::launch_schur(s, m.ev, m.hs, lambda, 0, m.d_Hpp.data(), m.bp(),
                                      m.d_Hll.data(), m.bl(), m.d_Hpl.data(), m.d_invHll.data(),
-                                     m.splan_on ? nullptr : m.d_T.data(), m.bsc(), m.Hsc());
+                                     m.splan_on ? nullptr : m.d_T.data(), m.bsc(), m.Hsc(), fused_T && q == 0);
             });
             if (sharded)
                 m.exchange(m.d_sys.data(), 36 * (size_t)m.hs.n_blocks + 6 * (size_t)m.P, 0);

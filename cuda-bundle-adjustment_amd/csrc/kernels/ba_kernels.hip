@@ -319,8 +319,16 @@ __global__ __launch_bounds__(BS) void k_build_edges(EV ev, const double* __restr
                                                     double* __restrict__ Hll,
                                                     double* __restrict__ bl,
                                                     double* __restrict__ rec,
-                                                    double* __restrict__ partials)
+                                                    double* __restrict__ partials,
+                                                    double fuse_lambda, double* __restrict__ invHll,
+                                                    S* __restrict__ T)
 {
+    // fuse_lambda >= 0 (the engine, whose slot layout keeps a landmark inside one workgroup, from the
+    // second LM iteration on: the damping of the first trial is known when the build is queued): this
+    // pass also leaves invHll = (Hll + lambda I)^-1 and T = Hpl invHll — exactly what k_schur_edges
+    // would compute from the arrays written here, without reading the Hpl stream again.
+    const bool fuse = fuse_lambda >= 0.0;
+    __shared__ double ivs[BS][7]; // per landmark owner slot: the six entries of invHll (7: bank spread)
     __shared__ double sm[BS / 64];
     // 36 KB used twice: first the landmark contributions cs[9][BS] and the per-edge records
     // rs_[BS*9] (9-double lane stride: conflict-free both ways), at the end the block's 256 Hpl
@@ -425,11 +433,22 @@ __global__ __launch_bounds__(BS) void k_build_edges(EV ev, const double* __restr
             a[0] += c2.h00, a[1] += c2.h01, a[2] += c2.h02, a[3] += c2.h11, a[4] += c2.h12;
             a[5] += c2.h22, a[6] += c2.b0, a[7] += c2.b1, a[8] += c2.b2;
         }
-        double* H = Hll + 9 * (size_t)l;
-        H[0] = a[0], H[1] = a[1], H[2] = a[2];
-        H[3] = a[1], H[4] = a[3], H[5] = a[4];
-        H[6] = a[2], H[7] = a[4], H[8] = a[5];
+        double* Hg = Hll + 9 * (size_t)l;
+        const double h9[9] = {a[0], a[1], a[2], a[1], a[3], a[4], a[2], a[4], a[5]};
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+            Hg[i] = h9[i];
         bl[3 * (size_t)l] = a[6], bl[3 * (size_t)l + 1] = a[7], bl[3 * (size_t)l + 2] = a[8];
+        if (fuse)
+        {
+            const Sym3 iv = sym3_inv(h9, fuse_lambda);
+            double* o = invHll + 9 * (size_t)l;
+            o[0] = iv.b00, o[1] = iv.b01, o[2] = iv.b02;
+            o[3] = iv.b01, o[4] = iv.b11, o[5] = iv.b12;
+            o[6] = iv.b02, o[7] = iv.b12, o[8] = iv.b22;
+            double* q = ivs[threadIdx.x];
+            q[0] = iv.b00, q[1] = iv.b01, q[2] = iv.b02, q[3] = iv.b11, q[4] = iv.b12, q[5] = iv.b22;
+        }
     }
     if (e < ev.L && ev.lm_ptr[e] == ev.lm_ptr[e + 1])
     { // landmark without any edge
@@ -460,6 +479,43 @@ __global__ __launch_bounds__(BS) void k_build_edges(EV ev, const double* __restr
             {
                 const double2 v = pool2[idx];
                 st_pair(Hpl, 9 * (size_t)ebase + idx, v.x, v.y);
+            }
+        }
+        if (fuse)
+        { // T = Hpl invHll of this block's slots, from the blocks still in registers
+            bool act = false;
+            double q[6] = {0, 0, 0, 0, 0, 0};
+            if (e < ev.E && l < ev.L)
+            {
+                const int to = ev.lm_ptr[l] - ebase; // owner slot of the landmark (inside this block)
+                if (to >= 0 && to < BS)
+                {
+#pragma unroll
+                    for (int i = 0; i < 6; i++)
+                        q[i] = ivs[to][i];
+                    act = !(ev.flags[e] & (CUGO_EDGE_FIXED_L | CUGO_EDGE_FIXED_P | CUGO_EDGE_INACTIVE));
+                }
+            }
+            __syncthreads(); // the Hpl blocks have left the pool
+            double* mine = reinterpret_cast<double*>(pool2) + 18 * threadIdx.x;
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+            { // the stored Hpl values (float storage rounds them) are what k_schur_edges would read
+                const double a = (double)(S)H[r], b = (double)(S)H[6 + r], c = (double)(S)H[12 + r];
+                mine[r] = act ? a * q[0] + b * q[1] + c * q[2] : 0.0;
+                mine[6 + r] = act ? a * q[1] + b * q[3] + c * q[4] : 0.0;
+                mine[12 + r] = act ? a * q[2] + b * q[4] + c * q[5] : 0.0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 9; i++)
+            {
+                const int idx = i * BS + threadIdx.x;
+                if (idx < nvalid)
+                {
+                    const double2 v = pool2[idx];
+                    st_pair(T, 9 * (size_t)ebase + idx, v.x, v.y);
+                }
             }
         }
     }
@@ -1454,7 +1510,8 @@ void launch_edge_chi(hipStream_t s, const cugo_edges& e, const double* d_poses, 
 template <typename S>
 static void launch_build_t(hipStream_t s, const cugo_edges& e, const double* d_poses, const double* d_lms,
                            cugo_robust rk, double* d_Hpp, double* d_bp, double* d_Hll, double* d_bl,
-                           S* d_Hpl, ReduceScratch rs, double* d_chi)
+                           S* d_Hpl, ReduceScratch rs, double* d_chi, double fuse_lambda, double* d_invHll,
+                           S* d_T)
 {
     const EV ev = make_ev(e);
     const Robust2 r{{rk.type, rk.delta}, {rk.type_stereo, rk.delta_stereo}};
@@ -1462,7 +1519,7 @@ static void launch_build_t(hipStream_t s, const cugo_edges& e, const double* d_p
     double* d_rec = rs.d_partials + scratch_partials(ev.E, ev.P, ev.L);
     if (nb > 0)
         CUGO_LAUNCH_T(k_build_edges, S, dim3(nb), dim3(BS), 0, s, ev, d_poses, d_lms, r, d_Hpl, d_Hll,
-                      d_bl, d_rec, rs.d_partials);
+                      d_bl, d_rec, rs.d_partials, (d_invHll && d_T) ? fuse_lambda : -1.0, d_invHll, d_T);
     if (d_chi)
         CUGO_LAUNCH(k_sum_partials, dim3(1), dim3(SP_BS), 0, s, rs.d_partials, nb, d_chi);
     if (ev.P > 0)
@@ -1472,12 +1529,14 @@ static void launch_build_t(hipStream_t s, const cugo_edges& e, const double* d_p
 
 void launch_build(hipStream_t s, const cugo_edges& e, const double* d_poses, const double* d_lms,
                   cugo_robust rk, double* d_Hpp, double* d_bp, double* d_Hll, double* d_bl,
-                  void* d_Hpl, ReduceScratch rs, double* d_chi)
+                  void* d_Hpl, ReduceScratch rs, double* d_chi, double fuse_lambda, double* d_invHll, void* d_T)
 {
     if (e.block_f32)
-        launch_build_t(s, e, d_poses, d_lms, rk, d_Hpp, d_bp, d_Hll, d_bl, static_cast<float*>(d_Hpl), rs, d_chi);
+        launch_build_t(s, e, d_poses, d_lms, rk, d_Hpp, d_bp, d_Hll, d_bl, static_cast<float*>(d_Hpl), rs, d_chi,
+                       fuse_lambda, d_invHll, static_cast<float*>(d_T));
     else
-        launch_build_t(s, e, d_poses, d_lms, rk, d_Hpp, d_bp, d_Hll, d_bl, static_cast<double*>(d_Hpl), rs, d_chi);
+        launch_build_t(s, e, d_poses, d_lms, rk, d_Hpp, d_bp, d_Hll, d_bl, static_cast<double*>(d_Hpl), rs, d_chi,
+                       fuse_lambda, d_invHll, static_cast<double*>(d_T));
 }
 
 void launch_max_diagonal(hipStream_t s, const double* d_Hpp, int nP, const double* d_Hll, int nL,
@@ -1497,7 +1556,7 @@ template <typename S>
 static void launch_schur_t(hipStream_t s, const cugo_edges& e, const cugo_hsc_struct& hs, double lambda,
                            int damp_hsc_diag, const double* d_Hpp, const double* d_bp, const double* d_Hll,
                            const double* d_bl, const S* d_Hpl, double* d_invHll, S* d_T,
-                           double* d_bsc, double* d_Hsc)
+                           double* d_bsc, double* d_Hsc, bool have_T)
 {
     const EV ev = make_ev(e);
     if (hs.d_grp_ptr && hs.n_groups == div_up(ev.E, BS))
@@ -1512,7 +1571,7 @@ static void launch_schur_t(hipStream_t s, const cugo_edges& e, const cugo_hsc_st
                         damp_hsc_diag ? lambda : 0.0, d_Hpp, d_bp, d_Hsc, d_bsc);
         return;
     }
-    if (ev.E > 0)
+    if (ev.E > 0 && !have_T) // have_T: the build pass left invHll and T for this lambda (launch_build)
         CUGO_LAUNCH_T(k_schur_edges, S, dim3(div_up(ev.E, BS)), dim3(BS), 0, s, ev, lambda, d_Hll,
                       d_Hpl, d_invHll, d_T);
     if (hs.n_blocks > 0)
@@ -1527,14 +1586,14 @@ static void launch_schur_t(hipStream_t s, const cugo_edges& e, const cugo_hsc_st
 void launch_schur(hipStream_t s, const cugo_edges& e, const cugo_hsc_struct& hs, double lambda,
                   int damp_hsc_diag, const double* d_Hpp, const double* d_bp, const double* d_Hll,
                   const double* d_bl, const void* d_Hpl, double* d_invHll, void* d_T,
-                  double* d_bsc, double* d_Hsc)
+                  double* d_bsc, double* d_Hsc, bool have_T)
 {
     if (e.block_f32)
         launch_schur_t(s, e, hs, lambda, damp_hsc_diag, d_Hpp, d_bp, d_Hll, d_bl,
-                       static_cast<const float*>(d_Hpl), d_invHll, static_cast<float*>(d_T), d_bsc, d_Hsc);
+                       static_cast<const float*>(d_Hpl), d_invHll, static_cast<float*>(d_T), d_bsc, d_Hsc, have_T);
     else
         launch_schur_t(s, e, hs, lambda, damp_hsc_diag, d_Hpp, d_bp, d_Hll, d_bl,
-                       static_cast<const double*>(d_Hpl), d_invHll, static_cast<double*>(d_T), d_bsc, d_Hsc);
+                       static_cast<const double*>(d_Hpl), d_invHll, static_cast<double*>(d_T), d_bsc, d_Hsc, have_T);
 }
 
 template <typename S>

@@ -55,9 +55,13 @@ void launch_errors(hipStream_t s, const cugo_edges& ev, const double* d_poses, c
                    cugo_robust rk, ReduceScratch rs, double* d_chi);
 
 // d_Hpl / d_T below: double [E][18], or float [E][18] when ev.block_f32 is set
+// fuse_lambda >= 0 with d_invHll and d_T given: the pass also leaves invHll = (Hll + lambda I)^-1 and
+// T = Hpl invHll (what launch_schur's edge kernel computes; pass have_T = true there).  Only for slot
+// layouts that keep every landmark's edges inside one 256-slot group (the engine's).
 void launch_build(hipStream_t s, const cugo_edges& ev, const double* d_poses, const double* d_lms,
                   cugo_robust rk, double* d_Hpp, double* d_bp, double* d_Hll, double* d_bl,
-                  void* d_Hpl, ReduceScratch rs, double* d_chi);
+                  void* d_Hpl, ReduceScratch rs, double* d_chi, double fuse_lambda = -1.0,
+                  double* d_invHll = nullptr, void* d_T = nullptr);
 
 void launch_max_diagonal(hipStream_t s, const double* d_Hpp, int nP, const double* d_Hll, int nL,
                          ReduceScratch rs, double* d_out);
@@ -65,7 +69,7 @@ void launch_max_diagonal(hipStream_t s, const double* d_Hpp, int nP, const doubl
 void launch_schur(hipStream_t s, const cugo_edges& ev, const cugo_hsc_struct& hs, double lambda,
                   int damp_hsc_diag, const double* d_Hpp, const double* d_bp, const double* d_Hll,
                   const double* d_bl, const void* d_Hpl, double* d_invHll, void* d_T,
-                  double* d_bsc, double* d_Hsc);
+                  double* d_bsc, double* d_Hsc, bool have_T = false);
 
 // lambda_pose: damping used in the pose part of the scale sum (0 on ranks > 0 of a sharded run
 // so that the all-reduced scale counts lambda*|xp|^2 once)

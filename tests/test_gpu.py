@@ -579,6 +579,30 @@ def test_global_information_and_camera_options(oracle_lib):
     assert np.array_equal(a["pose"], b["pose"])
 
 
+@pytest.mark.parametrize("f32", [False, True])
+def test_build_pass_forming_T_on_the_side_is_bitwise_the_separate_kernel(oracle_lib, f32, monkeypatch):
+    """from the second LM iteration on the build pass also leaves invHll and T = Hpl invHll for the
+    first trial's damping (k_build_edges, fuse_lambda >= 0); CUGO_FUSE_T=0 keeps the separate edge
+    kernel of the Schur complement.  Same arrays in, same arithmetic: bitwise the same run — also
+    with float block storage (T is formed from the ROUNDED Hpl values there) and with rejected
+    trials in between (reject_8x60 takes the separate kernel for its retries)"""
+    d, _ = synth_problem(oracle_lib, 200, 3000, 12500, seed=23, lc=100)
+    g8 = np.load(golden_path("reject_8x60.npz"))
+    cases = [d, {k: g8[k] for k in PROBLEM_KEYS}]
+    for dd in cases:
+        runs = []
+        for v in ("1", "0"):
+            monkeypatch.setenv("CUGO_FUSE_T", v)
+            g = cugo.graph_from_arrays(dd)
+            g.set_float32(f32)
+            g.initialize(); g.optimize(8)
+            runs.append((g.stats(), g.poses(), g.landmarks()))
+            g.close()
+        assert [s["chi2"] for s in runs[0][0]] == [s["chi2"] for s in runs[1][0]]
+        assert [s["trials"] for s in runs[0][0]] == [s["trials"] for s in runs[1][0]]
+        assert np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2])
+
+
 def test_bitwise_reproducible(oracle_lib):
     d, _ = synth_problem(oracle_lib, 200, 3000, 12500, seed=21, lc=100)
     a, b = run_graph(d, 8), run_graph(d, 8)

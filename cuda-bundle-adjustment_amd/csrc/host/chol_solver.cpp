@@ -79,6 +79,10 @@ void cugo_chol::upload(hipStream_t s)
     D.n = P.n, D.perm = b32 + o_perm, D.col_front = b32 + o_col_front;
     D.junk = d_junk.data();
     D.woff = b64 + o_woff, D.winv = d_winv.data(), D.nc_max = P.nc_max;
+    {
+        const char* e = std::getenv("CUGO_EA_LDS");
+        D.ea_lds = !(e && e[0] == '0');
+    }
     D.l21off = b64 + o_l21off, D.l21 = d_l21.data();
     D.ldf = b64 + o_ldf, D.alias_of = b32 + o_alias, D.bw_np = b32 + o_bwnp, D.la_np = b32 + o_lanp;
     d_wl_ptr = b32 + o_wl;

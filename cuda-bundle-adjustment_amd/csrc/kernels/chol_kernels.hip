@@ -154,7 +154,7 @@ __device__ __forceinline__ void wave_lds_sync()
 __device__ __forceinline__ void ea_chunk(const double* __restrict__ U, long ldc, int nru, int nbr,
                                          const int32_t* __restrict__ rel, double* __restrict__ Fp,
                                          long ldp, long rhs_row, int jb, int ch, int lane,
-                                         double* __restrict__ sink, int rbeg, int rend)
+                                         double* __restrict__ sink, double* dsink, int rbeg, int rend)
 {
     // rows [rbeg, rend) of the child's update block column jb (rbeg >= 6*jb, rend <= nru)
     const int i = rbeg + 64 * ch + lane;
@@ -172,7 +172,7 @@ __device__ __forceinline__ void ea_chunk(const double* __restrict__ U, long ldc,
         const int j = 6 * jb + jj;
         const bool okj = ok && ic >= j;
         const double* src = okj ? U + (long)j * ldc + ic : sink;
-        dst[jj] = okj ? Fp + (pjb + jj) * ldp + pi : sink;
+        dst[jj] = okj ? Fp + (pjb + jj) * ldp + pi : dsink;
         u[jj] = *src;
     }
 #pragma unroll
@@ -193,16 +193,22 @@ __device__ __forceinline__ void ea_chunk(const double* __restrict__ U, long ldc,
 // block rows: the ones inside the pivot columns of ITS parent): 3 = the rows that map into the lead
 // rows (what the lead block of the parent's update matrix needs), 4 = the rows below them.
 constexpr int EA_BATCH = 32;
+// dst_lds != nullptr (part 1 only): the contributions go into the LDS copy of F11 (leading dimension
+// LLD) instead of the front in memory — the potrf workgroup then never writes F11 back and reads it
+// again (a store -> load round trip through memory at the head of the critical kernel of the level).
+template <bool TO_LDS = false>
 __device__ __forceinline__ void dev_extend_add(const CholPlanDev& p, double* __restrict__ fronts, int f, int cb0,
-                               int cb1, int part)
+                               int cb1, int part, double* dst_lds = nullptr, double* sink_lds = nullptr)
 {
     __shared__ int s_child[EA_BATCH][5]; // child front, first / past-last matching update block column,
                                          // number of child rows (blocks) inside the parent's pivot block,
                                          // ... inside its pivot block or lead rows
     const int ncbp = p.ncb[f];
     const int nlead = ncbp + (part >= 3 ? p.la_np[f] : 0);
-    const long ldp = p.ldf[f], rhs_row = 6L * p.nb[f];
-    double* Fp = fronts + p.off[f];
+    // (a compile-time choice: with one destination pointer that may be either, every access would be
+    // a flat one)
+    const long ldp = TO_LDS ? (long)LLD : p.ldf[f], rhs_row = 6L * p.nb[f];
+    double* Fp = TO_LDS ? dst_lds : fronts + p.off[f];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
     double* sink = p.junk + ((blockIdx.x & 63) << 10) + threadIdx.x;
     const int c0 = p.child_ptr[f], c1 = p.child_ptr[f + 1];
@@ -250,7 +256,8 @@ __device__ __forceinline__ void dev_extend_add(const CholPlanDev& p, double* __r
                 const int rend = part == 1 ? min(nru, isplit) : part == 3 ? min(nru, isplit2) : nru;
                 const int nch = rend > rbeg ? (rend - rbeg + 63) >> 6 : 0;
                 for (; u < nch; u += nwv)
-                    ea_chunk(U, ldc, nru, nbr, rel, Fp, ldp, rhs_row, jb, u, lane, sink, rbeg, rend);
+                    ea_chunk(U, ldc, nru, nbr, rel, Fp, ldp, rhs_row, jb, u, lane, sink, TO_LDS ? sink_lds : sink, rbeg,
+                             rend);
                 u -= nch;
             }
             __syncthreads(); // the next child may touch the same parent entries
@@ -500,13 +507,28 @@ __device__ __forceinline__ void panel_update_next(double* __restrict__ Ls, int n
 // factorisation) overlaps the parallel part (trailing update).
 // On return Ls holds L11 (lower) and dinv the reciprocal diagonal.  L11 is NOT written back to
 // F: every later consumer (trsm, backward substitution) works with W = L11^-1 (dev_winv).
-__device__ __forceinline__ void dev_potrf(const double* __restrict__ F, long ld, int nc, double* __restrict__ Ls,
-                          double* __restrict__ dinv, int32_t* __restrict__ fail)
+__device__ __forceinline__ void dev_potrf_load(const double* __restrict__ F, long ld, int nc, double* __restrict__ Ls,
+                                               double* __restrict__ dinv)
 {
     dev_load_l11(F, ld, nc, Ls);
     if (threadIdx.x < NC_MAX)
         dinv[threadIdx.x] = 1.0; // identity padding; the panels overwrite the real columns
     __syncthreads();
+}
+
+__device__ __forceinline__ void dev_potrf_panels(int nc, double* __restrict__ Ls, double* __restrict__ dinv,
+                                                 int32_t* __restrict__ fail);
+
+__device__ __forceinline__ void dev_potrf(const double* __restrict__ F, long ld, int nc, double* __restrict__ Ls,
+                          double* __restrict__ dinv, int32_t* __restrict__ fail)
+{
+    dev_potrf_load(F, ld, nc, Ls, dinv);
+    dev_potrf_panels(nc, Ls, dinv, fail);
+}
+
+__device__ __forceinline__ void dev_potrf_panels(int nc, double* __restrict__ Ls, double* __restrict__ dinv,
+                                                 int32_t* __restrict__ fail)
+{
     stamp(0, 2);
     if (threadIdx.x < 64)
         if (nc > PW + 64 ? panel_factor_wave<true>(Ls, nc, 0, dinv) : panel_factor_wave<false>(Ls, nc, 0, dinv))
@@ -1480,18 +1502,25 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
     // the part of the extend-add this factorisation depends on: the children's contributions to
     // F11 (<= 96 x 96), gathered by this workgroup itself; the rest of the pivot columns and the
     // boundary columns are gathered meanwhile by the extra workgroups above
-    if (p.alias_of[f] < 0 && p.child_ptr[f + 1] > p.child_ptr[f])
-    {
+    const int ncp = pad16(ncs);
+    double* Ls = lds;
+    double* dinv = lds + NC_MAX * LLD;
+    double* Vs = dinv + NC_MAX;
+    const bool kids = p.alias_of[f] < 0 && p.child_ptr[f + 1] > p.child_ptr[f];
+    if (kids && !p.ea_lds)
+    { // (CUGO_EA_LDS=0: through the front in memory, then loaded like the rest)
         dev_extend_add(p, fronts, f, 0, p.ncb[f], 1);
         __threadfence_block();
         __syncthreads();
     }
-    const int ncp = pad16(ncs);
+    dev_potrf_load(fronts + p.off[f], p.ldf[f], ncs, Ls, dinv);
     stamp(0, 1);
-    double* Ls = lds;
-    double* dinv = lds + NC_MAX * LLD;
-    double* Vs = dinv + NC_MAX;
-    dev_potrf(fronts + p.off[f], p.ldf[f], ncs, Ls, dinv, fail);
+    if (kids && p.ea_lds)
+    { // straight into the LDS copy (Vs: unused until the W phase, serves as the masked lanes' sink)
+        dev_extend_add<true>(p, fronts, f, 0, p.ncb[f], 1, Ls, Vs + threadIdx.x);
+        __syncthreads();
+    }
+    dev_potrf_panels(ncs, Ls, dinv, fail);
     __syncthreads();
     stamp(0, 5);
     // one wave per diagonal block: V_J = inverse of the 16x16 diagonal block
@@ -1544,17 +1573,17 @@ __device__ __forceinline__ void dev_potrf_front(const CholPlanDev& p, double* __
                                                 double* __restrict__ lds, int32_t* __restrict__ fail)
 {
     const int ncs = 6 * p.ncb[f];
-    if (p.alias_of[f] < 0 && p.child_ptr[f + 1] > p.child_ptr[f])
-    {
-        dev_extend_add(p, fronts, f, 0, p.ncb[f], 1);
-        __threadfence_block();
-        __syncthreads();
-    }
     const int ncp = pad16(ncs);
     double* Ls = lds;
     double* dinv = lds + NC_MAX * LLD;
     double* Vs = dinv + NC_MAX;
-    dev_potrf(fronts + p.off[f], p.ldf[f], ncs, Ls, dinv, fail);
+    dev_potrf_load(fronts + p.off[f], p.ldf[f], ncs, Ls, dinv);
+    if (p.alias_of[f] < 0 && p.child_ptr[f + 1] > p.child_ptr[f])
+    {
+        dev_extend_add<true>(p, fronts, f, 0, p.ncb[f], 1, Ls, Vs + threadIdx.x);
+        __syncthreads();
+    }
+    dev_potrf_panels(ncs, Ls, dinv, fail);
     __syncthreads();
     if ((int)(threadIdx.x >> 6) < (ncp >> 4))
         inv_diag16_wave(Ls, dinv, threadIdx.x >> 6, Vs);

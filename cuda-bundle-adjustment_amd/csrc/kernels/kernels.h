@@ -114,6 +114,7 @@ struct CholPlanDev
     const int64_t* l21off;     // offset of the front's L21 (+ rhs row) in l21, or -1: in the front itself
     double* l21;               // column-major, leading dimension 6*(nb-ncb)+1
     int nc_max;                // widest pivot block (scalars)
+    int ea_lds;                // potrf: children's contributions to F11 go straight into its LDS copy
     const int32_t* col0;       // first pivot column (new ordering, block units)
     const int32_t* rows_ptr;   // [n_fronts+1] into rows: boundary block rows (new ordering)
     const int32_t* rows;

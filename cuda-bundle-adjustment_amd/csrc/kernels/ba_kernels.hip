@@ -869,6 +869,85 @@ __device__ __forceinline__ void sf_slot_products(const uint16_t* __restrict__ pl
     }
 }
 
+constexpr int SF_BS_FWD = 1024;
+// The product phase of k_schur_fused.  STAGED (compile time): the group's product list and slot
+// bounds are in LDS; else they are read from memory.  One pointer that may be either would make
+// every list access a flat one (waits on both memory counters, i.e. also on the partial-sum stores
+// in flight).
+template <bool STAGED>
+__device__ __forceinline__ void sf_products(const SchurPlanDev& pl, int t, int s0, int s1, int p0,
+                                            const uint16_t* __restrict__ sprod, const int32_t* __restrict__ sptr,
+                                            const int32_t* __restrict__ srhs, const double* __restrict__ hs,
+                                            const double* __restrict__ ts, const double* __restrict__ sbl,
+                                            double (*wsc)[10 * 6 * 7], int g)
+{
+    // ---- products.  The group's slots come longest first (host plan).  The first n_wave of them
+    // (more than SF_LONG products: the diagonal blocks, mostly) are taken by a whole wave each: lane
+    // group lg forms every 10th product, the ten sums are added in lane-group order through LDS.
+    // The others go to single lane groups: s_w + u, s_w + u + 80, ...
+    const int lane = t & 63, w = t >> 6;
+    const int lg = lane / 6, r = lane - 6 * lg;
+    if (lg >= SF_LG)
+        return;
+    const int nwave = pl.grp_nwave[g];
+    for (int sl = s0 + w; sl < s0 + nwave; sl += SF_BS_FWD / 64)
+    {
+        const int i0 = STAGED ? sptr[sl - s0] : pl.slot_ptr[sl] - p0;
+        const int i1 = STAGED ? sptr[sl - s0 + 1] : pl.slot_ptr[sl + 1] - p0;
+        const int ri = STAGED ? srhs[sl - s0] : pl.slot_rhs[sl];
+        double acc[6] = {0, 0, 0, 0, 0, 0}, rhs = 0;
+        const uint16_t* plist = STAGED ? sprod : pl.prod + p0;
+        if (ri >= 0) // wave-uniform: the whole wave works on this slot
+            sf_slot_products<true>(plist, i0 + lg, i1, SF_LG, r, hs, ts, sbl, acc, rhs);
+        else
+            sf_slot_products<false>(plist, i0 + lg, i1, SF_LG, r, hs, ts, sbl, acc, rhs);
+        double* sc = wsc[w] + (6 * lg + r) * 7;
+#pragma unroll
+        for (int c = 0; c < 6; c++)
+            sc[c] = acc[c];
+        sc[6] = rhs;
+        // wavefront scope: a wave's LDS operations complete in order, only the compiler must not
+        // move them (a workgroup-scope fence would also wait for the partial stores in flight)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lg == 0)
+        {
+            double tot[7] = {0, 0, 0, 0, 0, 0, 0};
+            for (int g2 = 0; g2 < SF_LG; g2++)
+#pragma unroll
+                for (int c = 0; c < 7; c++)
+                    tot[c] += wsc[w][(6 * g2 + r) * 7 + c];
+            double* o = pl.part_H + 36 * (size_t)sl;
+#pragma unroll
+            for (int c = 0; c < 6; c++)
+                o[6 * c + r] = tot[c];
+            if (ri >= 0)
+                pl.part_b[6 * (size_t)ri + r] = tot[6];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    const int unit = w * SF_LG + lg;
+    for (int sl = s0 + nwave + unit; sl < s1; sl += (SF_BS_FWD / 64) * SF_LG)
+    {
+        const int i0 = STAGED ? sptr[sl - s0] : pl.slot_ptr[sl] - p0;
+        const int i1 = STAGED ? sptr[sl - s0 + 1] : pl.slot_ptr[sl + 1] - p0;
+        const int ri = STAGED ? srhs[sl - s0] : pl.slot_rhs[sl];
+        double acc[6] = {0, 0, 0, 0, 0, 0}, rhs = 0;
+        const uint16_t* plist = STAGED ? sprod : pl.prod + p0;
+        if (ri >= 0)
+            sf_slot_products<true>(plist, i0, i1, 1, r, hs, ts, sbl, acc, rhs);
+        else
+            sf_slot_products<false>(plist, i0, i1, 1, r, hs, ts, sbl, acc, rhs);
+        double* o = pl.part_H + 36 * (size_t)sl;
+#pragma unroll
+        for (int c = 0; c < 6; c++)
+            o[6 * c + r] = acc[c];
+        if (ri >= 0)
+            pl.part_b[6 * (size_t)ri + r] = rhs;
+    }
+}
+
 constexpr int SF_BS = 1024; // 16 waves on a 256-edge group (its LDS footprint allows one workgroup per CU anyway)
 constexpr int SF_LR = (9 * BS + SF_BS - 1) / SF_BS; // load rounds
 template <typename S>
@@ -965,71 +1044,10 @@ __global__ __launch_bounds__(SF_BS) void k_schur_fused(EV ev, double lambda, con
             }
         }
     }
-    // ---- products.  The group's slots come longest first (host plan).  The first n_wave of them
-    // (more than SF_LONG products: the diagonal blocks, mostly) are taken by a whole wave each: lane
-    // group lg forms every 10th product, the ten sums are added in lane-group order through LDS.
-    // The others go to single lane groups: s_w + u, s_w + u + 80, ...
-    const int lane = t & 63, w = t >> 6;
-    const int lg = lane / 6, r = lane - 6 * lg;
-    if (lg >= SF_LG)
-        return;
-    const int nwave = pl.grp_nwave[g];
-    for (int sl = s0 + w; sl < s0 + nwave; sl += SF_BS / 64)
-    {
-        const int i0 = staged ? sptr[sl - s0] : pl.slot_ptr[sl] - p0;
-        const int i1 = staged ? sptr[sl - s0 + 1] : pl.slot_ptr[sl + 1] - p0;
-        const int ri = staged ? srhs[sl - s0] : pl.slot_rhs[sl];
-        double acc[6] = {0, 0, 0, 0, 0, 0}, rhs = 0;
-        const uint16_t* plist = staged ? sprod : pl.prod + p0;
-        if (ri >= 0) // wave-uniform: the whole wave works on this slot
-            sf_slot_products<true>(plist, i0 + lg, i1, SF_LG, r, hs, ts, sbl, acc, rhs);
-        else
-            sf_slot_products<false>(plist, i0 + lg, i1, SF_LG, r, hs, ts, sbl, acc, rhs);
-        double* sc = wsc[w] + (6 * lg + r) * 7;
-#pragma unroll
-        for (int c = 0; c < 6; c++)
-            sc[c] = acc[c];
-        sc[6] = rhs;
-        // wavefront scope: a wave's LDS operations complete in order, only the compiler must not
-        // move them (a workgroup-scope fence would also wait for the partial stores in flight)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (lg == 0)
-        {
-            double tot[7] = {0, 0, 0, 0, 0, 0, 0};
-            for (int g2 = 0; g2 < SF_LG; g2++)
-#pragma unroll
-                for (int c = 0; c < 7; c++)
-                    tot[c] += wsc[w][(6 * g2 + r) * 7 + c];
-            double* o = pl.part_H + 36 * (size_t)sl;
-#pragma unroll
-            for (int c = 0; c < 6; c++)
-                o[6 * c + r] = tot[c];
-            if (ri >= 0)
-                pl.part_b[6 * (size_t)ri + r] = tot[6];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-    const int unit = w * SF_LG + lg;
-    for (int sl = s0 + nwave + unit; sl < s1; sl += (SF_BS / 64) * SF_LG)
-    {
-        const int i0 = staged ? sptr[sl - s0] : pl.slot_ptr[sl] - p0;
-        const int i1 = staged ? sptr[sl - s0 + 1] : pl.slot_ptr[sl + 1] - p0;
-        const int ri = staged ? srhs[sl - s0] : pl.slot_rhs[sl];
-        double acc[6] = {0, 0, 0, 0, 0, 0}, rhs = 0;
-        const uint16_t* plist = staged ? sprod : pl.prod + p0;
-        if (ri >= 0)
-            sf_slot_products<true>(plist, i0, i1, 1, r, hs, ts, sbl, acc, rhs);
-        else
-            sf_slot_products<false>(plist, i0, i1, 1, r, hs, ts, sbl, acc, rhs);
-        double* o = pl.part_H + 36 * (size_t)sl;
-#pragma unroll
-        for (int c = 0; c < 6; c++)
-            o[6 * c + r] = acc[c];
-        if (ri >= 0)
-            pl.part_b[6 * (size_t)ri + r] = rhs;
-    }
+    if (staged)
+        sf_products<true>(pl, t, s0, s1, p0, sprod, sptr, srhs, hs, ts, sbl, wsc, g);
+    else
+        sf_products<false>(pl, t, s0, s1, p0, sprod, sptr, srhs, hs, ts, sbl, wsc, g);
 }
 
 // Hsc[k] = [Hpp(p) (+ lambda I)] - sum of the block's partial slots (group order);

@@ -133,14 +133,22 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
                                      plan.lead_ptr[st + 1] - plan.lead_ptr[st], d_wl_ptr + 3L * plan.ea_ptr[st],
                                      plan.ea_ptr[st + 1] - plan.ea_ptr[st], d_wl_ptr + 3L * plan.eab_ptr[st],
                                      plan.eab_ptr[st + 1] - plan.eab_ptr[st]);
-            pend0 = plan.sb_ptr[st], npend = plan.sb_ptr[st + 1] - plan.sb_ptr[st], pend_tile = plan.stage_tile[st];
+            pend0 = plan.sb_ptr[st], npend = plan.sb_ptr[st + 1] - plan.sb_ptr[st];
+            pend_tile = plan.stage_tile[st] ? plan.stage_tile[st] : 64; // (its item lists are 64x64 ones)
         }
         else
+        {
             cugo_k::launch_chol_upper_stage(
                 s, dev, d_fronts.data(), t0, t1 - t0, d_wl_ptr, plan.ea_ptr[st],
                 plan.ea_ptr[st + 1] - plan.ea_ptr[st], plan.eab_ptr[st],
                 plan.eab_ptr[st + 1] - plan.eab_ptr[st], plan.syrk_ptr[st],
                 plan.syrk_ptr[st + 1] - plan.syrk_ptr[st], plan.stage_tile[st], lds_factor, d_fail);
+            if (plan.stage_tile[st] == 0)
+                cugo_k::launch_chol_two_phase(s, dev, d_fronts.data(), d_wl_ptr + 3L * plan.trsm_ptr[st],
+                                              plan.trsm_ptr[st + 1] - plan.trsm_ptr[st],
+                                              d_wl_ptr + 3L * plan.syrk_ptr[st],
+                                              plan.syrk_ptr[st + 1] - plan.syrk_ptr[st]);
+        }
     }
     if (npend > 0) // the last level's tiles (the rhs rows of the roots)
         cugo_k::launch_chol_potrf_la(s, dev, d_fronts.data(), 0, 0, d_wl_ptr + 3L * pend0, npend, pend_tile, d_fail);

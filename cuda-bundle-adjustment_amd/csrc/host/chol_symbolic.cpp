@@ -36,6 +36,8 @@ CholOptions CholOptions::from_env()
         o.min_subtree_tasks = std::max(0, std::atoi(s));
     if (const char* s = std::getenv("CUGO_MAX_FRONT_COLS"))
         o.max_front_cols = std::min(16, std::max(1, std::atoi(s)));
+    if (const char* s = std::getenv("CUGO_TWO_PHASE_MIN_TILES"))
+        o.two_phase_min_tiles = std::max(0, std::atoi(s));
     if (const char* s = std::getenv("CUGO_XCD_AFFINITY"))
         o.xcd_affinity = std::atoi(s) != 0;
     if (const char* s = std::getenv("CUGO_TILE32_MAX_TILES"))
@@ -828,13 +830,15 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
     std::vector<int32_t> lead, sb;
     P.l21off.assign(ns, -1);
     P.l21_doubles = 0;
-    std::vector<int32_t> ea, eab, sy, bwg;
+    std::vector<int32_t> ea, eab, sy, bwg, tr;
     std::vector<int> sy_front_ntiles; // tiles per front of the level being listed
+    P.trsm_ptr.assign(1, 0);
     P.stage_tile.assign(P.n_stages, 64);
     for (int st = 0; st < P.n_stages; st++)
     {
         const bool subtree = P.has_subtree_stage && st == 0;
         int TS = 64;
+        bool two_phase = false;
         if (!subtree)
         { // tile edge of this level
             long n64 = 0;
@@ -847,6 +851,11 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
             if (n64 <= opt.tile32_max_tiles)
                 TS = 32;
             P.stage_tile[st] = TS;
+            // more tiles than CUs: the level is throughput-bound and the fused tile kernel recomputes every
+            // L21 row tile once per tile of its row / column — solve them once instead (k_up_trsm, k_up_syrk)
+            two_phase = opt.two_phase_min_tiles > 0 && n64 > opt.two_phase_min_tiles;
+            if (two_phase)
+                P.stage_tile[st] = 0;
         }
         if (!subtree)
             for (int t = P.stage_task_ptr[st]; t < P.stage_task_ptr[st + 1]; t++)
@@ -886,16 +895,34 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
                 const int nrs = 6 * (nb - ncb), nbelow = nrs + 1;
                 const int nti = (nbelow + TS - 1) / TS, ntj = (nrs + TS - 1) / TS;
                 const size_t sy_front0 = sy.size();
-                for (int tj = 0; tj < ntj; tj++)
-                    for (int ti = tj; ti < nti; ti++)
+                if (two_phase)
+                { // syrk items (front, linear index over the lower triangle of tiles, tile columns), and
+                  // the row tiles to solve first
+                    int ntl = 0;
+                    for (int tj = 0; tj < ntj; tj++)
+                        ntl += nti - tj;
+                    for (int t = 0; t < ntl; t++)
                     {
-                        sy.push_back(f), sy.push_back(ti), sy.push_back(tj);
+                        sy.push_back(f), sy.push_back(t), sy.push_back(ntj);
                     }
-                for (int ti = ntj; ti < nti; ti++)
-                {
-                    sy.push_back(f), sy.push_back(ti), sy.push_back(-1);
+                    for (int r0 = 0; r0 < nbelow; r0 += 64)
+                    {
+                        tr.push_back(f), tr.push_back(r0), tr.push_back(std::min(64, nbelow - r0));
+                    }
                 }
-                sy_front_ntiles.push_back((int)((sy.size() - sy_front0) / 3));
+                else
+                {
+                    for (int tj = 0; tj < ntj; tj++)
+                        for (int ti = tj; ti < nti; ti++)
+                        {
+                            sy.push_back(f), sy.push_back(ti), sy.push_back(tj);
+                        }
+                    for (int ti = ntj; ti < nti; ti++)
+                    {
+                        sy.push_back(f), sy.push_back(ti), sy.push_back(-1);
+                    }
+                }
+                sy_front_ntiles.push_back(std::max(1, (int)((sy.size() - sy_front0) / 3)));
                 // look-ahead schedule: one lead workgroup per front that has lead rows, and the same
                 // tiles without those that lie wholly inside the lead block
                 const int q = 6 * P.la_np[f];
@@ -996,12 +1023,14 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
                 // (the extend-add items of the potrf launch were tried the same way — they write what the
                 // tiles read — and that took the gain away again: 14.67 vs 14.64 ms; not done)
                 interleave(sy, (size_t)P.syrk_ptr.back(), 0);
+                interleave(tr, (size_t)P.trsm_ptr.back(), 0);
             }
         }
         sy_front_ntiles.clear();
         P.ea_ptr.push_back((int)ea.size() / 3);
         P.eab_ptr.push_back((int)eab.size() / 3);
         P.syrk_ptr.push_back((int)sy.size() / 3);
+        P.trsm_ptr.push_back((int)tr.size() / 3);
         P.bwg_ptr.push_back((int)bwg.size() / 3);
         P.lead_ptr.push_back((int)lead.size() / 3);
         P.sb_ptr.push_back((int)sb.size() / 3);
@@ -1019,6 +1048,9 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
         v += (int)(ea.size() + eab.size()) / 3;
     for (auto& v : P.bwg_ptr)
         v += (int)(ea.size() + eab.size() + sy.size()) / 3;
+    for (auto& v : P.trsm_ptr)
+        v += (int)P.wl.size() / 3;
+    P.wl.insert(P.wl.end(), tr.begin(), tr.end());
     // clearing the fronts before every assembly: only their lower triangles are ever written or read
     // for their value, so only those are cleared (items: front, first column, past-last column);
     // a front stored inside its child's update block has no storage of its own

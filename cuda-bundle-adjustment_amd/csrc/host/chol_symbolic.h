@@ -20,6 +20,9 @@ struct CholOptions
     // CUGO_MIN_SUBTREE_TASKS=0 turns it on (kept under test).
     int min_subtree_tasks = 1 << 30;
     int max_front_cols = 16; // hard cap on pivot block columns of a front (LDS-resident L11)
+    // a level with more 64x64 tiles than this solves its L21 row tiles once (k_up_trsm) and then runs
+    // syrk-only tiles (k_up_syrk) instead of the fused trsm+syrk tile kernel (0: never)
+    int two_phase_min_tiles = 256;
     bool xcd_affinity = true; // tile items of a front share an index class mod 8, i.e. an XCD and its L2 (CUGO_XCD_AFFINITY=0: listed front by front)
     int tile32_max_tiles = 64; // a level with at most this many 64x64 tiles is cut into 32x32 tiles (0: never)
     static CholOptions from_env();
@@ -72,7 +75,8 @@ struct CholPlan
     std::vector<int32_t> lead_ptr, sb_ptr;
     // edge of the syrk tiles of each stage: 64, or 32 where a level has so few 64-tiles that the
     // launch would leave most CUs idle (its duration is then one tile's, and a 32-tile is shorter)
-    std::vector<int32_t> stage_tile;
+    std::vector<int32_t> stage_tile; // (0: the two-phase form, items trsm_ptr / syrk_ptr)
+    std::vector<int32_t> trsm_ptr;   // [n_stages+1] trsm items (front, first row below the pivots, rows)
     // backward pass: boundary block rows of a front that lie in its PARENT's pivot columns (they come
     // first).  The mat-vec over the remaining rows — ancestors above the parent, solved earlier —
     // is done one launch ahead by extra workgroups riding with the parent's level (items bwg:

@@ -754,7 +754,8 @@ __device__ __forceinline__ void deal_col_blocks(int nblk, int g, int& cbA, int& 
 // l&15 store consecutive rows of one column.
 constexpr int PSTB = 80;
 __device__ __forceinline__ void dev_trsm_w(double* __restrict__ F, long ld, int nc, long row0, int nrows,
-                                           const double* __restrict__ Wg, double* __restrict__ Bt)
+                                           const double* __restrict__ Wg, double* __restrict__ Bt,
+                                           double* __restrict__ L21c = nullptr, long ld2 = 0)
 {
     const int ncp = pad16(nc), nblk = ncp >> 4;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, ln = lane & 15, lk = lane >> 4;
@@ -812,7 +813,11 @@ __device__ __forceinline__ void dev_trsm_w(double* __restrict__ F, long ld, int 
                 {
                     const int c = 16 * cb + lk + 4 * q;
                     if (c < nc && r < nrows)
+                    {
                         F[(long)c * ld + row0 + r] = acc[q];
+                        if (L21c) // the compact copy the backward substitution reads (row index below the pivots)
+                            L21c[(long)c * ld2 + (row0 - nc) + r] = acc[q];
+                    }
                 }
                 acc = double4_t{0, 0, 0, 0};
             }
@@ -840,11 +845,11 @@ constexpr int syrk_lds() { return 2 * KC_SYRK * PST; } // doubles
 constexpr int TPST = 72;
 constexpr int trsyrk_lds() { return 2 * KC_SYRK * TPST + 21 * 256; } // doubles
 
+template <int KC = KC_SYRK>
 __device__ __forceinline__ void dev_syrk_tiles(double* __restrict__ F, long ld, int ncs, int nt, int nrs,
                                int first_tile, int ntiles_total, int ntj, double* __restrict__ lds,
                                double* __restrict__ junk)
 {
-    constexpr int KC = KC_SYRK;
     double* sink = junk + ((blockIdx.x & 63) << 10) + threadIdx.x; // private slot of this lane
     // tile index -> (ti, tj): column-major over the lower triangle of tiles, nti = ceil(nt/64)
     const int nti = (nt + 63) >> 6;
@@ -1639,6 +1644,33 @@ __global__ __launch_bounds__(BIG) void k_up_lead(CholPlanDev p, double* __restri
                           p.l21 + p.l21off[f], nrs + 1, lds, p.junk, 0);
 }
 
+// ---- two-phase form of the tile work, for levels with more 64x64 tiles than the chip has CUs: there
+// the fused tile kernel is bound by throughput, and two thirds of its matrix-core work is the X = B W^T
+// of its two row tiles, recomputed by every tile of the row / column.  k_up_trsm solves every 64-row
+// tile ONCE (X in place of B in the front, and into the compact L21 buffer), k_up_syrk then forms
+// U(ti,tj) -= X_i X_j^T with K staged in two halves, so that two workgroups fit a CU.
+constexpr int KC_SYRK2 = 48;
+__global__ __launch_bounds__(BIG) void k_up_trsm(CholPlanDev p, double* __restrict__ fronts,
+                                                 const int32_t* __restrict__ wl)
+{
+    extern __shared__ double lds[];
+    const int32_t* it = wl + 3 * blockIdx.x;
+    const int f = it[0];
+    const int ncs = 6 * p.ncb[f], nrs = 6 * (p.nb[f] - p.ncb[f]);
+    dev_trsm_w(fronts + p.off[f], p.ldf[f], ncs, (long)ncs + it[1], it[2], p.winv + p.woff[f], lds,
+               p.l21 + p.l21off[f], nrs + 1);
+}
+
+__global__ __launch_bounds__(BIG) void k_up_syrk(CholPlanDev p, double* __restrict__ fronts,
+                                                 const int32_t* __restrict__ wl)
+{
+    extern __shared__ double lds[];
+    const int32_t* it = wl + 3 * blockIdx.x;
+    const int f = it[0];
+    const int ncs = 6 * p.ncb[f], nrs = 6 * (p.nb[f] - p.ncb[f]);
+    dev_syrk_tiles<KC_SYRK2>(fronts + p.off[f], p.ldf[f], ncs, nrs + 1, nrs, it[1], it[1] + 1, it[2], lds, p.junk);
+}
+
 // the ancestor part of a front's backward mat-vec, one launch ahead of the front itself:
 // v_j = y_j - sum_{i >= 6*npb} L21[i,j] x_R[i] for the 16 columns j0.. (one wave per column, its
 // 64 lanes stride the rows), parked in xnew at the front's own positions
@@ -1770,6 +1802,22 @@ void launch_chol_subtree_stage(hipStream_t s, const CholPlanDev& p, double* d_fr
                        d_fail);
 }
 
+void launch_chol_two_phase(hipStream_t s, const CholPlanDev& p, double* d_fronts, const int32_t* d_trsm, int ntrsm,
+                           const int32_t* d_syrk, int nsyrk)
+{
+    const size_t lds_t = (size_t)NC_MAX * PSTB * sizeof(double), lds_s = (size_t)2 * KC_SYRK2 * PST * sizeof(double);
+    if (ntrsm > 0)
+    {
+        ensure_lds(reinterpret_cast<const void*>(k_up_trsm), lds_t);
+        CUGO_LAUNCH(k_up_trsm, dim3(ntrsm), dim3(BIG), lds_t, s, p, d_fronts, d_trsm);
+    }
+    if (nsyrk > 0)
+    {
+        ensure_lds(reinterpret_cast<const void*>(k_up_syrk), lds_s);
+        CUGO_LAUNCH(k_up_syrk, dim3(nsyrk), dim3(BIG), lds_s, s, p, d_fronts, d_syrk);
+    }
+}
+
 void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,
                              int ntasks, const int32_t* d_wl, int eap0, int neap, int ea0, int nea,
                              int sy0, int nsy, int tile, size_t lds_bytes, int32_t* d_fail)
@@ -1780,6 +1828,8 @@ void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fron
     ensure_lds(reinterpret_cast<const void*>(k_up_potrf), chol_lds_potrf_bytes());
     CUGO_LAUNCH(k_up_potrf, dim3(ntasks + neap + nea), dim3(BIG), chol_lds_potrf_bytes(), s, p, d_fronts,
                 task0, ntasks, d_wl + 3L * eap0, neap, d_wl + 3L * ea0, d_fail);
+    if (tile == 0)
+        return; // two-phase level: the caller queues launch_chol_two_phase
     if (nsy > 0 && tile == 32)
     {
         const size_t lds32 = (2 * KC_SYRK * TPST32 + 21 * 256) * sizeof(double);

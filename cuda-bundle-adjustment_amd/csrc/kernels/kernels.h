@@ -156,6 +156,10 @@ void launch_chol_subtree_stage(hipStream_t s, const CholPlanDev& p, double* d_fr
 void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,
                              int ntasks, const int32_t* d_wl, int eap0, int neap, int ea0, int nea,
                              int sy0, int nsy, int tile, size_t lds_bytes, int32_t* d_fail);
+// two-phase form of a level's tile work (stage_tile == 0): trsm items (front, first row below the pivots,
+// rows) then syrk items (front, linear tile index, tile columns)
+void launch_chol_two_phase(hipStream_t s, const CholPlanDev& p, double* d_fronts, const int32_t* d_trsm, int ntrsm,
+                           const int32_t* d_syrk, int nsyrk);
 // look-ahead schedule, two launches per level (see k_up_potrf_la / k_up_lead):
 //   potrf of level k (ntasks fronts from task0) together with the non-lead update tiles of level k-1
 //   (items front, ti, tj of edge `tile`); then the lead workgroups of level k (items front,-,-)

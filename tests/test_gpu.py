@@ -296,7 +296,12 @@ def test_float32_block_kernels_vs_oracle(ctx, oracle_lib):
                                  # level's potrf, only the lead block of each front is computed in between
                                  {"CUGO_LOOKAHEAD": "1"},
                                  {"CUGO_LOOKAHEAD": "1", "CUGO_TILE32_MAX_TILES": "0", "CUGO_ALIAS_CHAINS": "0"},
-                                 {"CUGO_LOOKAHEAD": "1", "CUGO_MIN_SUBTREE_TASKS": "0", "CUGO_MAX_SUPER_COLS": "5"}])
+                                 {"CUGO_LOOKAHEAD": "1", "CUGO_MIN_SUBTREE_TASKS": "0", "CUGO_MAX_SUPER_COLS": "5"},
+                                 # every level in the two-phase form (row tiles solved once, then syrk-only tiles)
+                                 # that levels with more tiles than CUs take
+                                 {"CUGO_TWO_PHASE_MIN_TILES": "1", "CUGO_TILE32_MAX_TILES": "0"},
+                                 {"CUGO_TWO_PHASE_MIN_TILES": "1", "CUGO_TILE32_MAX_TILES": "0", "CUGO_ALIAS_CHAINS": "0",
+                                  "CUGO_MAX_SUPER_COLS": "5"}])
 def test_sparse_cholesky_vs_numpy(ctx, env, monkeypatch):
     from test_host import covis_pattern, patterns, random_spd_bsr
     for k, v in env.items():
@@ -390,10 +395,13 @@ def rmse(a, b):
     return float(np.sqrt(np.mean((a - b) ** 2)))
 
 
-@pytest.mark.parametrize("subtree_stage", [False, True, "lookahead"])
+@pytest.mark.parametrize("subtree_stage", [False, True, "lookahead", "two_phase"])
 def test_medium_synthetic_vs_oracle(oracle_lib, subtree_stage, monkeypatch):
     if subtree_stage == "lookahead":  # the opt-in Cholesky schedule, end to end
         monkeypatch.setenv("CUGO_LOOKAHEAD", "1")
+    elif subtree_stage == "two_phase":  # every level in the form the widest levels take
+        monkeypatch.setenv("CUGO_TWO_PHASE_MIN_TILES", "1")
+        monkeypatch.setenv("CUGO_TILE32_MAX_TILES", "0")
     elif subtree_stage:
         monkeypatch.setenv("CUGO_MIN_SUBTREE_TASKS", "0")
     d, prob = synth_problem(oracle_lib, 400, 8000, 33000, seed=11, lc=200)

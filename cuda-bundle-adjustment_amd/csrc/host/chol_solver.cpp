@@ -45,6 +45,7 @@ void cugo_chol::upload(hipStream_t s)
         const int f = P.task_fronts[P.task_ptr[t]];
         m[0] = P.task_ptr[t + 1] - P.task_ptr[t], m[1] = f, m[2] = P.ncb[f], m[3] = P.nb[f], m[4] = P.col0[f];
         m[5] = P.bw_np[f], m[6] = P.rows_ptr[f];
+        m[7] = (P.alias_of[f] < 0 && P.child_ptr[f + 1] > P.child_ptr[f]) ? 1 : 0;
         const int64_t q[4] = {P.off[f], P.ldf[f], P.woff[f], P.l21off[f]};
         std::memcpy(m + 8, q, sizeof q);
     }

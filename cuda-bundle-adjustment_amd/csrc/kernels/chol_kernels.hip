@@ -1502,8 +1502,12 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
         return;
     }
     stamp(0, 0);
-    const int f = p.task_fronts[p.task_ptr[task0 + blockIdx.x]];
-    const int ncs = 6 * p.ncb[f];
+    // the front's scalars from the task's 64-byte record (one scalar load instead of task -> front -> arrays)
+    const int32_t* tm = p.tmeta + 16 * (task0 + blockIdx.x);
+    const long* tm64 = reinterpret_cast<const long*>(tm + 8);
+    const int f = tm[1];
+    const int ncs = 6 * tm[2];
+    const long foff = tm64[0], fld = tm64[1], fwoff = tm64[2];
     // the part of the extend-add this factorisation depends on: the children's contributions to
     // F11 (<= 96 x 96), gathered by this workgroup itself; the rest of the pivot columns and the
     // boundary columns are gathered meanwhile by the extra workgroups above
@@ -1511,18 +1515,18 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
     double* Ls = lds;
     double* dinv = lds + NC_MAX * LLD;
     double* Vs = dinv + NC_MAX;
-    const bool kids = p.alias_of[f] < 0 && p.child_ptr[f + 1] > p.child_ptr[f];
+    const bool kids = tm[7] != 0; // has children and is not stored inside its only child
     if (kids && !p.ea_lds)
     { // (CUGO_EA_LDS=0: through the front in memory, then loaded like the rest)
-        dev_extend_add(p, fronts, f, 0, p.ncb[f], 1);
+        dev_extend_add(p, fronts, f, 0, tm[2], 1);
         __threadfence_block();
         __syncthreads();
     }
-    dev_potrf_load(fronts + p.off[f], p.ldf[f], ncs, Ls, dinv);
+    dev_potrf_load(fronts + foff, fld, ncs, Ls, dinv);
     stamp(0, 1);
     if (kids && p.ea_lds)
     { // straight into the LDS copy (Vs: unused until the W phase, serves as the masked lanes' sink)
-        dev_extend_add<true>(p, fronts, f, 0, p.ncb[f], 1, Ls, Vs + threadIdx.x);
+        dev_extend_add<true>(p, fronts, f, 0, tm[2], 1, Ls, Vs + threadIdx.x);
         __syncthreads();
     }
     dev_potrf_panels(ncs, Ls, dinv, fail);
@@ -1532,7 +1536,7 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
     if ((int)(threadIdx.x >> 6) < (ncp >> 4))
         inv_diag16_wave(Ls, dinv, threadIdx.x >> 6, Vs);
     __syncthreads();
-    dev_winv(Ls, ncp, Vs, p.winv + p.woff[f]);
+    dev_winv(Ls, ncp, Vs, p.winv + fwoff);
     stamp_value(0, 6, ncs);
     stamp(0, 7);
 }

@@ -50,6 +50,21 @@ void cugo_chol::upload(hipStream_t s)
         std::memcpy(m + 8, q, sizeof q);
     }
     const size_t o_tmeta = put32(tmeta);
+    // one 64-byte record per work item (kernels.h: CholPlanDev::fat); only the tile / row-tile items are
+    // read through it, the others just keep the indexing simple
+    std::vector<int32_t> fat(16 * (P.wl.size() / 3), 0);
+    for (size_t i = 0; i < P.wl.size() / 3; i++)
+    {
+        int32_t* m = fat.data() + 16 * i;
+        const int f = P.wl[3 * i];
+        m[0] = f, m[1] = P.wl[3 * i + 1], m[2] = P.wl[3 * i + 2];
+        if (f < 0 || f >= P.n_super)
+            continue;
+        m[3] = 6 * P.ncb[f], m[4] = 6 * (P.nb[f] - P.ncb[f]);
+        const int64_t q[4] = {P.off[f], P.ldf[f], P.woff[f], P.l21off[f]};
+        std::memcpy(m + 8, q, sizeof q);
+    }
+    const size_t o_fat = put32(fat);
     const size_t o_trans = pack32.size(); // bytes
     pack32.resize(o_trans + (P.blk_trans.size() + 3) / 4 + 4, 0);
     if (!P.blk_trans.empty())
@@ -87,6 +102,7 @@ void cugo_chol::upload(hipStream_t s)
     D.l21off = b64 + o_l21off, D.l21 = d_l21.data();
     D.ldf = b64 + o_ldf, D.alias_of = b32 + o_alias, D.bw_np = b32 + o_bwnp, D.la_np = b32 + o_lanp;
     d_wl_ptr = b32 + o_wl;
+    D.wl_base = d_wl_ptr, D.fat = b32 + o_fat;
     lds_factor = cugo_k::chol_lds_factor_bytes(P.nc_max);
     lds_backward = cugo_k::chol_lds_backward_bytes(P.nc_max, P.ld_max);
 }

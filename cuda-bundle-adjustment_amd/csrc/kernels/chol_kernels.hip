@@ -1542,29 +1542,41 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
 }
 
 // fused trsm + syrk: one workgroup per item (front, ti, tj), see dev_trsyrk_tile
+// A tile / row-tile item with everything its kernel needs about the front in ONE 64-byte record
+// (CholPlanDev::fat, parallel to the item list): {front, a, b, 6 ncb, 6 (nb - ncb), -, -, -, off, ldf,
+// woff, l21off}.  item -> front -> six per-front arrays was one dependent round trip more at the head
+// of every tile kernel.
+struct TileItem
+{
+    int a, b, ncs, nrs;
+    long off, ld, woff, l21off;
+};
+__device__ __forceinline__ TileItem tile_item(const CholPlanDev& p, const int32_t* __restrict__ wl)
+{
+    const int32_t* ft = p.fat + 16 * ((int)((wl - p.wl_base) / 3) + (int)blockIdx.x);
+    const long* f64 = reinterpret_cast<const long*>(ft + 8);
+    return TileItem{ft[1], ft[2], ft[3], ft[4], f64[0], f64[1], f64[2], f64[3]};
+}
+
 __global__ __launch_bounds__(BIG) void k_up_trsyrk(CholPlanDev p, double* __restrict__ fronts,
                                                    const int32_t* __restrict__ wl)
 {
     extern __shared__ double lds[];
     stamp(4, 0);
-    const int32_t* it = wl + 3 * blockIdx.x;
-    const int f = it[0];
-    const int ncs = 6 * p.ncb[f], nrs = 6 * (p.nb[f] - p.ncb[f]);
-    dev_trsyrk_tile<false>(fronts + p.off[f], p.ldf[f], ncs, nrs + 1, nrs, it[1], it[2],
-                           p.winv + p.woff[f], p.l21 + p.l21off[f], nrs + 1, lds, p.junk, 0);
+    const TileItem t = tile_item(p, wl);
+    dev_trsyrk_tile<false>(fronts + t.off, t.ld, t.ncs, t.nrs + 1, t.nrs, t.a, t.b, p.winv + t.woff,
+                           p.l21 + t.l21off, t.nrs + 1, lds, p.junk, 0);
     stamp(4, 7);
-    stamp_value(4, 6, 1000000L * (it[1] * 10 + it[2] + 1) + 1000L * ncs + nrs);
+    stamp_value(4, 6, 1000000L * (t.a * 10 + t.b + 1) + 1000L * t.ncs + t.nrs);
 }
 
 __global__ __launch_bounds__(BIG) void k_up_trsyrk32(CholPlanDev p, double* __restrict__ fronts,
                                                      const int32_t* __restrict__ wl)
 {
     extern __shared__ double lds[];
-    const int32_t* it = wl + 3 * blockIdx.x;
-    const int f = it[0];
-    const int ncs = 6 * p.ncb[f], nrs = 6 * (p.nb[f] - p.ncb[f]);
-    dev_trsyrk_tile32(fronts + p.off[f], p.ldf[f], ncs, nrs + 1, nrs, it[1], it[2], p.winv + p.woff[f],
-                      p.l21 + p.l21off[f], nrs + 1, lds, p.junk, 0);
+    const TileItem t = tile_item(p, wl);
+    dev_trsyrk_tile32(fronts + t.off, t.ld, t.ncs, t.nrs + 1, t.nrs, t.a, t.b, p.winv + t.woff, p.l21 + t.l21off,
+                      t.nrs + 1, lds, p.junk, 0);
 }
 
 // ---- look-ahead schedule (CUGO_LOOKAHEAD=1; off by default, see chol_solver.h): two launches per level, the bulk of the update matrix of level
@@ -1658,21 +1670,16 @@ __global__ __launch_bounds__(BIG) void k_up_trsm(CholPlanDev p, double* __restri
                                                  const int32_t* __restrict__ wl)
 {
     extern __shared__ double lds[];
-    const int32_t* it = wl + 3 * blockIdx.x;
-    const int f = it[0];
-    const int ncs = 6 * p.ncb[f], nrs = 6 * (p.nb[f] - p.ncb[f]);
-    dev_trsm_w(fronts + p.off[f], p.ldf[f], ncs, (long)ncs + it[1], it[2], p.winv + p.woff[f], lds,
-               p.l21 + p.l21off[f], nrs + 1);
+    const TileItem t = tile_item(p, wl);
+    dev_trsm_w(fronts + t.off, t.ld, t.ncs, (long)t.ncs + t.a, t.b, p.winv + t.woff, lds, p.l21 + t.l21off, t.nrs + 1);
 }
 
 __global__ __launch_bounds__(BIG) void k_up_syrk(CholPlanDev p, double* __restrict__ fronts,
                                                  const int32_t* __restrict__ wl)
 {
     extern __shared__ double lds[];
-    const int32_t* it = wl + 3 * blockIdx.x;
-    const int f = it[0];
-    const int ncs = 6 * p.ncb[f], nrs = 6 * (p.nb[f] - p.ncb[f]);
-    dev_syrk_tiles<KC_SYRK2>(fronts + p.off[f], p.ldf[f], ncs, nrs + 1, nrs, it[1], it[1] + 1, it[2], lds, p.junk);
+    const TileItem t = tile_item(p, wl);
+    dev_syrk_tiles<KC_SYRK2>(fronts + t.off, t.ld, t.ncs, t.nrs + 1, t.nrs, t.a, t.a + 1, t.b, lds, p.junk);
 }
 
 // the ancestor part of a front's backward mat-vec, one launch ahead of the front itself:

@@ -126,6 +126,8 @@ struct CholPlanDev
     int n_stages;
     const int32_t* tmeta;      // [n_tasks_total][16]: {fronts in the task, first front, its ncb, nb, col0, bw_np,
                                // rows_ptr, has-children-to-add flag, off, ldf, woff, l21off (four int64)} (potrf, backward substitution)
+    const int32_t* wl_base;    // the work-item triples (chol_symbolic.h: CholPlan::wl) ...
+    const int32_t* fat;        // ... and one 64-byte record per item for the tile kernels (TileItem)
     const int32_t* task_ptr;   // [n_tasks_total+1] into task_fronts
     const int32_t* task_fronts;
     // assembly of A (one entry per Hsc block)

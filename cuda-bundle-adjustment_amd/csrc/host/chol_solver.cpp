@@ -38,14 +38,33 @@ void cugo_chol::upload(hipStream_t s)
     const size_t o_perm = put32(P.perm), o_col_front = put32(P.col_front), o_wl = put32(P.wl);
     // one 64-byte record per task (kernels.h: CholPlanDev::tmeta)
     const size_t ntask = P.task_ptr.empty() ? 0 : P.task_ptr.size() - 1; // (no free pose: an empty plan)
-    std::vector<int32_t> tmeta(16 * ntask, 0);
+    // child records of the extend-add into F11 (kernels.h: CholPlanDev::ea1), per front in child order
+    std::vector<int32_t> ea1, ea1_ptr(P.n_super + 1, 0);
+    for (int f = 0; f < P.n_super; f++)
+    {
+        if (P.alias_of[f] < 0)
+            for (int k = P.child_ptr[f]; k < P.child_ptr[f + 1]; k++)
+            {
+                const int c = P.child[k];
+                const int64_t ncs_c = 6 * (int64_t)P.ncb[c], ldc = P.ldf[c];
+                const int64_t q[2] = {P.off[c] + ncs_c * ldc + ncs_c, ldc};
+                int32_t r[8] = {c, P.nb[c] - P.ncb[c], P.la_np[c], P.rel_ptr[c], 0, 0, 0, 0};
+                std::memcpy(r + 4, q, sizeof q);
+                ea1.insert(ea1.end(), r, r + 8);
+            }
+        ea1_ptr[f + 1] = (int32_t)(ea1.size() / 8);
+    }
+    ea1.resize(ea1.size() + 8, 0);
+    const size_t o_ea1 = put32(ea1);
+    std::vector<int32_t> tmeta(20 * ntask, 0);
     for (size_t t = 0; t < ntask; t++)
     {
-        int32_t* m = tmeta.data() + 16 * t;
+        int32_t* m = tmeta.data() + 20 * t;
         const int f = P.task_fronts[P.task_ptr[t]];
         m[0] = P.task_ptr[t + 1] - P.task_ptr[t], m[1] = f, m[2] = P.ncb[f], m[3] = P.nb[f], m[4] = P.col0[f];
         m[5] = P.bw_np[f], m[6] = P.rows_ptr[f];
         m[7] = (P.alias_of[f] < 0 && P.child_ptr[f + 1] > P.child_ptr[f]) ? 1 : 0;
+        m[16] = ea1_ptr[f], m[17] = ea1_ptr[f + 1];
         const int64_t q[4] = {P.off[f], P.ldf[f], P.woff[f], P.l21off[f]};
         std::memcpy(m + 8, q, sizeof q);
     }
@@ -102,7 +121,7 @@ void cugo_chol::upload(hipStream_t s)
     D.l21off = b64 + o_l21off, D.l21 = d_l21.data();
     D.ldf = b64 + o_ldf, D.alias_of = b32 + o_alias, D.bw_np = b32 + o_bwnp, D.la_np = b32 + o_lanp;
     d_wl_ptr = b32 + o_wl;
-    D.wl_base = d_wl_ptr, D.fat = b32 + o_fat;
+    D.wl_base = d_wl_ptr, D.fat = b32 + o_fat, D.ea1 = b32 + o_ea1;
     lds_factor = cugo_k::chol_lds_factor_bytes(P.nc_max);
     lds_backward = cugo_k::chol_lds_backward_bytes(P.nc_max, P.ld_max);
 }

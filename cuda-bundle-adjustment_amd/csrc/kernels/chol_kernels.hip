@@ -266,6 +266,38 @@ __device__ __forceinline__ void dev_extend_add(const CholPlanDev& p, double* __r
     }
 }
 
+// Part 1 into the LDS copy of F11, from the host-built child records CholPlanDev::ea1 (per child of
+// the front, in child order: {child, boundary block rows, leading rows inside this front's pivots,
+// offset of its rel list, offset of its update block (int64), its leading dimension (int64)}): what
+// the general routine finds by walking child_ptr -> child -> five per-front arrays and counting over
+// rel is known when the plan is built — three dependent round trips less before the first panel.
+__device__ __forceinline__ void dev_extend_add_lead(const CholPlanDev& p, const double* __restrict__ fronts, int e0,
+                                                    int e1, double* __restrict__ Ls, double* sink_lds)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    double* sink = p.junk + ((blockIdx.x & 63) << 10) + threadIdx.x;
+    for (int k = e0; k < e1; k++)
+    {
+        const int32_t* d = p.ea1 + 8 * k;
+        const long* d64 = reinterpret_cast<const long*>(d + 4);
+        const int nbr = d[1], np = d[2];
+        const int32_t* rel = p.rel + d[3];
+        const double* U = fronts + d64[0];
+        const long ldc = d64[1];
+        const int nru = 6 * nbr + 1, isplit = 6 * np;
+        int u = wv;
+        for (int jb = 0; jb < np; jb++)
+        {
+            const int rbeg = 6 * jb, rend = isplit;
+            const int nch = (rend - rbeg + 63) >> 6;
+            for (; u < nch; u += nwv)
+                ea_chunk(U, ldc, nru, nbr, rel, Ls, (long)LLD, 0L, jb, u, lane, sink, sink_lds, rbeg, rend);
+            u -= nch;
+        }
+        __syncthreads(); // the next child may touch the same entries
+    }
+}
+
 __device__ __forceinline__ int pad16(int nc) { return (nc + 15) & ~15; }
 
 // load base[idx] with a 32-bit BYTE offset: `uniform 64-bit base + zero-extended 32-bit offset` is
@@ -1503,7 +1535,7 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
     }
     stamp(0, 0);
     // the front's scalars from the task's 64-byte record (one scalar load instead of task -> front -> arrays)
-    const int32_t* tm = p.tmeta + 16 * (task0 + blockIdx.x);
+    const int32_t* tm = p.tmeta + 20 * (task0 + blockIdx.x);
     const long* tm64 = reinterpret_cast<const long*>(tm + 8);
     const int f = tm[1];
     const int ncs = 6 * tm[2];
@@ -1526,8 +1558,7 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
     stamp(0, 1);
     if (kids && p.ea_lds)
     { // straight into the LDS copy (Vs: unused until the W phase, serves as the masked lanes' sink)
-        dev_extend_add<true>(p, fronts, f, 0, tm[2], 1, Ls, Vs + threadIdx.x);
-        __syncthreads();
+        dev_extend_add_lead(p, fronts, tm[16], tm[17], Ls, Vs + threadIdx.x);
     }
     dev_potrf_panels(ncs, Ls, dinv, fail);
     __syncthreads();
@@ -1742,7 +1773,7 @@ __global__ __launch_bounds__(BIG) void k_backward_stage(CholPlanDev p,
     }
     stamp(3, 0);
     const int task = task0 + blockIdx.x;
-    const int32_t* tm = p.tmeta + 16 * task;
+    const int32_t* tm = p.tmeta + 20 * task;
     if (tm[0] == 1)
         dev_backward(p, fronts, front_view(tm), lds, xnew, xout);
     else

@@ -124,7 +124,10 @@ struct CholPlanDev
     const int32_t* rel;        // position (block row in the parent front) of each boundary row
     // schedule
     int n_stages;
-    const int32_t* tmeta;      // [n_tasks_total][16]: {fronts in the task, first front, its ncb, nb, col0, bw_np,
+    const int32_t* ea1;        // per child link: {child, its boundary block rows, its leading rows inside the
+                               // parent's pivots, offset of its rel list, update-block offset (int64), its leading
+                               // dimension (int64)} — the potrf workgroup's extend-add into F11 (tmeta[16..17])
+    const int32_t* tmeta;      // [n_tasks_total][20] (16..17: range in ea1, 18..19 unused): {fronts in the task, first front, its ncb, nb, col0, bw_np,
                                // rows_ptr, has-children-to-add flag, off, ldf, woff, l21off (four int64)} (potrf, backward substitution)
     const int32_t* wl_base;    // the work-item triples (chol_symbolic.h: CholPlan::wl) ...
     const int32_t* fat;        // ... and one 64-byte record per item for the tile kernels (TileItem)

@@ -760,11 +760,16 @@ void Engine::refresh_estimates(const FlatGraph& g)
     if (!m.plan_only)
     {
         hipStream_t s = m.ctx.stream;
-        for (int k = 0; k < 2; k++)
-        {
-            m.d_poses[k].upload(g.poses, s);
-            m.d_lms[k].upload(g.lms, s);
-        }
+        // one copy from (pageable) host memory per array; the second buffer is filled on the device
+        m.d_poses[0].upload(g.poses, s);
+        m.d_lms[0].upload(g.lms, s);
+        m.d_poses[1].resize(g.poses.size()), m.d_lms[1].resize(g.lms.size());
+        if (!g.poses.empty())
+            CUGO_HIP(hipMemcpyAsync(m.d_poses[1].data(), m.d_poses[0].data(), g.poses.size() * sizeof(double),
+                                    hipMemcpyDeviceToDevice, s));
+        if (!g.lms.empty())
+            CUGO_HIP(hipMemcpyAsync(m.d_lms[1].data(), m.d_lms[0].data(), g.lms.size() * sizeof(double),
+                                    hipMemcpyDeviceToDevice, s));
         m.d_x.zero(s);
         CUGO_HIP(hipStreamSynchronize(s)); // the staging vectors may change after return
     }

@@ -314,8 +314,8 @@ __device__ __forceinline__ double ldg32(const double* __restrict__ base, unsigne
 // the factorisation is `base + compile-time offset` — one instruction per access.
 __device__ __forceinline__ void dev_load_l11(const double* __restrict__ F, long ld, int nc, double* __restrict__ Ls)
 {
-    // 1024 threads cover the full NC_MAX x NC_MAX LDS matrix, 9 elements each: all global loads
-    // (clamped addresses, no branch) are issued before the first LDS store; everything outside
+    // 1024 threads cover the full NC_MAX x NC_MAX LDS matrix, 9 elements each: all global loads (6 per
+    // thread: clamped addresses, no branch) are issued before the first LDS store; everything outside
     // the nc x nc lower triangle becomes identity / zero
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const unsigned uld = (unsigned)ld;
@@ -326,7 +326,8 @@ __device__ __forceinline__ void dev_load_l11(const double* __restrict__ F, long 
         for (int q = 0; q < 3; q++)
         {
             const int c = ty + 32 * u, r = tx + 32 * q;
-            v[u][q] = ldg32(F, (unsigned)min(c, nc - 1) * uld + (unsigned)min(r, nc - 1));
+            // (q < u: rows 32q.. lie above columns 32u.. for every thread — nothing of the lower triangle)
+            v[u][q] = q < u ? 0.0 : ldg32(F, (unsigned)min(c, nc - 1) * uld + (unsigned)min(r, nc - 1));
         }
 #pragma unroll
     for (int u = 0; u < 3; u++)

@@ -346,9 +346,12 @@ __device__ __forceinline__ void dev_load_l11(const double* __restrict__ F, long 
 // column to its own rows below the block (lane t: rows j0+6+t and j0+70+t; nc <= 96).
 // Right-looking inside the panel, so every value is touched by one FMA per column: the
 // dependent chain is 6 x (sqrt || 1/d, mul, mul, fma) ~ 6 x 220 cycles.  Writes dinv[j0..j0+5].
+// The factored 6x6 diagonal block and the reciprocal pivots are NOT stored here: nothing reads them
+// before the W phase, so the caller stores them (panel_store_diag) after the barrier that releases the
+// other waves — 27 lane-0 LDS stores less on the one wave whose instruction stream is the chain.
 template <bool HAS1>
 __device__ __forceinline__ bool panel_factor_wave(double* __restrict__ Ls, int nc, int j0,
-                                                  double* __restrict__ dinv)
+                                                  double* __restrict__ dinv, double (&Dout)[21], double (&ivout)[PW])
 {
     const int lane = threadIdx.x & 63;
     const int r0 = j0 + PW + lane, r1 = j0 + PW + 64 + lane;
@@ -445,8 +448,30 @@ __device__ __forceinline__ bool panel_factor_wave(double* __restrict__ Ls, int n
                 W1[c * LLD] = a1[c];
         }
     }
-    if (lane == 0)
     {
+        int k = 0;
+#pragma unroll
+        for (int c = 0; c < PW; c++)
+        {
+            ivout[c] = iv[c];
+#pragma unroll
+            for (int r = 0; r < PW; r++)
+                if (r >= c)
+                    Dout[k++] = D[r][c];
+        }
+    }
+    if (j0 == 0)
+        stamp(2, 3);
+    return bad;
+}
+
+__device__ __forceinline__ void panel_store_diag(double* __restrict__ Ls, int j0, double* __restrict__ dinv,
+                                                 const double (&Dv)[21], const double (&iv)[PW])
+{
+    if ((threadIdx.x & 63) == 0)
+    {
+        double* P = Ls + j0 * LLD + j0;
+        int k = 0;
 #pragma unroll
         for (int c = 0; c < PW; c++)
         {
@@ -454,12 +479,9 @@ __device__ __forceinline__ bool panel_factor_wave(double* __restrict__ Ls, int n
 #pragma unroll
             for (int r = 0; r < PW; r++)
                 if (r >= c)
-                    P[c * LLD + r] = D[r][c];
+                    P[c * LLD + r] = Dv[k++];
         }
     }
-    if (j0 == 0)
-        stamp(2, 3);
-    return bad;
 }
 
 // Trailing update on the matrix cores: columns [c0, NC) of the LDS matrix -= P P^T with P the
@@ -512,12 +534,14 @@ __device__ __forceinline__ void panel_update_mfma(double* __restrict__ Ls, int n
 }
 
 // the PW columns right after panel j0 (the next panel), one matrix element per thread:
-// column = tid >> 7, row = j0 + PW + (tid & 127)   (needs blockDim >= 128 * PW, nc <= 128)
+// column = t >> 7, row = j0 + PW + (t & 127), t = tid - 256   (needs blockDim >= 256 + 128 * PW, nc <= 128)
 __device__ __forceinline__ void panel_update_next(double* __restrict__ Ls, int nc, int j0)
 {
-    const int cc = threadIdx.x >> 7, rr = threadIdx.x & 127;
+    // threads 256 .. 1023: the first wave stores the previous diagonal block meanwhile (dev_potrf_panels)
+    const int t = (int)threadIdx.x - 256;
+    const int cc = t >> 7, rr = t & 127;
     const int c = j0 + PW + cc, r = j0 + PW + rr;
-    if (cc < PW && c < nc && r < nc && r >= c)
+    if (t >= 0 && cc < PW && c < nc && r < nc && r >= c)
     { // two partial sums: a dependent fp64 FMA costs ~40 cycles
         double s0 = 0, s1 = 0;
 #pragma unroll
@@ -563,29 +587,37 @@ __device__ __forceinline__ void dev_potrf_panels(int nc, double* __restrict__ Ls
                                                  int32_t* __restrict__ fail)
 {
     stamp(0, 2);
+    double Dv[21], iv[PW]; // first wave: the diagonal block of the panel factored last, stored one phase later
     if (threadIdx.x < 64)
-        if (nc > PW + 64 ? panel_factor_wave<true>(Ls, nc, 0, dinv) : panel_factor_wave<false>(Ls, nc, 0, dinv))
+        if (nc > PW + 64 ? panel_factor_wave<true>(Ls, nc, 0, dinv, Dv, iv) : panel_factor_wave<false>(Ls, nc, 0, dinv, Dv, iv))
             *fail = 1;
     __syncthreads();
     stamp(0, 3);
+    int jlast = 0;
     for (int j0 = 0; j0 < nc; j0 += PW)
     {
         const int jn = j0 + PW;
         if (jn >= nc)
             break;
-        panel_update_next(Ls, nc, j0); // next panel's columns, one element per thread
+        if (threadIdx.x < 64)
+            panel_store_diag(Ls, j0, dinv, Dv, iv); // off the chain: the others update the next panel's columns
+        panel_update_next(Ls, nc, j0); // one element per thread (threads 256 ..)
         __syncthreads();
         if (threadIdx.x < 64)
         {
             // rows beyond the first 64 below the panel (second register row per lane) exist only
             // in the first panels of a wide pivot block
-            if (jn + PW + 64 < nc ? panel_factor_wave<true>(Ls, nc, jn, dinv) : panel_factor_wave<false>(Ls, nc, jn, dinv))
+            if (jn + PW + 64 < nc ? panel_factor_wave<true>(Ls, nc, jn, dinv, Dv, iv)
+                                  : panel_factor_wave<false>(Ls, nc, jn, dinv, Dv, iv))
                 *fail = 1;
         }
         else
             panel_update_mfma(Ls, nc, j0, jn + PW, (int)(threadIdx.x >> 6) - 1, (int)(blockDim.x >> 6) - 1); // the rest, meanwhile
         __syncthreads();
+        jlast = jn;
     }
+    if (threadIdx.x < 64)
+        panel_store_diag(Ls, jlast, dinv, Dv, iv);
     stamp(0, 4);
 }
 

@@ -491,8 +491,13 @@ __device__ __forceinline__ void panel_store_diag(double* __restrict__ Ls, int j0
 // issues roughly one instruction per 8 cycles, so instruction count is what matters here.
 // Diagonal tiles also write their upper half (never read); rows/columns >= NC_MAX are masked.
 __device__ __forceinline__ void panel_update_mfma(double* __restrict__ Ls, int nc, int j0, int c0,
-                                                  int widx, int nw)
+                                                  int widx_, int nw)
 {
+    // the wave index as a scalar: tile coordinates and the edge test then live in SGPRs, and the common
+    // case — a tile wholly inside the NC_MAX square — runs without a single per-element condition (an
+    // exec-mask region per conditional store costs ~14 instructions; a wave's tile took 1.6 k cycles,
+    // longer than the panel factorisation it is supposed to hide behind)
+    const int widx = __builtin_amdgcn_readfirstlane(widx_);
     if (widx < 0 || c0 >= nc)
         return;
     const int lane = threadIdx.x & 63, ln = lane & 15, lk = lane >> 4;
@@ -512,6 +517,23 @@ __device__ __forceinline__ void panel_update_mfma(double* __restrict__ Ls, int n
             tj++;
         }
         const int R = c0 + 16 * (tj + rem), C = c0 + 16 * tj;
+        if (R + 16 <= NC_MAX) // (C <= R) scalar branch
+        {
+            const double a0 = k0ok ? -P0[R + ln] : 0.0, b0 = P0[C + ln];
+            const double a1 = k1ok ? -P1[R + ln] : 0.0, b1 = P1[C + ln];
+            double4_t acc;
+            double* Cc = Ls + (C + ln) * LLD + R + lk;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                acc[q] = Cc[4 * q];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+            if (PW > 4)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                Cc[4 * q] = acc[q];
+            continue;
+        }
         const int ra = min(R + ln, NC_MAX - 1), cb = min(C + ln, NC_MAX - 1);
         const double a0 = k0ok ? -P0[ra] : 0.0, b0 = P0[cb];
         const double a1 = k1ok ? -P1[ra] : 0.0, b1 = P1[cb];

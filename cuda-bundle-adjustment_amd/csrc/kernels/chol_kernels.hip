@@ -38,7 +38,10 @@ constexpr int CBS = 256;
 constexpr double PIVOT_TOL = 1e-14;
 constexpr int TR = 64; // trsm / syrk tile edge
 constexpr int NC_MAX = 96; // widest pivot block (scalars): L11 lives in LDS
-constexpr int LLD = NC_MAX + 1; // leading dimension of the LDS copy of L11
+// leading dimension of the LDS copy of L11: odd, and 16 rows longer than the matrix — a 16x16 tile of the
+// trailing update that starts inside the matrix may hang over its lower edge into padding nobody reads,
+// so only the one tile per panel that also hangs over the RIGHT edge needs per-element conditions
+constexpr int LLD = NC_MAX + 17;
 // Panel width of the in-LDS Cholesky (must divide 6).  The redundant in-register factorisation of
 // the PW x PW diagonal block grows with PW^3 while the per-panel barrier / look-ahead / LDS
 // round-trip overhead is paid 6/PW times per pose block: measured, 6 beats 3 (32 vs 38 us per
@@ -310,7 +313,7 @@ __device__ __forceinline__ double ldg32(const double* __restrict__ base, unsigne
 
 // lower triangle of F11 -> LDS (upper part zero), padded to a multiple of 16 with an identity
 // block (W = L11^-1 is built from 16-column blocks).  The LDS copy always has leading dimension
-// LLD = 97 (odd: column walks are conflict-free) whatever nc is, so that every LDS address in
+// LLD = 113 (odd: column walks are conflict-free) whatever nc is, so that every LDS address in
 // the factorisation is `base + compile-time offset` — one instruction per access.
 __device__ __forceinline__ void dev_load_l11(const double* __restrict__ F, long ld, int nc, double* __restrict__ Ls)
 {
@@ -517,7 +520,7 @@ __device__ __forceinline__ void panel_update_mfma(double* __restrict__ Ls, int n
             tj++;
         }
         const int R = c0 + 16 * (tj + rem), C = c0 + 16 * tj;
-        if (R + 16 <= NC_MAX) // (C <= R) scalar branch
+        if (C + 16 <= NC_MAX) // scalar branch; rows may run into the padding below row NC_MAX (LLD)
         {
             const double a0 = k0ok ? -P0[R + ln] : 0.0, b0 = P0[C + ln];
             const double a1 = k1ok ? -P1[R + ln] : 0.0, b1 = P1[C + ln];
@@ -1546,7 +1549,7 @@ __global__ __launch_bounds__(BIG) void k_subtree_factor(CholPlanDev p, double* _
         double* Ls = lds;
         double* dinv = lds + NC_MAX * LLD;
         double* Vs = dinv + NC_MAX;
-        double* Bt = Vs + (NC_MAX >> 4) * (16 * 17);
+        double* Bt = Vs; // the trsm tile overlays the diagonal-block inverses (dead once W is built)
         double* Wg = p.winv + p.woff[f];
         if (p.alias_of[f] < 0) // a front stored in its only child's update block needs no extend-add
             dev_extend_add(p, fronts, f, 0, nb, 0);
@@ -1851,7 +1854,7 @@ namespace cugo_k
 size_t chol_lds_factor_bytes(int nc_max)
 { // subtree / potrf kernels: L11 + dinv + inverted diagonal blocks + one trsm B tile, or the syrk panels
     (void)nc_max; // fixed layout (LLD): see dev_load_l11
-    const size_t trsm = (size_t)NC_MAX * LLD + NC_MAX + (NC_MAX >> 4) * (16 * 17) + (size_t)NC_MAX * PSTB;
+    const size_t trsm = (size_t)NC_MAX * LLD + NC_MAX + std::max((size_t)(NC_MAX >> 4) * (16 * 17), (size_t)NC_MAX * PSTB);
     const size_t syrk = (size_t)syrk_lds();
     return (std::max(trsm, syrk) + 8) * sizeof(double);
 }

@@ -845,11 +845,17 @@ __device__ __forceinline__ void deal_col_blocks(int nblk, int g, int& cbA, int& 
 constexpr int PSTB = 80;
 __device__ __forceinline__ void dev_trsm_w(double* __restrict__ F, long ld, int nc, long row0, int nrows,
                                            const double* __restrict__ Wg, double* __restrict__ Bt,
-                                           double* __restrict__ L21c = nullptr, long ld2 = 0)
+                                           double* __restrict__ junk, double* __restrict__ L21c = nullptr,
+                                           long ld2 = 0)
 {
+    // the wave index as a scalar (roles, K-block counts and column indices then live in SGPRs and the
+    // branches on them are scalar ones); rows / columns past the end are clamped for the loads and sent
+    // to a private sink slot for the stores: no exec-mask region per access
     const int ncp = pad16(nc), nblk = ncp >> 4;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, ln = lane & 15, lk = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63, ln = lane & 15, lk = lane >> 4;
     const int rg = w & 3, g = w >> 2;
+    double* sink = junk + ((blockIdx.x & 63) << 10) + threadIdx.x;
     int cbA, cbB;
     deal_col_blocks(nblk, g, cbA, cbB);
     const int nA = cbA + 1, nU = nA + cbB + 1; // K-blocks of the first block / in total (<= 6)
@@ -858,24 +864,36 @@ __device__ __forceinline__ void dev_trsm_w(double* __restrict__ F, long ld, int 
     for (int u = 0; u < 6; u++)
     {
         const int cb = u < nA ? cbA : cbB, kb = u < nA ? u : u - nA;
+        if (u < nU) // scalar
+        {
 #pragma unroll
-        for (int kk = 0; kk < 4; kk++)
-            a[u][kk] = (u < nU) ? Wg[(long)(16 * kb + lk + 4 * kk) * ncp + 16 * cb + ln] : 0.0;
+            for (int kk = 0; kk < 4; kk++)
+                a[u][kk] = Wg[(long)(16 * kb + lk + 4 * kk) * ncp + 16 * cb + ln];
+        }
+        else
+        {
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++)
+                a[u][kk] = 0.0;
+        }
     }
-    { // stage the B tile: r = t&63, 6 columns per thread, loads first
-        const int r = threadIdx.x & 63, kq = threadIdx.x >> 6;
+    { // stage the B tile: r = lane, 6 columns per thread (k = w + 16u), loads first
+        const int r = lane;
+        const bool rok = r < nrows;
+        const long rc = row0 + min(r, nrows - 1);
         double v[6];
 #pragma unroll
         for (int u = 0; u < 6; u++)
         {
-            const int k = kq + 16 * u;
-            v[u] = (k < nc && r < nrows) ? F[(long)k * ld + row0 + r] : 0.0;
+            const int k = w + 16 * u; // scalar
+            const double x = F[(long)min(k, nc - 1) * ld + rc];
+            v[u] = (k < nc && rok) ? x : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < 6; u++)
         {
-            const int k = kq + 16 * u;
-            if (k < ncp)
+            const int k = w + 16 * u;
+            if (k < ncp) // scalar
                 Bt[k * PSTB + r] = v[u];
         }
     }
@@ -902,11 +920,13 @@ __device__ __forceinline__ void dev_trsm_w(double* __restrict__ F, long ld, int 
                 for (int q = 0; q < 4; q++)
                 {
                     const int c = 16 * cb + lk + 4 * q;
-                    if (c < nc && r < nrows)
+                    const bool ok = c < nc && r < nrows;
+                    double* d0 = ok ? F + ((long)c * ld + row0 + r) : sink;
+                    *d0 = acc[q];
+                    if (L21c) // the compact copy the backward substitution reads (row index below the pivots); scalar
                     {
-                        F[(long)c * ld + row0 + r] = acc[q];
-                        if (L21c) // the compact copy the backward substitution reads (row index below the pivots)
-                            L21c[(long)c * ld2 + (row0 - nc) + r] = acc[q];
+                        double* d1 = ok ? L21c + ((long)c * ld2 + (row0 - nc) + r) : sink;
+                        *d1 = acc[q];
                     }
                 }
                 acc = double4_t{0, 0, 0, 0};
@@ -1561,7 +1581,7 @@ __global__ __launch_bounds__(BIG) void k_subtree_factor(CholPlanDev p, double* _
         __threadfence_block();
         __syncthreads();
         for (int r0 = 0; r0 < nt; r0 += TR)
-            dev_trsm_w(F, ld, ncs, ncs + r0, min(TR, nt - r0), Wg, Bt);
+            dev_trsm_w(F, ld, ncs, ncs + r0, min(TR, nt - r0), Wg, Bt, p.junk);
         __threadfence_block();
         __syncthreads();
         const int nti = (nt + 63) / 64, ntj = (nrs + 63) / 64;
@@ -1760,7 +1780,8 @@ __global__ __launch_bounds__(BIG) void k_up_trsm(CholPlanDev p, double* __restri
 {
     extern __shared__ double lds[];
     const TileItem t = tile_item(p, wl);
-    dev_trsm_w(fronts + t.off, t.ld, t.ncs, (long)t.ncs + t.a, t.b, p.winv + t.woff, lds, p.l21 + t.l21off, t.nrs + 1);
+    dev_trsm_w(fronts + t.off, t.ld, t.ncs, (long)t.ncs + t.a, t.b, p.winv + t.woff, lds, p.junk, p.l21 + t.l21off,
+               t.nrs + 1);
 }
 
 __global__ __launch_bounds__(BIG) void k_up_syrk(CholPlanDev p, double* __restrict__ fronts,

@@ -762,7 +762,9 @@ __device__ __forceinline__ void dev_winv(const double* __restrict__ Ls, int ncp,
                                          double* __restrict__ Wg)
 {
     const int nblk = ncp >> 4;
-    const int J = threadIdx.x >> 6, lane = threadIdx.x & 63, ln = lane & 15, lk = lane >> 4;
+    // (the wave index as a scalar: the block counts below are then scalar conditions, not exec-mask regions)
+    const int J = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63, ln = lane & 15, lk = lane >> 4;
     if (J >= nblk)
         return;
     // Right-looking over the block column: as soon as W_KJ is known, every later row's sum
@@ -1642,8 +1644,11 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
     __syncthreads();
     stamp(0, 5);
     // one wave per diagonal block: V_J = inverse of the 16x16 diagonal block
-    if ((int)(threadIdx.x >> 6) < (ncp >> 4))
-        inv_diag16_wave(Ls, dinv, threadIdx.x >> 6, Vs);
+    {
+        const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        if (wv < (ncp >> 4))
+            inv_diag16_wave(Ls, dinv, wv, Vs);
+    }
     __syncthreads();
     dev_winv(Ls, ncp, Vs, p.winv + fwoff);
     stamp_value(0, 6, ncs);

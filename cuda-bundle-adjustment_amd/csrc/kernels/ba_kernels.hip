@@ -375,9 +375,10 @@ __global__ __launch_bounds__(BS) void k_build_edges(EV ev, const double* __restr
 #pragma unroll
                     for (int r = 0; r < 6; r++)
                     {
+                        // (the third Jacobian rows are zero for a monocular edge: the term is added
+                        // unconditionally — a per-lane condition here is an exec-mask region per entry)
                         double s = JP[0][r] * JL[0][c] + JP[1][r] * JL[1][c];
-                        if (in.stereo)
-                            s += JP[2][r] * JL[2][c];
+                        s += JP[2][r] * JL[2][c];
                         H[c * 6 + r] = g.w * s;
                     }
             }
@@ -616,16 +617,14 @@ __global__ __launch_bounds__(BS) void k_build_poses(EV ev, const double* __restr
                 for (int c = rr; c < 6; c++)
                 {
                     double sacc = JP[0][rr] * JP[0][c] + JP[1][rr] * JP[1][c];
-                    if (stereo)
-                        sacc += JP[2][rr] * JP[2][c];
+                    sacc += JP[2][rr] * JP[2][c]; // zero row for a monocular edge (see k_build_edges)
                     acc[k++] += w * sacc;
                 }
 #pragma unroll
             for (int rr = 0; rr < 6; rr++)
             {
                 double sacc = JP[0][rr] * ee[0] + JP[1][rr] * ee[1];
-                if (stereo)
-                    sacc += JP[2][rr] * ee[2];
+                sacc += JP[2][rr] * ee[2];
                 acc[21 + rr] += w * sacc;
             }
         }

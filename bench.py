@@ -50,7 +50,7 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_PEAK_TFLOPS = 78.6    # MI355X fp64 vector / matrix peak
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 
 def survey_bytes(group, E, P, L, B):
@@ -503,6 +503,18 @@ def main():
             "chi2": gpu_chi,
         }
         out.update(extras)
+        # the regimes a caller can be in, beside the headline (config survives the driver's parsing):
+        # ORB-SLAM2 builds a new graph per BA call, i.e. pays `structure_dirty`
+        out["config"]["regimes_ms_per_step"] = {
+            "headline_estimates_only_changed": elapsed / args.steps * 1e3,
+            "reflatten": extras.get("reflatten", {}).get("ms_per_step"),
+            "structure_dirty_new_graph": extras.get("structure_dirty", {}).get("ms_per_step"),
+            "optimize_only": extras.get("optimize_only", {}).get("ms_per_step"),
+            "cold_first_call": (cold["initialize_ms"] + cold["optimize1_ms"]) if cold else None}
+        if world > 1 and comm is None:
+            # a run that fell back to host staging through gloo is not a scaling point: no throughput
+            out["value"] = None
+            out["invalid"] = "native RCCL communicator unavailable: host-staged gloo fallback, value withheld"
         if world > 1 and xstats:
             trials = max(1, (xstats["calls"] - 3) // 2)
             out["exchange"] = {"form": exchange_form, "calls_per_step": xstats["calls"], "bytes_per_step": xstats["bytes"],

@@ -9,7 +9,7 @@ for c in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_INSTS_VALU_MFMA
   tag=$(echo $c | tr ' ' '_')
   rm -rf gpurun_out/pmcc_$tag
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmcc_$tag -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/pmcc_$tag.json 2> gpurun_out/pmcc_$tag.err || exit 1
-  python tests/pmc_summary.py gpurun_out/pmcc_$tag | grep "k_up_\|k_backward\|==" >> gpurun_out/pmc_chol_summary.txt 2>&1
+  python tools/pmc_summary.py gpurun_out/pmcc_$tag | grep "k_up_\|k_backward\|==" >> gpurun_out/pmc_chol_summary.txt 2>&1
   rm -rf gpurun_out/pmcc_$tag
 done
 cat gpurun_out/pmc_chol_summary.txt

@@ -14,12 +14,12 @@ timeout -k 10 300 python bench.py --steps 10 --warmup 2 --float32 --no-cpu-basel
 for W in kitti00 synth10k; do
   rm -rf gpurun_out/prof_${R}_$W
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${R}_$W -- python bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/prof_${R}_$W.json 2> gpurun_out/prof_${R}_$W.err
-  python tests/prof_summary.py gpurun_out/prof_${R}_$W timeline > gpurun_out/prof_${R}_${W}_summary.txt 2>&1
+  python tools/prof_summary.py gpurun_out/prof_${R}_$W timeline > gpurun_out/prof_${R}_${W}_summary.txt 2>&1
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf gpurun_out/pmc_${W}_$c
     timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc_${W}_$c -- python bench.py --workload $W --steps 1 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/pmc_${W}_$c.json 2> gpurun_out/pmc_${W}_$c.err
   done
-  python tests/pmc_summary.py gpurun_out/pmc_${W}_FETCH_SIZE gpurun_out/pmc_${W}_WRITE_SIZE > gpurun_out/pmc_${W}_summary.txt 2>&1
+  python tools/pmc_summary.py gpurun_out/pmc_${W}_FETCH_SIZE gpurun_out/pmc_${W}_WRITE_SIZE > gpurun_out/pmc_${W}_summary.txt 2>&1
 done
 # the landmark-major Schur plan (opt-in): its traffic and L2 behaviour next to the default gather kernels
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
@@ -29,5 +29,5 @@ for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
 done
 rm -rf gpurun_out/pmc_kitti00_TCC
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/pmc_kitti00_TCC -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/pmc_kitti00_TCC.json 2> gpurun_out/pmc_kitti00_TCC.err
-python tests/pmc_summary.py gpurun_out/pmc_plan_FETCH_SIZE gpurun_out/pmc_plan_WRITE_SIZE gpurun_out/pmc_plan_TCC_HIT_sum_TCC_MISS_sum gpurun_out/pmc_kitti00_TCC > gpurun_out/pmc_plan_summary.txt 2>&1
+python tools/pmc_summary.py gpurun_out/pmc_plan_FETCH_SIZE gpurun_out/pmc_plan_WRITE_SIZE gpurun_out/pmc_plan_TCC_HIT_sum_TCC_MISS_sum gpurun_out/pmc_kitti00_TCC > gpurun_out/pmc_plan_summary.txt 2>&1
 tail -2 gpurun_out/gpu_tests.log

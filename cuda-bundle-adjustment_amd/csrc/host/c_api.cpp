@@ -548,7 +548,17 @@ int cugo_graph_initialize(cugo_graph* g)
         g->opt->initialize();
     });
 }
-int cugo_graph_flatten_reuses(cugo_graph* g) { return g->opt->flattenReuses(); }
+int cugo_graph_flatten_reuses(cugo_graph* g)
+{
+    int n = -1;
+    if (guarded([&] {
+            if (!g)
+                throw std::runtime_error("cugo_graph_flatten_reuses: null graph");
+            n = g->opt->flattenReuses();
+        }) != 0)
+        return -1;
+    return n;
+}
 int cugo_graph_optimize(cugo_graph* g, int n_iters)
 {
     return guarded([&] { g->opt->optimize(n_iters); });

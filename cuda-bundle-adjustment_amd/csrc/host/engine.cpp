@@ -4,6 +4,7 @@
 #include "engine.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -60,6 +61,7 @@ struct Engine::Impl : cugo_k::LaunchHook
     cugo_ctx ctx;
     cugo_chol chol;
     int rank = 0, world = 1;
+    int init_rank = -1, init_world = -1; // what the last full initialize() was built for
     cugo_exchange_fn xfn = nullptr;
     void* xuser = nullptr;
     std::shared_ptr<RcclComm> comm; // native exchange (RCCL on the solver's stream); else xfn
@@ -334,6 +336,7 @@ void Engine::initialize(FlatGraph& g)
     hipStream_t s = m.ctx.stream;
     m.Pall = g.Pall, m.Lall = g.Lall, m.P = g.P, m.L = g.L;
     m.rk = g.rk;
+    m.init_rank = m.rank, m.init_world = m.world;
     const int Etot = g.n_edges();
     E_global_ = Etot;
 
@@ -461,15 +464,28 @@ void Engine::initialize(FlatGraph& g)
         for (int l = 0; l < m.L; l++)
             m.cov_ptr[l + 1] += m.cov_ptr[l];
         m.cov_pose.resize((size_t)m.cov_ptr[m.L]);
+        std::atomic<int> dup_lm{-1};
         parallel_chunks((size_t)m.L, 65536, [&](size_t la, size_t lb, unsigned) {
             for (size_t l = la; l < lb; l++)
             {
                 int o = m.cov_ptr[l];
                 for (int i = lm_cnt[l]; i < lm_cnt[l + 1]; i++)
                     if (is_ff(order[i]))
+                    {
+                        // (the slots of a landmark are sorted by pose: equal poses are neighbours)
+                        if (o > m.cov_ptr[l] && m.cov_pose[o - 1] == g.e_pose[order[i]])
+                            dup_lm.store((int)l, std::memory_order_relaxed);
                         m.cov_pose[o++] = g.e_pose[order[i]];
+                    }
             }
         });
+        // Two active edges between the same free pose and free landmark: the reference stores ONE Hpl block
+        // per (pose, landmark) pair and forms only one of the two cross products of such a pair
+        // (ref: .cu:1347-1378 iterates j >= i inside a column), i.e. it has no defined behaviour for them;
+        // here every structure (Hpl slots, Hsc lists, the device structure build) assumes distinct pairs.
+        if (dup_lm.load() >= 0)
+            throw std::runtime_error("cugo: two active edges join the same free pose and free landmark (landmark index " +
+                                     std::to_string(dup_lm.load()) + "): duplicate (pose, landmark) edges are not supported");
     }
     laps.lap("engine: co-visibility");
     // ---- shard: contiguous landmark range balanced by edge count -----------------------
@@ -754,6 +770,8 @@ void Engine::refresh_estimates(const FlatGraph& g)
     Impl& m = *impl_;
     if ((int)(g.poses.size() / 7) != m.Pall || (int)(g.lms.size() / 3) != m.Lall)
         throw std::runtime_error("cugo: refresh_estimates on another graph");
+    if (m.rank != m.init_rank || m.world != m.init_world)
+        throw std::runtime_error("cugo: refresh_estimates after the shard changed (a full initialize() is needed)");
     m.last_err_buf = 0;
     m.xchg_bytes = 0, m.xchg_calls = 0;
     m.cur = 0;

@@ -50,11 +50,13 @@ CudaGraphOptimisationImpl::~CudaGraphOptimisationImpl() {}
 void CudaGraphOptimisationImpl::setShard(int rank, int world, ExchangeFn fn, void* user)
 {
     engine_->set_shard(rank, world, fn, user);
+    flattenValid_ = false; // slot layout, landmark range and Hsc lists were built for the old rank / world
 }
 
 void CudaGraphOptimisationImpl::setComm(std::shared_ptr<cugo_host::RcclComm> comm)
 {
     engine_->set_comm(std::move(comm));
+    flattenValid_ = false;
 }
 
 void CudaGraphOptimisationImpl::exchangeStats(double& bytes, int& calls) const

@@ -9,6 +9,7 @@
 //    pointers, so its device edge order — and fp64 atomic sums — vary run to run);
 //  * robust-kernel parameters are per edge set, not a process-global device object.
 #pragma once
+#include <atomic>
 #include <algorithm>
 #include <array>
 #include <cassert>
@@ -60,11 +61,12 @@ private:
 class ChangeCounted
 {
 public:
-    void touch() noexcept { ++changes_; }
-    unsigned long long changeCount() const noexcept { return changes_; }
+    // (relaxed atomic: members of one set may be mutated from several threads, as they could be before the counter existed)
+    void touch() noexcept { changes_.fetch_add(1, std::memory_order_relaxed); }
+    unsigned long long changeCount() const noexcept { return changes_.load(std::memory_order_relaxed); }
 
 private:
-    unsigned long long changes_ = 0;
+    std::atomic<unsigned long long> changes_{0};
 };
 class BaseVertexSet;
 class BaseEdgeSet;

@@ -133,7 +133,9 @@ int cugo_max_diagonal(cugo_ctx* ctx, const double* d_Hpp, int n_poses, const dou
  * src/sparse_block_matrix.cpp:63-156, and mulBlockIds .cu:1347-1378).
  * Upper-triangular block CSR, diagonal block first in each row.  Off-diagonal block k has
  * the contribution list [d_off_ptr[k], d_off_ptr[k+1]) of (edge_i, edge_j) pairs:
- * Hsc[k] -= T[edge_i] * Hpl[edge_j]^T. (diagonal blocks use the pose's own edge list). */
+ * Hsc[k] -= T[edge_i] * Hpl[edge_j]^T. (diagonal blocks use the pose's own edge list).
+ * ZERO-INITIALISE the struct (memset / = {0}) before filling it: cugo_compute_schur selects the
+ * landmark-major plan kernels when the plan fields (d_grp_ptr ...) are non-NULL. */
 typedef struct cugo_hsc_struct
 {
     int n_blocks;             /* B */

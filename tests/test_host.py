@@ -345,3 +345,52 @@ def test_plan_only_sharded_structure_is_global(lib):
             tot += int(s["offdiag_products"])
             g.close()
         assert tot == offdiag
+
+
+def test_duplicate_pose_landmark_edges_are_rejected(lib):
+    """two active edges between the same free pose and free landmark have no defined behaviour in the
+    reference (one Hpl block per pair, ref .cu:1347-1378) and would break the Hsc lists here: the
+    flattening refuses them with a clear error; a duplicate that touches a fixed vertex is fine"""
+    import synth
+    d = synth.make_problem(n_poses=8, n_landmarks=60, seed=3, fixed_poses=(0,))
+    ff = np.flatnonzero((d["pose_fixed"][d["e_pose"]] == 0) & (d["lm_fixed"][d["e_lm"]] == 0))
+    k = int(ff[len(ff) // 2])
+
+    def with_copy_of(e):
+        out = dict(d)
+        for key in ("e_pose", "e_lm", "e_stereo", "e_omega", "e_cam"):
+            out[key] = np.concatenate([d[key], d[key][e:e + 1]])
+        out["e_meas"] = np.concatenate([d["e_meas"], d["e_meas"][e:e + 1] + 0.25], axis=0)
+        return out
+    g = cugo.graph_from_arrays(with_copy_of(k), plan_only=True)
+    with pytest.raises(cugo.CugoError, match="duplicate"):
+        g.initialize()
+    g.close()
+    fixed_e = int(np.flatnonzero(d["pose_fixed"][d["e_pose"]] != 0)[0])
+    g = cugo.graph_from_arrays(with_copy_of(fixed_e), plan_only=True)
+    g.initialize()
+    assert g.n_active_edges() == len(d["e_pose"]) + 1
+    g.close()
+
+
+def test_changing_the_shard_forces_a_full_initialize(lib):
+    """initialize(); set_shard(); initialize(): the second call must not take the estimates-only path
+    (slot layout, landmark range and Hsc lists belong to the old rank / world)"""
+    d = cugo.synth(60, 900, 3700, seed=1)
+    _, _, offdiag = _expected_structure(d)
+    g = cugo.graph_from_arrays(d, plan_only=True)
+    g.initialize()
+    assert int(g.structure_stats()["offdiag_products"]) == offdiag
+    g.initialize()
+    reuses = g.flatten_reuses()
+    assert reuses >= 1
+    g.set_shard(0, 2, lambda ptr, n, op: None)
+    g.initialize()
+    assert g.flatten_reuses() == reuses                      # a full flattening ran
+    part0 = int(g.structure_stats()["offdiag_products"])
+    g.close()
+    f = cugo.graph_from_arrays(d, plan_only=True)
+    f.set_shard(0, 2, lambda ptr, n, op: None)
+    f.initialize()
+    assert part0 == int(f.structure_stats()["offdiag_products"]) and 0 < part0 < offdiag
+    f.close()

@@ -601,13 +601,6 @@ __device__ __forceinline__ void dev_potrf_load(const double* __restrict__ F, lon
 __device__ __forceinline__ void dev_potrf_panels(int nc, double* __restrict__ Ls, double* __restrict__ dinv,
                                                  int32_t* __restrict__ fail);
 
-__device__ __forceinline__ void dev_potrf(const double* __restrict__ F, long ld, int nc, double* __restrict__ Ls,
-                          double* __restrict__ dinv, int32_t* __restrict__ fail)
-{
-    dev_potrf_load(F, ld, nc, Ls, dinv);
-    dev_potrf_panels(nc, Ls, dinv, fail);
-}
-
 __device__ __forceinline__ void dev_potrf_panels(int nc, double* __restrict__ Ls, double* __restrict__ dinv,
                                                  int32_t* __restrict__ fail)
 {
@@ -644,6 +637,361 @@ __device__ __forceinline__ void dev_potrf_panels(int nc, double* __restrict__ Ls
     if (threadIdx.x < 64)
         panel_store_diag(Ls, jlast, dinv, Dv, iv);
     stamp(0, 4);
+}
+
+// ---------------------------------------------------------------- 16-column panels (default) ----
+// k_up_potrf, round 3.  The 6-column panel loop above is bound by ONE wave's instruction stream (a
+// wave issues at most one instruction per ~4-5 cycles, whatever the instruction): per 6 columns it
+// pays ~100 LDS accesses, two barriers and a redundant 6x6 factorisation in every lane, and W = L11^-1
+// is then built in a phase of its own (12 k cycles) after the last panel.  This form:
+//   * keeps a 16-column panel in REGISTERS, lane <-> row, with no LDS access on the chain: the matrix
+//     is symmetric, so lane k of the 16 lanes that hold the rows of the diagonal block also holds (in
+//     its registers j > k) ROW k of the trailing block — exactly the multipliers step k needs.  They
+//     are broadcast with v_readlane (to SGPRs; an FMA takes one SGPR operand), not through LDS;
+//   * factors L D L^T, not L L^T: step k is  d = a[k][k] (lane k);  y = 1/d (v_rcp + two Newton steps:
+//     5 instructions where sqrt || rsqrt needs 10);  a[i][j] -= (a[i][k] y) a[k][j]  for j > k — one FMA
+//     per column, rows below the diagonal block ride along for free (same instructions, other lanes).
+//     The panel is stored UNSCALED (a[i][k] = l_ik d_k) with the reciprocal pivots beside it; every
+//     consumer scales the operand it loads (one multiply per loaded value, off the critical wave);
+//   * 16 columns = 136 values to broadcast (272 v_readlane_b32) + 120 FMAs + 16 x 8 for the pivots:
+//     ~490 instructions per 16 columns where the 6-column form needs ~3 x 330 plus its LDS round trips;
+//   * K = 16 trailing updates are four v_mfma_f64_16x16x4 per 16x16 tile (two independent chains): the
+//     tiles of the NEXT panel's block column first (phase A: <= 5 tiles, one wave each), then the panel
+//     waves factor it while the remaining tiles are updated (phase B).  Diagonal tiles are kept
+//     symmetric in LDS (mirrored once after the load, updated as full tiles), so a panel load is 16
+//     plain ds_reads with immediate offsets;
+//   * W = L11^-1 = D^-1/2 U, U = L^-1 (unit lower), is built WHILE the panels run, by the waves the
+//     trailing update leaves idle: in the slot after panel J is factored one wave inverts its diagonal
+//     block (V_J, 4 lanes per column), checks its pivots (zero-pivot flag) and forms d^-1/2; one slot
+//     later block row J of U follows on the matrix cores, U_IJ = -V_I sum_K L_IK U_KJ (earlier U blocks
+//     parked in LDS).  After the last panel only V of the last block and one block row remain.
+// Rows 64.. of a panel (the first two panels of a 96-column block) go to a second wave that carries
+// the 16 rows of the diagonal block redundantly in its lanes 0..15: same instruction stream, another SIMD.
+// quad-broadcast of lane Q of every quad (DPP quad_perm: two v_mov_dpp, no LDS)
+template <int Q>
+__device__ __forceinline__ double quad_bcast(double x)
+{
+    constexpr int ctrl = Q * 0x55; // quad_perm [Q, Q, Q, Q]
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), ctrl, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), ctrl, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+namespace p16
+{
+constexpr int OFF_INV = NC_MAX * LLD;     // reciprocal pivots 1/d            [96]
+constexpr int OFF_RS = OFF_INV + NC_MAX;  // d^-1/2                            [96]
+constexpr int OFF_VS = OFF_RS + NC_MAX;   // V_J = L_JJ^-1, [i*17 + c]         [6][272]
+constexpr int OFF_UB = OFF_VS + 6 * 272;  // off-diagonal blocks of U = L^-1, block (I,J) at I(I-1)/2 + J, [k*16 + n]
+constexpr int LDS_DOUBLES = OFF_UB + 15 * 256;
+} // namespace p16
+
+__device__ __forceinline__ double readlane_f64(double x, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ void stamp_wave(int kernel, int slot)
+{
+#ifdef CUGO_STAMPS
+    if (g_stamps && (int)blockIdx.x == g_stamp_block[kernel] && (threadIdx.x & 63) == 0)
+        g_stamps[kernel * 8 + slot] = clock64();
+#else
+    (void)kernel, (void)slot;
+#endif
+}
+
+// half 0: rows j0 .. j0+63; half 1: the diagonal block's rows again (lanes 0..15, not stored) and rows
+// j0+64 .. j0+95 (lanes 16..47).  ncp = padded size of the LDS matrix (identity beyond nc).
+__device__ __forceinline__ void panel16_factor(double* __restrict__ Ls, int ncp, int j0, double* __restrict__ invd,
+                                               int half)
+{
+    const int lane = threadIdx.x & 63;
+    const int rr = half == 0 ? lane : (lane < 16 ? lane : lane + 48); // row inside the panel
+    // rows past the matrix are clamped into the 16 padding rows below it for the loads (valid LDS,
+    // values unused: nothing is ever broadcast from these lanes) and stored into those rows
+    const int rrc = min(rr, NC_MAX + 15 - j0);
+    const double* Pc = Ls + j0 * LLD + j0 + rrc;
+    double a[16];
+#pragma unroll
+    for (int c = 0; c < 16; c++)
+        a[c] = Pc[c * LLD]; // (rows of the diagonal block: its tile is symmetric in LDS)
+    double iv[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+    {
+        const double d = readlane_f64(a[k], k);
+        // 1/d: v_rcp_f64 seed and two Newton steps.  A pivot <= tol (or NaN) is found by the wave that
+        // inverts this diagonal block (it raises the flag): whatever flows on is discarded with the trial
+        double y = __builtin_amdgcn_rcp(d);
+        // row k of the trailing block (lane k's registers j > k) to SGPRs: independent of the reciprocal,
+        // issued in the shadow of v_rcp_f64.  The scheduling barriers keep this order — left alone, the
+        // scheduler of the loop instance re-uses ONE SGPR pair and pays a hazard s_nop per FMA
+        double sk[16];
+#pragma unroll
+        for (int j = k + 1; j < 16; j++)
+            sk[j] = readlane_f64(a[j], k);
+        __builtin_amdgcn_sched_barrier(0);
+        double e = fma(-d, y, 1.0);
+        y = fma(y, e, y);
+        e = fma(-d, y, 1.0);
+        y = fma(y, e, y);
+        iv[k] = y;
+        const double t = a[k] * y; // l_ik
+#pragma unroll
+        for (int j = k + 1; j < 16; j++)
+            a[j] = fma(-t, sk[j], a[j]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    {
+        const bool st = (half == 0 || lane >= 16) && j0 + rr < ncp;
+        double* W0 = Ls + j0 * LLD + (st ? j0 + rr : NC_MAX + (lane & 15));
+#pragma unroll
+        for (int c = 0; c < 16; c++)
+            W0[c * LLD] = a[c];
+    }
+    if (half == 0 && lane == 0)
+    {
+        double* dv = invd + j0;
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            dv[k] = iv[k];
+    }
+}
+
+// trailing tile (rows R.., columns C..) -= L_R D L_C^T, from the factored 16-column panel at j0 (stored
+// unscaled: l_ik d_k, reciprocal pivots in invd)
+__device__ __forceinline__ void panel16_update_tile(double* __restrict__ Ls, const double* __restrict__ invd, int j0,
+                                                    int R, int C)
+{
+    const int lane = threadIdx.x & 63, ln = lane & 15, lk = lane >> 4;
+    const double* Pk = Ls + (j0 + lk) * LLD;
+    double a[4], b[4], y[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++)
+        y[kk] = invd[j0 + lk + 4 * kk], a[kk] = Pk[4 * kk * LLD + R + ln], b[kk] = Pk[4 * kk * LLD + C + ln];
+    double* Cc = Ls + (C + ln) * LLD + R + lk;
+    double c[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        c[q] = Cc[4 * q];
+    double4_t s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
+    s0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0] * y[0], b[0], s0, 0, 0, 0);
+    s1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1] * y[1], b[1], s1, 0, 0, 0);
+    s0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2] * y[2], b[2], s0, 0, 0, 0);
+    s1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3] * y[3], b[3], s1, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        Cc[4 * q] = c[q] - (s0[q] + s1[q]);
+}
+
+// One wave: pivots of diagonal block `blk` checked (zero-pivot flag), d^-1/2 formed, V = L_JJ^-1 (unit
+// lower; l_ik = Ls[k][i] / d_k) by four lanes per column, W_JJ = D^-1/2 V stored to global memory.
+template <int K>
+__device__ __forceinline__ void p16_vstep(const double* __restrict__ Lb, const double* __restrict__ yv, int r4,
+                                          double (&v)[4])
+{
+    constexpr int ko = K & 3, km = K >> 2;
+    // row K of this column is final (unit diagonal); scaled by 1/d_K once for all the rows below
+    const double vk = quad_bcast<ko>(v[km]) * yv[K];
+#pragma unroll
+    for (int m = km; m < 4; m++)
+    {
+        // rows below K only: for m == km that is r4 > ko (clamped address, zero coefficient otherwise)
+        const double l = Lb[K * LLD + r4 + 4 * m];
+        const double coef = (m > km || r4 > ko) ? l : 0.0;
+        v[m] -= coef * vk;
+    }
+}
+
+__device__ __forceinline__ void p16_vblock(const double* __restrict__ Ls, const double* __restrict__ invd,
+                                           double* __restrict__ rsv, double* __restrict__ Vs, int blk,
+                                           double* __restrict__ Wg, int ncp, int32_t* __restrict__ fail)
+{
+    const int lane = threadIdx.x & 63, r4 = lane & 3, c = lane >> 2;
+    const double* Lb = Ls + (16 * blk) * LLD + 16 * blk;
+    {
+        const int l = lane & 15;
+        const double d = Lb[l * LLD + l];
+        const bool bad = !(d > PIVOT_TOL); // ref: csrcholZeroPivot tol (a NaN pivot counts)
+        const double y = __builtin_amdgcn_rsq(d);
+        double g = d * y, h = 0.5 * y;
+        const double r0 = fma(-h, g, 0.5);
+        const double h2 = fma(y, r0, y);
+        g = fma(g, r0, g), h = fma(h, r0, h);
+        const double rh = fma(-h, g, 0.5);
+        const double rs = fma(h2, rh, h2);
+        if (lane < 16)
+            rsv[16 * blk + l] = rs;
+        if (__ballot(bad) != 0 && lane == 0)
+            *fail = 1;
+    }
+    const double* yv = invd + 16 * blk;
+    double v[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+        v[m] = (r4 + 4 * m == c) ? 1.0 : 0.0;
+    p16_vstep<0>(Lb, yv, r4, v), p16_vstep<1>(Lb, yv, r4, v), p16_vstep<2>(Lb, yv, r4, v), p16_vstep<3>(Lb, yv, r4, v);
+    p16_vstep<4>(Lb, yv, r4, v), p16_vstep<5>(Lb, yv, r4, v), p16_vstep<6>(Lb, yv, r4, v), p16_vstep<7>(Lb, yv, r4, v);
+    p16_vstep<8>(Lb, yv, r4, v), p16_vstep<9>(Lb, yv, r4, v), p16_vstep<10>(Lb, yv, r4, v), p16_vstep<11>(Lb, yv, r4, v);
+    p16_vstep<12>(Lb, yv, r4, v), p16_vstep<13>(Lb, yv, r4, v), p16_vstep<14>(Lb, yv, r4, v);
+    wave_lds_sync(); // rsv of this block (written above by lanes 0..15) is read below
+    double* V = Vs + blk * 272;
+    double* wc = Wg + (long)(16 * blk + c) * ncp + 16 * blk;
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+    {
+        const int i = r4 + 4 * m;
+        const double x = (i >= c) ? v[m] : 0.0;
+        V[i * 17 + c] = x;
+        wc[i] = x * rsv[16 * blk + i];
+    }
+}
+
+// One wave: block (I, J), I > J, of U = L^-1:  U_IJ = -V_I sum_{K=J..I-1} L_IK U_KJ  on the matrix cores
+// (the MFMA result layout is the B-operand layout of the next product: the sum never leaves registers),
+// parked in LDS for the rows below and stored to global memory as W_IJ = D_I^-1/2 U_IJ.
+__device__ __forceinline__ void p16_ublock(const double* __restrict__ Ls, const double* __restrict__ invd,
+                                           const double* __restrict__ rsv, const double* __restrict__ Vs,
+                                           double* __restrict__ Ub, int I, int J, bool park, double* __restrict__ Wg,
+                                           int ncp)
+{
+    const int lane = threadIdx.x & 63, ln = lane & 15, lk = lane >> 4;
+    double4_t s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
+    for (int K = J; K < I; K++)
+    {
+        // A = L_IK [m = ln][k = lk + 4kk] = Ls[col 16K + k][row 16I + m] / d_k ;  B = U_KJ [k][n = ln]
+        const double* La = Ls + (16 * K + lk) * LLD + 16 * I + ln;
+        const double* Bb = K == J ? Vs + J * 272 + lk * 17 + ln : Ub + (K * (K - 1) / 2 + J) * 256 + lk * 16 + ln;
+        const int bs = K == J ? 4 * 17 : 4 * 16;
+        double a[4], b[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++)
+            a[kk] = La[4 * kk * LLD] * invd[16 * K + lk + 4 * kk], b[kk] = Bb[kk * bs];
+        s0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], s1, 0, 0, 0);
+        s0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b[2], s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b[3], s1, 0, 0, 0);
+    }
+    double4_t S;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        S[q] = s0[q] + s1[q];
+    double v[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++)
+        v[kk] = Vs[I * 272 + ln * 17 + lk + 4 * kk];
+    double4_t u0 = {0, 0, 0, 0}, u1 = {0, 0, 0, 0};
+    u0 = __builtin_amdgcn_mfma_f64_16x16x4f64(v[0], S[0], u0, 0, 0, 0);
+    u1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v[1], S[1], u1, 0, 0, 0);
+    u0 = __builtin_amdgcn_mfma_f64_16x16x4f64(v[2], S[2], u0, 0, 0, 0);
+    u1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v[3], S[3], u1, 0, 0, 0);
+    double* ub = Ub + (I * (I - 1) / 2 + J) * 256 + lk * 16 + ln;
+    double* wg = Wg + (long)(16 * J + ln) * ncp + 16 * I + lk;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+    {
+        const double u = -(u0[q] + u1[q]);
+        if (park) // (uniform) the last block row is not needed again
+            ub[64 * q] = u;
+        wg[4 * q] = u * rsv[16 * I + lk + 4 * q];
+    }
+}
+
+// F11 (ncp x ncp in LDS, lower triangle, identity padding) -> W = F11^-1/2-inverse in global memory.
+// lds: Ls | invd | rsv | Vs | Ub  (p16::LDS_DOUBLES doubles)
+__device__ __forceinline__ void dev_potrf16(int ncp, double* __restrict__ lds, double* __restrict__ Wg,
+                                            int32_t* __restrict__ fail)
+{
+    double* Ls = lds;
+    double* invd = lds + p16::OFF_INV;
+    double* rsv = lds + p16::OFF_RS;
+    double* Vs = lds + p16::OFF_VS;
+    double* Ub = lds + p16::OFF_UB;
+    const int nblk = ncp >> 4;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // the diagonal 16x16 tiles become symmetric: the trailing update treats them as full tiles and a
+    // panel load is then the same plain column walk for every lane
+    for (int e = threadIdx.x; e < nblk * 256; e += blockDim.x)
+    {
+        const int b = e >> 8, r = (e >> 4) & 15, c = e & 15;
+        if (r > c)
+            Ls[(16 * b + r) * LLD + 16 * b + c] = Ls[(16 * b + c) * LLD + 16 * b + r];
+    }
+    __syncthreads();
+    stamp(0, 2);
+    if (w == 0 || (w == 1 && ncp > 64))
+        panel16_factor(Ls, ncp, 0, invd, w);
+    __syncthreads();
+    stamp(0, 3);
+    // slot s: [phase A: block column s+1 updated by panel s] [phase B: panel s+1 factored || the other
+    // block columns updated by panel s || V_s || block row s-1 of U]; the last two slots have no panel
+    const int nslots = nblk > 1 ? nblk + 1 : 1;
+    for (int s = 0; s < nslots; s++)
+    {
+        const int j0 = 16 * s, jn = j0 + 16;
+        const bool panel = s + 1 < nblk;
+        if (s == 1)
+            stamp(5, 0);
+        if (panel)
+        {
+            for (int I = s + 1 + w; I < nblk; I += 16)
+                panel16_update_tile(Ls, invd, j0, 16 * I, jn);
+            __syncthreads();
+        }
+        if (s == 1)
+            stamp(5, 1);
+        if (w < 2)
+        {
+            if (panel && (w == 0 || ncp - jn > 64))
+                panel16_factor(Ls, ncp, jn, invd, w);
+            if (s == 1)
+                stamp(5, 2);
+        }
+        else
+        {
+            // one task per wave: V_s, the blocks of row s-1 of U, the remaining trailing tiles
+            const int r = s - 1;
+            const int nv = s < nblk ? 1 : 0, nu = (r >= 1 && r < nblk) ? r : 0;
+            int t = w - 2;
+            if (t < nv)
+            {
+                p16_vblock(Ls, invd, rsv, Vs, s, Wg, ncp, fail);
+                if (s == 1)
+                    stamp_wave(5, 4);
+            }
+            else if (t < nv + nu)
+            {
+                p16_ublock(Ls, invd, rsv, Vs, Ub, r, t - nv, r + 1 < nblk, Wg, ncp);
+                if (s == 3)
+                    stamp_wave(5, 5);
+            }
+            else if (s + 2 < nblk)
+            {
+                const int nt = nblk - (s + 2); // block columns still to update
+                const int ntiles = nt * (nt + 1) / 2;
+                for (t -= nv + nu; t < ntiles; t += 14 - nv - nu)
+                {
+                    int tj = 0, rem = t;
+                    while (rem >= nt - tj)
+                    {
+                        rem -= nt - tj;
+                        tj++;
+                    }
+                    panel16_update_tile(Ls, invd, j0, 16 * (s + 2 + tj + rem), 16 * (s + 2 + tj));
+                }
+            }
+        }
+        __syncthreads();
+        if (s == 1)
+            stamp(5, 3);
+        if (s == nblk - 2)
+            stamp(0, 4);
+        if (s == nblk - 1)
+            stamp(0, 5);
+    }
 }
 
 // V = inverse of the 16x16 diagonal block `blk` of L11 (lower triangular) by 16 lanes: lane c
@@ -690,14 +1038,6 @@ __device__ __forceinline__ void inv_diag16_block(const double* __restrict__ Ls, 
 // single wave can issue, not by its chain (16 lanes: 15 FMAs + 15 broadcast LDS loads per step for one
 // wave, ~340 cycles): split four ways a step is <= 4 FMAs + 4 loads per lane plus ONE cross-lane move,
 // the quad-broadcast of the scaled pivot-row entry (DPP quad_perm: two v_mov_dpp, no LDS).
-template <int Q>
-__device__ __forceinline__ double quad_bcast(double x)
-{
-    constexpr int ctrl = Q * 0x55; // quad_perm [Q, Q, Q, Q]
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), ctrl, 0xF, 0xF, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), ctrl, 0xF, 0xF, true);
-    return __hiloint2double(hi, lo);
-}
 
 template <int K>
 __device__ __forceinline__ void inv_diag16_step(const double* __restrict__ Lb, const double* __restrict__ di, int r4,
@@ -1575,7 +1915,8 @@ __global__ __launch_bounds__(BIG) void k_subtree_factor(CholPlanDev p, double* _
         double* Wg = p.winv + p.woff[f];
         if (p.alias_of[f] < 0) // a front stored in its only child's update block needs no extend-add
             dev_extend_add(p, fronts, f, 0, nb, 0);
-        dev_potrf(F, ld, ncs, Ls, dinv, fail);
+        dev_potrf_load(F, ld, ncs, Ls, dinv);
+        dev_potrf_panels(ncs, Ls, dinv, fail);
         __syncthreads();
         dev_inv_diag16(Ls, dinv, ncp, Vs);
         __syncthreads();
@@ -1639,6 +1980,13 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
     if (kids && p.ea_lds)
     { // straight into the LDS copy (Vs: unused until the W phase, serves as the masked lanes' sink)
         dev_extend_add_lead(p, fronts, tm[16], tm[17], Ls, Vs + threadIdx.x);
+    }
+    if (p.panel16)
+    { // 16-column L D L^T panels, W built behind them (dev_potrf16)
+        dev_potrf16(ncp, lds, p.winv + fwoff, fail);
+        stamp_value(0, 6, ncs);
+        stamp(0, 7);
+        return;
     }
     dev_potrf_panels(ncs, Ls, dinv, fail);
     __syncthreads();
@@ -1886,7 +2234,8 @@ size_t chol_lds_factor_bytes(int nc_max)
 }
 size_t chol_lds_potrf_bytes()
 {
-    return ((size_t)NC_MAX * LLD + NC_MAX + (NC_MAX >> 4) * (16 * 17) + 8) * sizeof(double);
+    return std::max((size_t)NC_MAX * LLD + NC_MAX + (NC_MAX >> 4) * (16 * 17) + 8, (size_t)p16::LDS_DOUBLES + 8) *
+           sizeof(double);
 }
 int chol_max_pivot_cols() { return NC_MAX; }
 size_t chol_lds_backward_bytes(int nc_max, long ld_max)

@@ -115,6 +115,7 @@ struct CholPlanDev
     double* l21;               // column-major, leading dimension 6*(nb-ncb)+1
     int nc_max;                // widest pivot block (scalars)
     int ea_lds;                // potrf: children's contributions to F11 go straight into its LDS copy
+    int panel16;               // potrf: 16-column register panels (CUGO_PANEL16=0: the 6-column LDS panels)
     const int32_t* col0;       // first pivot column (new ordering, block units)
     const int32_t* rows_ptr;   // [n_fronts+1] into rows: boundary block rows (new ordering)
     const int32_t* rows;

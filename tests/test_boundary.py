@@ -58,3 +58,121 @@ def test_kernel_seam_shim_compiles_and_links(tmp_path):
                  "updatePoses", "updateLandmarks", "computeScale", "buildHplStructure",
                  "findHschureMulBlockIndices", "createRkFunction"):
         assert "cugo::gpu::" + name in syms, name
+
+
+def _build_seam_library(tmp_path):
+    src = os.path.join(ROOT, "samples", "shim", "seam_driver.cpp")
+    so = str(tmp_path / "libseam.so")
+    libdir = os.path.join(ROOT, "cuda-bundle-adjustment_amd")
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-fPIC", "-shared", "-Wall", "-Wextra", "-Wno-unused-parameter",
+                        "-I", os.path.join(ROOT, "include"), "-I", os.path.dirname(src), src, "-o", so,
+                        "-L", libdir, "-lcugo_hip", "-Wl,--no-undefined", "-Wl,-rpath," + libdir],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-4000:]
+    return so
+
+
+def test_kernel_seam_driver_builds(tmp_path):
+    """CPU leg: the driver that executes the seam compiles and links (the GPU leg below runs it)"""
+    so = _build_seam_library(tmp_path)
+    syms = subprocess.run(["nm", "-C", "--defined-only", so], capture_output=True, text=True).stdout
+    assert "cugo_seam_two_iterations" in syms
+
+
+@pytest.mark.gpu
+def test_kernel_seam_executes_in_block_solver_order(tmp_path):
+    """The reference's kernel seam, EXECUTED: samples/shim/seam_driver.cpp calls cugo::gpu::
+    computeActiveErrors_ -> constructQuadraticForm_ -> maxDiagonal -> addLambda -> computeBschure ->
+    computeHschure -> convertHschureBSRToCSR -> solve -> schurComplementPost -> updatePoses /
+    updateLandmarks -> computeScale in the order of ref src/block_solver.cpp:250-421 for an accepted
+    trial, then a trial forced down the reject path (restoreDiagonal, pop) and its retry, on the
+    golden problem small_10x200; every returned number is compared with the CPU oracle."""
+    import ctypes as C
+    import importlib
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import devmem
+    import oracle
+    from conftest import PROBLEM_KEYS, golden_path
+    cugo = importlib.import_module("cuda-bundle-adjustment_amd")
+    seam = C.CDLL(_build_seam_library(tmp_path))
+    g = np.load(golden_path("small_10x200.npz"))
+    prob = oracle.Problem(*[g[k] for k in PROBLEM_KEYS])
+    ctx = devmem.Ctx()
+    try:
+        f = devmem.flatten(prob)
+        ev = devmem.upload_edges(ctx, f)
+        rowptr, colind, off_ptr, ei, ej = devmem.hsc_structure(f)
+        hs = cugo.HscStruct(len(colind), ctx.to_dev(rowptr), ctx.to_dev(colind), ctx.to_dev(off_ptr), ctx.to_dev(ei),
+                            ctx.to_dev(ej))
+        P, L = f["P"], f["L"]
+        d_pose, d_lm = ctx.to_dev(f["poses"]), ctx.to_dev(f["lms"])
+        out = np.zeros(16)
+        xp1, xl1, xpB, xlB = np.zeros((P, 6)), np.zeros((L, 3)), np.zeros((P, 6)), np.zeros((L, 3))
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+        ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+        seam.cugo_seam_two_iterations.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                                  C.c_void_p, C.c_void_p, C.c_double] + [C.POINTER(C.c_double)] * 5
+        rc = seam.cugo_seam_two_iterations(C.byref(ev), C.byref(hs), ip(rowptr), ip(colind), d_pose, d_lm,
+                                           C.c_double(1e-5), dp(out), dp(xp1), dp(xl1), dp(xpB), dp(xlB))
+        assert rc == 0
+        F0, lam0, ok1, Fhat1, scale1, F1, okA, FhatA, scaleA, lamB, okB, FhatB, scaleB = out[:13]
+
+        def apply_step(p, dxp, dxl):
+            pidx, lidx, _, _ = p.indices()
+            q = p.copy()
+            for i in range(p.n_poses):
+                if not p.pose_fixed[i]:
+                    q.pose[i] = oracle.pose_update(p.pose[i], dxp[pidx[i]])
+            for i in range(p.n_landmarks):
+                if not p.lm_fixed[i]:
+                    q.lm[i] = p.lm[i] + dxl[lidx[i]]
+            return q
+
+        def scale_of(sysd, lam, dxp, dxl):
+            return (dxp * (lam * dxp + sysd["bp"])).sum() + (dxl * (lam * dxl + sysd["bl"])).sum() + 1e-3
+
+        rel = lambda a, b: abs(a - b) / max(abs(b), 1e-300)
+        # ---- iteration 0 against the oracle (ref: cuda_graph_optimisation.cpp:60-101)
+        sys0 = prob.build_system()
+        assert rel(F0, prob.compute_errors()) < 1e-12
+        want_lam0 = 1e-5 * max(0.0, sys0["Hpp"].reshape(-1, 6, 6).diagonal(axis1=1, axis2=2).max(),
+                               sys0["Hll"].reshape(-1, 3, 3).diagonal(axis1=1, axis2=2).max())
+        assert rel(lam0, want_lam0) < 1e-12
+        ok, dxp, dxl = prob.solve_step(lam0)
+        assert ok and ok1 == 1.0
+        np.testing.assert_allclose(xp1, dxp, rtol=1e-8, atol=1e-11 * np.abs(dxp).max())
+        np.testing.assert_allclose(xl1, dxl, rtol=1e-7, atol=1e-10 * np.abs(dxl).max())
+        p1 = apply_step(prob, dxp, dxl)
+        assert rel(Fhat1, p1.compute_errors()) < 1e-10
+        assert rel(scale1, scale_of(sys0, lam0, dxp, dxl)) < 1e-9
+        # the golden trajectory's first iteration is this accepted trial
+        # (trace columns: iteration, chi2, lambda after the iteration, rho, rejected trials)
+        assert int(g["trace"][0][4]) == 0 and rel(Fhat1, float(g["trace"][0][1])) < 1e-10
+        rho = (F0 - Fhat1) / scale1
+        assert rho > 0
+        # ---- iteration 1: computeErrors at the accepted estimates, a trial, the forced reject, the retry
+        assert rel(F1, Fhat1) < 1e-13
+        lam1 = lam0 * max(1.0 / 3.0, min(1.0 - (2 * rho - 1) ** 3, 2.0 / 3.0))
+        assert rel(lam1, float(g["trace"][0][2])) < 1e-8 and rel(rho, float(g["trace"][0][3])) < 1e-8
+        sys1 = p1.build_system()
+        okr, dxpA, dxlA = p1.solve_step(lam1)
+        assert okr and okA == 1.0
+        assert rel(FhatA, apply_step(p1, dxpA, dxlA).compute_errors()) < 1e-10
+        assert rel(scaleA, scale_of(sys1, lam1, dxpA, dxlA)) < 1e-9
+        assert rel(lamB, 2 * lam1) < 1e-12
+        okr, dxpB, dxlB = p1.solve_step(2 * lam1)     # from the SAME estimates: pop() restored them
+        assert okr and okB == 1.0
+        np.testing.assert_allclose(xpB, dxpB, rtol=1e-8, atol=1e-11 * np.abs(dxpB).max())
+        np.testing.assert_allclose(xlB, dxlB, rtol=1e-7, atol=1e-10 * np.abs(dxlB).max())
+        pB = apply_step(p1, dxpB, dxlB)
+        assert rel(FhatB, pB.compute_errors()) < 1e-10
+        assert rel(scaleB, scale_of(sys1, 2 * lam1, dxpB, dxlB)) < 1e-9
+        # the estimates handed back are those of the retry
+        got_pose = ctx.to_host(d_pose, (f["Pall"], 7))
+        want = np.zeros_like(got_pose)
+        want[f["pidx"]] = pB.pose
+        np.testing.assert_allclose(got_pose, want, rtol=0, atol=1e-12)
+    finally:
+        ctx.close()

@@ -301,7 +301,10 @@ def test_float32_block_kernels_vs_oracle(ctx, oracle_lib):
                                  # that levels with more tiles than CUs take
                                  {"CUGO_TWO_PHASE_MIN_TILES": "1", "CUGO_TILE32_MAX_TILES": "0"},
                                  {"CUGO_TWO_PHASE_MIN_TILES": "1", "CUGO_TILE32_MAX_TILES": "0", "CUGO_ALIAS_CHAINS": "0",
-                                  "CUGO_MAX_SUPER_COLS": "5"}])
+                                  "CUGO_MAX_SUPER_COLS": "5"},
+                                 # the 6-column LDS panels of rounds 1-2 (the default is the 16-column register panel)
+                                 {"CUGO_PANEL16": "0"},
+                                 {"CUGO_PANEL16": "0", "CUGO_MIN_SUBTREE_TASKS": "0", "CUGO_MAX_SUPER_COLS": "5"}])
 def test_sparse_cholesky_vs_numpy(ctx, env, monkeypatch):
     from test_host import covis_pattern, patterns, random_spd_bsr
     for k, v in env.items():
@@ -764,6 +767,23 @@ def test_kitti00_shape_full_size(kitti00):
     assert rmse(out["lm"], kitti00["lm"]) < 1e-8
     again = run_graph(d, 10)
     assert chi == [s["chi2"] for s in again["stats"]]
+
+
+def test_kitti07_shape_full_size(oracle_lib):
+    """BASELINE config 1's shape (ba_kitti_07: 248 / 26 127 / 95 037, seed 7, the README's other
+    dataset): 10 LM iterations of the HIP path against the CPU oracle (the "g2o CPU reference path" of
+    that config) at 1e-10, monotone chi2, estimates compared as the reference's README does."""
+    d = cugo.synth(248, 26127, 95037, seed=7, n_loop_closures=500)
+    out = run_graph(d, 10)
+    prob = oracle_lib.Problem(*[d[k] for k in PROBLEM_KEYS])
+    ref = prob.optimize(10)
+    chi = [s["chi2"] for s in out["stats"]]
+    assert len(chi) == 10 and all(b < a for a, b in zip(chi, chi[1:]))
+    assert out["nedges"] == 95037
+    assert_trajectories_match(out["stats"], ref, 1e-10)
+    assert rmse(out["pose"][:, :4], prob.pose[:, :4]) < 1e-11
+    assert rmse(out["pose"][:, 4:], prob.pose[:, 4:]) < 1e-9
+    assert rmse(out["lm"], prob.lm) < 1e-8
 
 
 def test_kitti00_float32_full_size(kitti00):

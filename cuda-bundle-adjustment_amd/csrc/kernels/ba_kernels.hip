@@ -482,7 +482,7 @@ __global__ __launch_bounds__(BS) void k_build_edges(EV ev, const double* __restr
                 st_pair(Hpl, 9 * (size_t)ebase + idx, v.x, v.y);
             }
         }
-        if (fuse)
+        if (fuse && T != nullptr)
         { // T = Hpl invHll of this block's slots, from the blocks still in registers
             bool act = false;
             double q[6] = {0, 0, 0, 0, 0, 0};
@@ -1309,6 +1309,276 @@ __global__ __launch_bounds__(BS) void k_hsc_offdiag(int nblocks,
         Hsc[36 * (size_t)k + lane] = -acc;
 }
 
+// ---------------------------------------------------------------- Schur: pose rows ------
+// The whole block row p of the Schur complement in ONE workgroup (round 3; replaces k_schur_edges' T
+// stream, k_hsc_offdiag and k_hsc_diag when the engine asks for it):
+//     Hsc(p, p) = Hpp[p] (+ lambda I) - sum_e T_e Hpl_e^T        e = edges of pose p
+//     Hsc(p, q) =                     - sum_e T_e Hpl_e'^T       e' = the edge of e's landmark seen by pose q > p
+//     bsc[p]    = bp[p] - sum_e T_e bl[l(e)],                    T_e = Hpl_e (Hll + lambda I)^-1
+// (ref: computeBschureKernel + computeHschureKernel, src/cuda/cuda_block_solver.cu:1286-1345.)
+// Why: the destination-major gather (one wave per Hsc block over its product list) reads every T and Hpl
+// block once per product — 2.6x the compulsory bytes on the kitti_00 shape, 6-8x in memory-side traffic —
+// and runs at ~5 TB/s on that re-fetch traffic.  Here the row's accumulators live in LDS for the lifetime
+// of the workgroup and the pose's edges are STREAMED through it once: Hpl_e is read once for the diagonal
+// product and T_e is formed from it on the spot (T is never written or read); the partner blocks Hpl_e' are
+// the slots right behind e in the landmark-major layout (contiguous), and the poses of a neighbourhood
+// (same XCD: xcd_contiguous_item) re-read the same lines out of L2.  No product lists at all: the column of
+// a product is looked up from the partner's pose index (a direct map for the near columns, binary search in
+// the row's colind for the far ones).
+// Mapping: a round = 28 edges of the pose (7 per wave, lanes 9j..9j+8 load edge j's 144-B block: ~2 cache
+// lines per block), staged in LDS with their first HR_PM partner blocks; products are dealt to the four
+// waves BY DESTINATION COLUMN (column j belongs to wave j mod 4: no two waves ever add to the same block,
+// each block's products arrive in ascending landmark order: fixed order, bit-reproducible), lane = output
+// element; the diagonal block and the rhs are summed in registers per wave and added in wave order.
+constexpr int HR_BS = 256;
+constexpr int HR_W = HR_BS / 64;
+constexpr int HR_CH = 7;            // edges per wave and round
+constexpr int HR_E = HR_W * HR_CH;  // edges per round
+constexpr int HR_PM = 4;            // partner blocks of an edge staged per sub-round
+constexpr int HR_NEAR = 1024;       // direct map q - p -> column position for the near columns
+constexpr int HR_SH = 1 + HR_PM;    // blocks staged per edge: its own + partners
+// doubles of dynamic LDS besides the nnz_cap x 36 accumulators
+constexpr int hr_fixed_doubles() { return HR_E * 18 + HR_E * HR_SH * 18 + HR_E * 9 + HR_E * 3 + HR_W * 42 + HR_NEAR / 4 + HR_E * HR_PM / 2 + HR_E / 2 + 8; }
+
+// per entry of the pose-major edge list: {slot, end of its landmark's slots, landmark, flags}
+__global__ __launch_bounds__(BS) void k_pose_rec(EV ev, int n, int4* __restrict__ rec)
+{
+    const int i = blockIdx.x * BS + threadIdx.x;
+    if (i >= n)
+        return;
+    const int e = ev.pose_edge[i];
+    const int l = ev.lm[e];
+    rec[i] = make_int4(e, ev.lm_ptr[l + 1], l, (int)ev.flags[e]);
+}
+
+// invHll = (Hll + lambda I)^-1 alone (the retry of a rejected trial: a new lambda, no new build pass)
+__global__ __launch_bounds__(BS) void k_inv_hll(int L, double lambda, const double* __restrict__ Hll,
+                                                double* __restrict__ invHll)
+{
+    const int l = blockIdx.x * BS + threadIdx.x;
+    if (l >= L)
+        return;
+    const Sym3 iv = sym3_inv(Hll + 9 * (size_t)l, lambda);
+    double* o = invHll + 9 * (size_t)l;
+    o[0] = iv.b00, o[1] = iv.b01, o[2] = iv.b02;
+    o[3] = iv.b01, o[4] = iv.b11, o[5] = iv.b12;
+    o[6] = iv.b02, o[7] = iv.b12, o[8] = iv.b22;
+}
+
+template <typename S>
+__global__ __launch_bounds__(HR_BS) void k_hsc_rows(EV ev, const int4* __restrict__ rec,
+                                                    const int32_t* __restrict__ rowptr,
+                                                    const int32_t* __restrict__ colind, double lambda_diag,
+                                                    const double* __restrict__ Hpp, const double* __restrict__ bp,
+                                                    const double* __restrict__ bl,
+                                                    const double* __restrict__ invHll, const S* __restrict__ Hpl,
+                                                    double* __restrict__ Hsc, double* __restrict__ bsc, int nnz_cap)
+{
+    extern __shared__ double hr_lds[];
+    double* acc = hr_lds;                                  // [nnz_cap][36]; column 0 (the diagonal) unused
+    double* sT = acc + 36 * (size_t)nnz_cap;               // [HR_E][18]
+    double* sH = sT + HR_E * 18;                           // [HR_E][HR_SH][18]
+    double* sInv = sH + HR_E * HR_SH * 18;                 // [HR_E][9]
+    double* sBl = sInv + HR_E * 9;                         // [HR_E][3]
+    double* dpart = sBl + HR_E * 3;                        // [HR_W][42]
+    int16_t* near = reinterpret_cast<int16_t*>(dpart + HR_W * 42); // [HR_NEAR]
+    int32_t* sdst = reinterpret_cast<int32_t*>(near + HR_NEAR);   // [HR_E][HR_PM] column of a partner product, -1: none
+    int32_t* sact = sdst + HR_E * HR_PM;                           // [HR_E] edge contributes
+    const int p = xcd_contiguous_item(ev.P);
+    if (p >= ev.P)
+        return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int row0 = rowptr[p], nnz = rowptr[p + 1] - row0;
+    for (int j = tid; j < nnz; j += HR_BS)
+    {
+        const int q = colind[row0 + j];
+        if (q - p < HR_NEAR)
+            near[q - p] = (int16_t)j;
+    }
+    for (int i = tid; i < 36 * nnz; i += HR_BS)
+        acc[i] = 0.0;
+    const int i0 = ev.pose_ptr[p], i1 = ev.pose_ptr[p + 1];
+    // staging role: lane = 9 pj + part loads the pair `part` of edge pj of this wave's seven
+    const int pj = min(lane / 9, HR_CH - 1), part = lane - 9 * (lane / 9);
+    const bool writer = lane < 9 * HR_CH;
+    const int u = HR_CH * w + pj; // edge of the round this lane stages
+    // product role: lane = output element (r, c) of a 6x6 product; the diagonal block is formed as its
+    // upper triangle mirrored (exactly symmetric); lanes 36..41: the rhs
+    const int lc = lane < 36 ? lane : 35;
+    const int r6 = lc % 6, c6 = lc / 6;
+    const int dr = min(r6, c6), dc = max(r6, c6);
+    const int rb = lane >= 36 && lane < 42 ? lane - 36 : 0;
+    double dacc = 0.0, bacc = 0.0;
+    constexpr uint8_t NOT_FF = CUGO_EDGE_FIXED_L | CUGO_EDGE_FIXED_P | CUGO_EDGE_INACTIVE;
+    __syncthreads();
+    const int nrounds = (i1 - i0 + HR_E - 1) / HR_E;
+    int4 rc = make_int4(0, 0, 0, NOT_FF);
+    if (nrounds > 0)
+        rc = rec[min(i0 + u, i1 - 1)];
+    for (int rd = 0; rd < nrounds; rd++)
+    {
+        const int idx = i0 + HR_E * rd + u;
+        const int e = rc.x, lend = rc.y;
+        const bool act = writer && idx < i1 && !(rc.w & NOT_FF);
+        const int l = act ? rc.z : 0;
+        const int np = act ? lend - e - 1 : 0; // slots behind e in its landmark (inactive ones included)
+        if (rd + 1 < nrounds) // the next round's records: in flight during this round
+            rc = rec[min(idx + HR_E, i1 - 1)];
+        // ---- loads of this round: own block, invHll and bl of its landmark, the first HR_PM partners
+        const double2 hv = ld_pair(Hpl, 9 * (size_t)e + part);
+        const double ivv = invHll[9 * (size_t)l + part];
+        const double blv = bl[3 * (size_t)l + min(part, 2)];
+        for (int t0 = 0;; t0 += HR_PM)
+        {
+            double2 pv[HR_PM];
+#pragma unroll
+            for (int t = 0; t < HR_PM; t++)
+            {
+                const int es = e + 1 + t0 + t;
+                pv[t] = ld_pair(Hpl, 9 * (size_t)(es < lend ? es : e) + part);
+            }
+            int dstj = -1;
+            if (part < HR_PM)
+            { // lane `part` of the group looks up the column of partner t0 + part
+                const int es = e + 1 + t0 + part;
+                if (act && es < lend && !(ev.flags[es] & NOT_FF))
+                {
+                    const int q = ev.pose[es];
+                    if (q - p < HR_NEAR)
+                        dstj = near[q - p];
+                    else
+                    { // far column (loop closure): binary search in the row's sorted column list
+                        int lo = 0, hi = nnz - 1;
+                        while (lo < hi)
+                        {
+                            const int mid = (lo + hi) >> 1;
+                            if (colind[row0 + mid] < q)
+                                lo = mid + 1;
+                            else
+                                hi = mid;
+                        }
+                        dstj = lo;
+                    }
+                }
+            }
+            // ---- stage
+            if (writer)
+            {
+                double* h0 = sH + (u * HR_SH) * 18 + 2 * part;
+                if (t0 == 0)
+                {
+                    h0[0] = hv.x, h0[1] = hv.y;
+                    sInv[u * 9 + part] = ivv;
+                    if (part < 3)
+                        sBl[u * 3 + part] = blv;
+                    if (part == 0)
+                        sact[u] = act ? 1 : 0;
+                }
+#pragma unroll
+                for (int t = 0; t < HR_PM; t++)
+                    h0[18 * (1 + t)] = pv[t].x, h0[18 * (1 + t) + 1] = pv[t].y;
+                if (part < HR_PM)
+                    sdst[u * HR_PM + part] = dstj;
+            }
+            if (t0 == 0)
+            {
+                wave_sync_lds();
+                if (writer)
+                { // T = Hpl invHll: entries 2 part, 2 part + 1 (the operation order of k_schur_edges)
+                    const double* H = sH + (u * HR_SH) * 18;
+                    const double* iv = sInv + u * 9;
+#pragma unroll
+                    for (int k = 0; k < 2; k++)
+                    {
+                        const int i = 2 * part + k, r = i % 6, c = i / 6;
+                        sT[u * 18 + i] = H[r] * iv[c] + H[6 + r] * iv[3 + c] + H[12 + r] * iv[6 + c];
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- products
+            if (t0 == 0)
+            { // the diagonal block and the rhs: the seven edges of this wave, in edge order
+#pragma unroll
+                for (int k = 0; k < HR_CH; k++)
+                {
+                    const int uu = HR_CH * w + k;
+                    if (sact[uu]) // wave-uniform
+                    {
+                        const double* T = sT + uu * 18;
+                        const double* H = sH + (uu * HR_SH) * 18;
+                        double sd = T[dr] * H[dc];
+                        sd = fma(T[6 + dr], H[6 + dc], sd);
+                        sd = fma(T[12 + dr], H[12 + dc], sd);
+                        dacc += sd;
+                        const double* b3 = sBl + uu * 3;
+                        double sb = T[rb] * b3[0];
+                        sb = fma(T[6 + rb], b3[1], sb);
+                        sb = fma(T[12 + rb], b3[2], sb);
+                        bacc += sb;
+                    }
+                }
+            }
+            { // partner products whose column belongs to this wave (column j -> wave j mod 4)
+                const int d0 = sdst[lane], d1 = lane < HR_E * HR_PM - 64 ? sdst[64 + lane] : -1;
+                unsigned long long m0 = __ballot(d0 >= 0 && (d0 & (HR_W - 1)) == w);
+                unsigned long long m1 = __ballot(d1 >= 0 && (d1 & (HR_W - 1)) == w);
+                while (m0 | m1)
+                {
+                    int i;
+                    if (m0)
+                    {
+                        i = __builtin_ctzll(m0);
+                        m0 &= m0 - 1;
+                    }
+                    else
+                    {
+                        i = 64 + __builtin_ctzll(m1);
+                        m1 &= m1 - 1;
+                    }
+                    const int uu = i / HR_PM, t = i - HR_PM * uu;
+                    const int j = sdst[i];
+                    const double* T = sT + uu * 18;
+                    const double* H = sH + (uu * HR_SH + 1 + t) * 18;
+                    double sp = T[r6] * H[c6];
+                    sp = fma(T[6 + r6], H[6 + c6], sp);
+                    sp = fma(T[12 + r6], H[12 + c6], sp);
+                    if (lane < 36)
+                        acc[36 * j + lane] += sp;
+                }
+            }
+            // more partners than staged so far in any edge of the round?
+            if (!__syncthreads_or(np > t0 + HR_PM))
+                break;
+        }
+    }
+    // ---- finish: diagonal block and rhs in wave order, off-diagonal blocks straight from the accumulators
+    if (lane < 36)
+        dpart[w * 42 + lane] = dacc;
+    else if (lane < 42)
+        dpart[w * 42 + lane] = bacc;
+    __syncthreads();
+    if (tid < 36)
+    {
+        double sum = 0;
+        for (int q = 0; q < HR_W; q++)
+            sum += dpart[q * 42 + tid];
+        double val = Hpp[36 * (size_t)p + tid] - sum;
+        if (tid % 7 == 0)
+            val += lambda_diag;
+        Hsc[36 * (size_t)row0 + tid] = val;
+    }
+    else if (tid < 42)
+    {
+        double sum = 0;
+        for (int q = 0; q < HR_W; q++)
+            sum += dpart[q * 42 + tid];
+        bsc[6 * (size_t)p + (tid - 36)] = bp[6 * (size_t)p + (tid - 36)] - sum;
+    }
+    for (int i = 36 + tid; i < 36 * nnz; i += HR_BS)
+        Hsc[36 * (size_t)row0 + i] = -acc[i];
+}
+
 // ---------------------------------------------------------------- back-substitution ----
 // xl = invHll (bl - sum Hpl^T xp), landmark update, scale partials
 // (ref: schurComplementPostKernel .cu:1419, updateLandmarksKernel .cu:1457,
@@ -1536,7 +1806,7 @@ static void launch_build_t(hipStream_t s, const cugo_edges& e, const double* d_p
     double* d_rec = rs.d_partials + scratch_partials(ev.E, ev.P, ev.L);
     if (nb > 0)
         CUGO_LAUNCH_T(k_build_edges, S, dim3(nb), dim3(BS), 0, s, ev, d_poses, d_lms, r, d_Hpl, d_Hll,
-                      d_bl, d_rec, rs.d_partials, (d_invHll && d_T) ? fuse_lambda : -1.0, d_invHll, d_T);
+                      d_bl, d_rec, rs.d_partials, d_invHll ? fuse_lambda : -1.0, d_invHll, d_T);
     if (d_chi)
         CUGO_LAUNCH(k_sum_partials, dim3(1), dim3(SP_BS), 0, s, rs.d_partials, nb, d_chi);
     if (ev.P > 0)
@@ -1573,7 +1843,7 @@ template <typename S>
 static void launch_schur_t(hipStream_t s, const cugo_edges& e, const cugo_hsc_struct& hs, double lambda,
                            int damp_hsc_diag, const double* d_Hpp, const double* d_bp, const double* d_Hll,
                            const double* d_bl, const S* d_Hpl, double* d_invHll, S* d_T,
-                           double* d_bsc, double* d_Hsc, bool have_T)
+                           double* d_bsc, double* d_Hsc, bool have_T, SchurRows rows)
 {
     const EV ev = make_ev(e);
     if (hs.d_grp_ptr && hs.n_groups == div_up(ev.E, BS))
@@ -1587,6 +1857,30 @@ static void launch_schur_t(hipStream_t s, const cugo_edges& e, const cugo_hsc_st
                         hs.d_red_slot, hs.d_slot_rhs, hs.d_blk_pose, hs.d_part_H, hs.d_part_b,
                         damp_hsc_diag ? lambda : 0.0, d_Hpp, d_bp, d_Hsc, d_bsc);
         return;
+    }
+    if (rows.d_pose_rec && hs.d_rowptr && hs.d_colind)
+    {
+        const size_t lds = (36 * (size_t)std::max(rows.max_row_nnz, 1) + hr_fixed_doubles()) * sizeof(double);
+        if (lds <= 150 * 1024)
+        { // the whole block row of a pose in one workgroup: no T stream, no product lists (k_hsc_rows)
+            if (ev.L > 0 && !have_T)
+                CUGO_LAUNCH(k_inv_hll, dim3(div_up(ev.L, BS)), dim3(BS), 0, s, ev.L, lambda, d_Hll, d_invHll);
+            if (ev.P > 0)
+            {
+                static bool attr_set[2] = {false, false};
+                if (!attr_set[sizeof(S) == 4])
+                {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_hsc_rows<S>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+                    attr_set[sizeof(S) == 4] = true;
+                }
+                CUGO_LAUNCH_T(k_hsc_rows, S, dim3(xcd_grid(ev.P)), dim3(HR_BS), lds, s, ev,
+                              reinterpret_cast<const int4*>(rows.d_pose_rec), hs.d_rowptr, hs.d_colind,
+                              damp_hsc_diag ? lambda : 0.0, d_Hpp, d_bp, d_bl, (const double*)d_invHll, d_Hpl, d_Hsc,
+                              d_bsc, std::max(rows.max_row_nnz, 1));
+            }
+            return;
+        }
     }
     if (ev.E > 0 && !have_T) // have_T: the build pass left invHll and T for this lambda (launch_build)
         CUGO_LAUNCH_T(k_schur_edges, S, dim3(div_up(ev.E, BS)), dim3(BS), 0, s, ev, lambda, d_Hll,
@@ -1603,14 +1897,21 @@ static void launch_schur_t(hipStream_t s, const cugo_edges& e, const cugo_hsc_st
 void launch_schur(hipStream_t s, const cugo_edges& e, const cugo_hsc_struct& hs, double lambda,
                   int damp_hsc_diag, const double* d_Hpp, const double* d_bp, const double* d_Hll,
                   const double* d_bl, const void* d_Hpl, double* d_invHll, void* d_T,
-                  double* d_bsc, double* d_Hsc, bool have_T)
+                  double* d_bsc, double* d_Hsc, bool have_T, SchurRows rows)
 {
     if (e.block_f32)
         launch_schur_t(s, e, hs, lambda, damp_hsc_diag, d_Hpp, d_bp, d_Hll, d_bl,
-                       static_cast<const float*>(d_Hpl), d_invHll, static_cast<float*>(d_T), d_bsc, d_Hsc, have_T);
+                       static_cast<const float*>(d_Hpl), d_invHll, static_cast<float*>(d_T), d_bsc, d_Hsc, have_T, rows);
     else
         launch_schur_t(s, e, hs, lambda, damp_hsc_diag, d_Hpp, d_bp, d_Hll, d_bl,
-                       static_cast<const double*>(d_Hpl), d_invHll, static_cast<double*>(d_T), d_bsc, d_Hsc, have_T);
+                       static_cast<const double*>(d_Hpl), d_invHll, static_cast<double*>(d_T), d_bsc, d_Hsc, have_T, rows);
+}
+
+void launch_pose_rec(hipStream_t s, const cugo_edges& e, int n, int32_t* d_rec)
+{
+    const EV ev = make_ev(e);
+    if (n > 0)
+        CUGO_LAUNCH(k_pose_rec, dim3(div_up(n, BS)), dim3(BS), 0, s, ev, n, reinterpret_cast<int4*>(d_rec));
 }
 
 template <typename S>

@@ -681,9 +681,8 @@ namespace p16
 {
 constexpr int OFF_INV = NC_MAX * LLD;     // reciprocal pivots 1/d            [96]
 constexpr int OFF_RS = OFF_INV + NC_MAX;  // d^-1/2                            [96]
-constexpr int OFF_VS = OFF_RS + NC_MAX;   // V_J = L_JJ^-1, [i*17 + c]         [6][272]
-constexpr int OFF_UB = OFF_VS + 6 * 272;  // off-diagonal blocks of U = L^-1, block (I,J) at I(I-1)/2 + J, [k*16 + n]
-constexpr int LDS_DOUBLES = OFF_UB + 15 * 256;
+constexpr int OFF_UB = OFF_RS + NC_MAX;   // blocks of U = L^-1 (unit lower), block (I,J), J <= I, at I(I+1)/2 + J, [k*16 + n]
+constexpr int LDS_DOUBLES = OFF_UB + 21 * 256;
 } // namespace p16
 
 __device__ __forceinline__ double readlane_f64(double x, int lane)
@@ -691,6 +690,16 @@ __device__ __forceinline__ double readlane_f64(double x, int lane)
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
     return __hiloint2double(hi, lo);
+}
+
+// the lane index behind an optimisation barrier: the address arithmetic of a role (panel / tile / U block)
+// is then redone where it is used instead of being hoisted out of the slot loop, where the hoisted
+// values of ALL roles stay live side by side and push the kernel over its 128 VGPRs (scratch spills)
+__device__ __forceinline__ int opaque_lane()
+{
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
+    return lane;
 }
 
 __device__ __forceinline__ void stamp_wave(int kernel, int slot)
@@ -708,16 +717,25 @@ __device__ __forceinline__ void stamp_wave(int kernel, int slot)
 __device__ __forceinline__ void panel16_factor(double* __restrict__ Ls, int ncp, int j0, double* __restrict__ invd,
                                                int half)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = opaque_lane();
     const int rr = half == 0 ? lane : (lane < 16 ? lane : lane + 48); // row inside the panel
     // rows past the matrix are clamped into the 16 padding rows below it for the loads (valid LDS,
     // values unused: nothing is ever broadcast from these lanes) and stored into those rows
     const int rrc = min(rr, NC_MAX + 15 - j0);
     const double* Pc = Ls + j0 * LLD + j0 + rrc;
+    if (j0 == 32 && half == 0)
+        stamp(2, 0);
     double a[16];
 #pragma unroll
     for (int c = 0; c < 16; c++)
         a[c] = Pc[c * LLD]; // (rows of the diagonal block: its tile is symmetric in LDS)
+    if (j0 == 32 && half == 0)
+    {
+        asm volatile("" ::"v"(a[15]), "v"(a[0]), "v"(a[7]));
+        stamp(2, 1);
+    }
+    const bool st = (half == 0 || lane >= 16) && j0 + rr < ncp;
+    double* W0 = Ls + j0 * LLD + (st ? j0 + rr : NC_MAX + (lane & 15));
     double iv[16];
 #pragma unroll
     for (int k = 0; k < 16; k++)
@@ -733,6 +751,10 @@ __device__ __forceinline__ void panel16_factor(double* __restrict__ Ls, int ncp,
 #pragma unroll
         for (int j = k + 1; j < 16; j++)
             sk[j] = readlane_f64(a[j], k);
+        // column k is final (unscaled: l_ik d_k; the diagonal entry is d_k): it leaves for LDS now, so that
+        // at the end of the panel only the last store is still in flight (16 stores issued together at the
+        // end wait ~1000 cycles in the LDS queue behind the other waves' traffic)
+        W0[k * LLD] = a[k];
         __builtin_amdgcn_sched_barrier(0);
         double e = fma(-d, y, 1.0);
         y = fma(y, e, y);
@@ -745,12 +767,10 @@ __device__ __forceinline__ void panel16_factor(double* __restrict__ Ls, int ncp,
             a[j] = fma(-t, sk[j], a[j]);
         __builtin_amdgcn_sched_barrier(0);
     }
+    if (j0 == 32 && half == 0)
     {
-        const bool st = (half == 0 || lane >= 16) && j0 + rr < ncp;
-        double* W0 = Ls + j0 * LLD + (st ? j0 + rr : NC_MAX + (lane & 15));
-#pragma unroll
-        for (int c = 0; c < 16; c++)
-            W0[c * LLD] = a[c];
+        asm volatile("" ::"v"(a[15]), "v"(a[0]), "v"(a[7]));
+        stamp(2, 2);
     }
     if (half == 0 && lane == 0)
     {
@@ -759,6 +779,8 @@ __device__ __forceinline__ void panel16_factor(double* __restrict__ Ls, int ncp,
         for (int k = 0; k < 16; k++)
             dv[k] = iv[k];
     }
+    if (j0 == 32 && half == 0)
+        stamp(2, 3);
 }
 
 // trailing tile (rows R.., columns C..) -= L_R D L_C^T, from the factored 16-column panel at j0 (stored
@@ -766,7 +788,7 @@ __device__ __forceinline__ void panel16_factor(double* __restrict__ Ls, int ncp,
 __device__ __forceinline__ void panel16_update_tile(double* __restrict__ Ls, const double* __restrict__ invd, int j0,
                                                     int R, int C)
 {
-    const int lane = threadIdx.x & 63, ln = lane & 15, lk = lane >> 4;
+    const int lane = opaque_lane(), ln = lane & 15, lk = lane >> 4;
     const double* Pk = Ls + (j0 + lk) * LLD;
     double a[4], b[4], y[4];
 #pragma unroll
@@ -787,116 +809,124 @@ __device__ __forceinline__ void panel16_update_tile(double* __restrict__ Ls, con
         Cc[4 * q] = c[q] - (s0[q] + s1[q]);
 }
 
-// One wave: pivots of diagonal block `blk` checked (zero-pivot flag), d^-1/2 formed, V = L_JJ^-1 (unit
-// lower; l_ik = Ls[k][i] / d_k) by four lanes per column, W_JJ = D^-1/2 V stored to global memory.
+// x := L^-1 x for the unit lower 16 x 16 block at Lb (Lb already offset by r4; l_ik = Lb[k*LLD + 4m] / d_k,
+// yv = 1/d), quad layout (see p16_utask).  Step K: rows below K take  x_i -= l_iK x_K.
 template <int K>
-__device__ __forceinline__ void p16_vstep(const double* __restrict__ Lb, const double* __restrict__ yv, int r4,
-                                          double (&v)[4])
+__device__ __forceinline__ void p16_sub_step(const double* __restrict__ Lb, int r4, const double (&c)[4], double yk,
+                                             double (&x)[4], double (&cn)[4], double& yn, const double* __restrict__ yv)
 {
     constexpr int ko = K & 3, km = K >> 2;
-    // row K of this column is final (unit diagonal); scaled by 1/d_K once for all the rows below
-    const double vk = quad_bcast<ko>(v[km]) * yv[K];
+    // the coefficients of the NEXT step first: their latency hides behind this step's chain
+    if (K + 1 < 15)
+    {
+        constexpr int kmn = (K + 1) >> 2;
+#pragma unroll
+        for (int m = kmn; m < 4; m++)
+            cn[m] = Lb[(K + 1) * LLD + 4 * m];
+        yn = yv[K + 1];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const double xk = quad_bcast<ko>(x[km]) * yk;
 #pragma unroll
     for (int m = km; m < 4; m++)
-    {
-        // rows below K only: for m == km that is r4 > ko (clamped address, zero coefficient otherwise)
-        const double l = Lb[K * LLD + r4 + 4 * m];
-        const double coef = (m > km || r4 > ko) ? l : 0.0;
-        v[m] -= coef * vk;
+    { // rows below K only: for m == km that is r4 > ko
+        const double coef = (m > km || r4 > ko) ? c[m] : 0.0;
+        x[m] = fma(-coef, xk, x[m]);
     }
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void p16_substitute(const double* __restrict__ Lb, const double* __restrict__ yv, int r4,
+                                               double (&x)[4])
+{
+    double c[4], cn[4] = {0, 0, 0, 0}, yk = yv[0], yn = 0.0;
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+        c[m] = Lb[4 * m];
+#define P16_STEP(K)                                   \
+    p16_sub_step<K>(Lb, r4, c, yk, x, cn, yn, yv);    \
+    c[0] = cn[0], c[1] = cn[1], c[2] = cn[2], c[3] = cn[3], yk = yn;
+    P16_STEP(0) P16_STEP(1) P16_STEP(2) P16_STEP(3) P16_STEP(4) P16_STEP(5) P16_STEP(6) P16_STEP(7)
+    P16_STEP(8) P16_STEP(9) P16_STEP(10) P16_STEP(11) P16_STEP(12) P16_STEP(13) P16_STEP(14)
+#undef P16_STEP
 }
 
-__device__ __forceinline__ void p16_vblock(const double* __restrict__ Ls, const double* __restrict__ invd,
-                                           double* __restrict__ rsv, double* __restrict__ Vs, int blk,
-                                           double* __restrict__ Wg, int ncp, int32_t* __restrict__ fail)
+// One wave: block (I, J), J <= I, of U = L^-1 (unit lower):  L_II U_IJ = -sum_{K=J..I-1} L_IK U_KJ  (J < I),
+// L_II U_II = I.  The sum runs on the matrix cores (four independent accumulators: a chain of I - J MFMAs),
+// goes through the block's LDS slot into the substitution layout, and the 16 x 16 unit lower triangular
+// solve is a forward substitution in registers (p16_substitute): no explicit inverse of the diagonal block,
+// no dependent MFMA chain behind it.  The block is parked in LDS for the rows below and stored to global
+// memory as W_IJ = D_I^-1/2 U_IJ.  The task of the diagonal block also checks the pivots of block row I
+// (zero-pivot flag; ref: csrcholZeroPivot tol).
+// (Measured alternatives, all within 0.15 ms of each other per 10-iteration step: an explicit inverse V_I by
+// one wave and U_IJ = -V_I S one slot later; the sums kept right-looking, each term added by the task that
+// formed U_KJ, or by the idle waves of the next phase A — every form moves the same work between waves of
+// ONE CU that share its LDS pipe and issue slots.)
+__device__ __forceinline__ void p16_utask(const double* __restrict__ Ls, const double* __restrict__ invd,
+                                          double* __restrict__ rsv, double* __restrict__ Ub, int I, int J,
+                                          double* __restrict__ Wg, int ncp, int32_t* __restrict__ fail)
 {
-    const int lane = threadIdx.x & 63, r4 = lane & 3, c = lane >> 2;
-    const double* Lb = Ls + (16 * blk) * LLD + 16 * blk;
+    const int lane = opaque_lane(), ln = lane & 15, lk = lane >> 4;
+    double* slot = Ub + (I * (I + 1) / 2 + J) * 256;
+    if (J < I)
     {
-        const int l = lane & 15;
-        const double d = Lb[l * LLD + l];
-        const bool bad = !(d > PIVOT_TOL); // ref: csrcholZeroPivot tol (a NaN pivot counts)
+        double4_t s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0}, s2 = {0, 0, 0, 0}, s3 = {0, 0, 0, 0};
+        for (int K = J; K < I; K++)
+        {
+            // A = L_IK [m = ln][k = lk + 4kk] = Ls[col 16K + k][row 16I + m] / d_k ;  B = U_KJ [k][n = ln]
+            const double* La = Ls + (16 * K + lk) * LLD + 16 * I + ln;
+            const double* Bb = Ub + (K * (K + 1) / 2 + J) * 256 + lk * 16 + ln;
+            double a[4], b[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++)
+                a[kk] = La[4 * kk * LLD] * invd[16 * K + lk + 4 * kk], b[kk] = Bb[64 * kk];
+            s0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], s1, 0, 0, 0);
+            s2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b[2], s2, 0, 0, 0);
+            s3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b[3], s3, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) // result element [m = lk + 4q][n = ln]
+            slot[(lk + 4 * q) * 16 + ln] = -((s0[q] + s1[q]) + (s2[q] + s3[q]));
+    }
+    else
+    { // the diagonal block: right-hand side = identity (through the slot as well: one code path below)
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            slot[(lk + 4 * q) * 16 + ln] = (lk + 4 * q == ln) ? 1.0 : 0.0;
+    }
+    wave_lds_sync();
+    // forward substitution, four lanes per column: lane = 4 n + r4 holds rows r4 + 4m of column n.  The one
+    // value a step shares — the finished entry x_k — goes round the quad by DPP (no LDS); a lane needs
+    // <= 4 coefficients per step, loaded one step ahead (broadcast reads: they depend on r4 only)
+    const int n = lane >> 2, r4 = lane & 3;
+    double x[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+        x[m] = slot[(r4 + 4 * m) * 16 + n];
+    const double* Lb = Ls + (16 * I) * LLD + 16 * I + r4;
+    const double* yv = invd + 16 * I;
+    {
+        // d^-1/2 of block row I (lane k forms entry k; every task of the row writes the same values)
+        const double d = Ls[(16 * I + ln) * LLD + 16 * I + ln];
         const double y = __builtin_amdgcn_rsq(d);
         double g = d * y, h = 0.5 * y;
         const double r0 = fma(-h, g, 0.5);
         const double h2 = fma(y, r0, y);
         g = fma(g, r0, g), h = fma(h, r0, h);
         const double rh = fma(-h, g, 0.5);
-        const double rs = fma(h2, rh, h2);
         if (lane < 16)
-            rsv[16 * blk + l] = rs;
-        if (__ballot(bad) != 0 && lane == 0)
+            rsv[16 * I + ln] = fma(h2, rh, h2);
+        if (J == I && __ballot(!(d > PIVOT_TOL)) != 0 && lane == 0) // (a NaN pivot counts)
             *fail = 1;
     }
-    const double* yv = invd + 16 * blk;
-    double v[4];
-#pragma unroll
-    for (int m = 0; m < 4; m++)
-        v[m] = (r4 + 4 * m == c) ? 1.0 : 0.0;
-    p16_vstep<0>(Lb, yv, r4, v), p16_vstep<1>(Lb, yv, r4, v), p16_vstep<2>(Lb, yv, r4, v), p16_vstep<3>(Lb, yv, r4, v);
-    p16_vstep<4>(Lb, yv, r4, v), p16_vstep<5>(Lb, yv, r4, v), p16_vstep<6>(Lb, yv, r4, v), p16_vstep<7>(Lb, yv, r4, v);
-    p16_vstep<8>(Lb, yv, r4, v), p16_vstep<9>(Lb, yv, r4, v), p16_vstep<10>(Lb, yv, r4, v), p16_vstep<11>(Lb, yv, r4, v);
-    p16_vstep<12>(Lb, yv, r4, v), p16_vstep<13>(Lb, yv, r4, v), p16_vstep<14>(Lb, yv, r4, v);
-    wave_lds_sync(); // rsv of this block (written above by lanes 0..15) is read below
-    double* V = Vs + blk * 272;
-    double* wc = Wg + (long)(16 * blk + c) * ncp + 16 * blk;
+    p16_substitute(Lb, yv, r4, x);
+    wave_lds_sync(); // rsv (and the slot: every lane has read its entries)
+    double* wg = Wg + (long)(16 * J + n) * ncp + 16 * I + r4;
 #pragma unroll
     for (int m = 0; m < 4; m++)
     {
-        const int i = r4 + 4 * m;
-        const double x = (i >= c) ? v[m] : 0.0;
-        V[i * 17 + c] = x;
-        wc[i] = x * rsv[16 * blk + i];
-    }
-}
-
-// One wave: block (I, J), I > J, of U = L^-1:  U_IJ = -V_I sum_{K=J..I-1} L_IK U_KJ  on the matrix cores
-// (the MFMA result layout is the B-operand layout of the next product: the sum never leaves registers),
-// parked in LDS for the rows below and stored to global memory as W_IJ = D_I^-1/2 U_IJ.
-__device__ __forceinline__ void p16_ublock(const double* __restrict__ Ls, const double* __restrict__ invd,
-                                           const double* __restrict__ rsv, const double* __restrict__ Vs,
-                                           double* __restrict__ Ub, int I, int J, bool park, double* __restrict__ Wg,
-                                           int ncp)
-{
-    const int lane = threadIdx.x & 63, ln = lane & 15, lk = lane >> 4;
-    double4_t s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
-    for (int K = J; K < I; K++)
-    {
-        // A = L_IK [m = ln][k = lk + 4kk] = Ls[col 16K + k][row 16I + m] / d_k ;  B = U_KJ [k][n = ln]
-        const double* La = Ls + (16 * K + lk) * LLD + 16 * I + ln;
-        const double* Bb = K == J ? Vs + J * 272 + lk * 17 + ln : Ub + (K * (K - 1) / 2 + J) * 256 + lk * 16 + ln;
-        const int bs = K == J ? 4 * 17 : 4 * 16;
-        double a[4], b[4];
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++)
-            a[kk] = La[4 * kk * LLD] * invd[16 * K + lk + 4 * kk], b[kk] = Bb[kk * bs];
-        s0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], b[0], s0, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], b[1], s1, 0, 0, 0);
-        s0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], b[2], s0, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], b[3], s1, 0, 0, 0);
-    }
-    double4_t S;
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-        S[q] = s0[q] + s1[q];
-    double v[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; kk++)
-        v[kk] = Vs[I * 272 + ln * 17 + lk + 4 * kk];
-    double4_t u0 = {0, 0, 0, 0}, u1 = {0, 0, 0, 0};
-    u0 = __builtin_amdgcn_mfma_f64_16x16x4f64(v[0], S[0], u0, 0, 0, 0);
-    u1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v[1], S[1], u1, 0, 0, 0);
-    u0 = __builtin_amdgcn_mfma_f64_16x16x4f64(v[2], S[2], u0, 0, 0, 0);
-    u1 = __builtin_amdgcn_mfma_f64_16x16x4f64(v[3], S[3], u1, 0, 0, 0);
-    double* ub = Ub + (I * (I - 1) / 2 + J) * 256 + lk * 16 + ln;
-    double* wg = Wg + (long)(16 * J + ln) * ncp + 16 * I + lk;
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-    {
-        const double u = -(u0[q] + u1[q]);
-        if (park) // (uniform) the last block row is not needed again
-            ub[64 * q] = u;
-        wg[4 * q] = u * rsv[16 * I + lk + 4 * q];
+        slot[(r4 + 4 * m) * 16 + n] = x[m];
+        wg[4 * m] = x[m] * rsv[16 * I + r4 + 4 * m];
     }
 }
 
@@ -908,7 +938,6 @@ __device__ __forceinline__ void dev_potrf16(int ncp, double* __restrict__ lds, d
     double* Ls = lds;
     double* invd = lds + p16::OFF_INV;
     double* rsv = lds + p16::OFF_RS;
-    double* Vs = lds + p16::OFF_VS;
     double* Ub = lds + p16::OFF_UB;
     const int nblk = ncp >> 4;
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -927,9 +956,8 @@ __device__ __forceinline__ void dev_potrf16(int ncp, double* __restrict__ lds, d
     __syncthreads();
     stamp(0, 3);
     // slot s: [phase A: block column s+1 updated by panel s] [phase B: panel s+1 factored || the other
-    // block columns updated by panel s || V_s || block row s-1 of U]; the last two slots have no panel
-    const int nslots = nblk > 1 ? nblk + 1 : 1;
-    for (int s = 0; s < nslots; s++)
+    // block columns updated by panel s || block row s of U]; the last slot has no panel
+    for (int s = 0; s < nblk; s++)
     {
         const int j0 = 16 * s, jn = j0 + 16;
         const bool panel = s + 1 < nblk;
@@ -937,42 +965,47 @@ __device__ __forceinline__ void dev_potrf16(int ncp, double* __restrict__ lds, d
             stamp(5, 0);
         if (panel)
         {
-            for (int I = s + 1 + w; I < nblk; I += 16)
-                panel16_update_tile(Ls, invd, j0, 16 * I, jn);
+            // phase A: the block column of the next panel, <= 5 tiles, one per wave, on waves 0 1 2 3 6 (four
+            // different SIMDs first)
+            const int ta = w < 4 ? w : (w == 6 ? 4 : 99);
+            if (s + 1 + ta < nblk)
+                panel16_update_tile(Ls, invd, j0, 16 * (s + 1 + ta), jn);
             __syncthreads();
         }
         if (s == 1)
             stamp(5, 1);
         if (w < 2)
         {
+            // the panel wave is the critical path of the slot: it goes first wherever it competes with the
+            // other waves of the CU (after the barrier every wave issues its LDS operand loads at once; at
+            // equal priority the panel's 16 loads — and later its stores — queue behind ~200 others)
+            __builtin_amdgcn_s_setprio(3);
             if (panel && (w == 0 || ncp - jn > 64))
                 panel16_factor(Ls, ncp, jn, invd, w);
+            __builtin_amdgcn_s_setprio(0);
             if (s == 1)
                 stamp(5, 2);
         }
         else
         {
-            // one task per wave: V_s, the blocks of row s-1 of U, the remaining trailing tiles
-            const int r = s - 1;
-            const int nv = s < nblk ? 1 : 0, nu = (r >= 1 && r < nblk) ? r : 0;
-            int t = w - 2;
-            if (t < nv)
+            // one task per wave: the s + 1 blocks of row s of U, then the remaining trailing tiles.
+            // Waves w and w + 4 share a SIMD (observed placement; speed only): the tasks go first to the
+            // waves that do not sit beside a panel wave (2, 3 mod 4), the heavy ones (U blocks) first
+            const int tw = (w & 3) >= 2 ? (w >> 2) * 2 + (w & 1) : ((w & 3) == 1 ? 8 + (w >> 2) - 1 : 11 + (w >> 2) - 1);
+            int t = tw;
+            if (t <= s)
             {
-                p16_vblock(Ls, invd, rsv, Vs, s, Wg, ncp, fail);
-                if (s == 1)
+                p16_utask(Ls, invd, rsv, Ub, s, t, Wg, ncp, fail);
+                if (s == 1 && t == 0)
                     stamp_wave(5, 4);
-            }
-            else if (t < nv + nu)
-            {
-                p16_ublock(Ls, invd, rsv, Vs, Ub, r, t - nv, r + 1 < nblk, Wg, ncp);
-                if (s == 3)
+                if (s == 4 && t == 0)
                     stamp_wave(5, 5);
             }
             else if (s + 2 < nblk)
             {
                 const int nt = nblk - (s + 2); // block columns still to update
                 const int ntiles = nt * (nt + 1) / 2;
-                for (t -= nv + nu; t < ntiles; t += 14 - nv - nu)
+                for (t -= s + 1; t < ntiles; t += 13 - s)
                 {
                     int tj = 0, rem = t;
                     while (rem >= nt - tj)
@@ -989,9 +1022,8 @@ __device__ __forceinline__ void dev_potrf16(int ncp, double* __restrict__ lds, d
             stamp(5, 3);
         if (s == nblk - 2)
             stamp(0, 4);
-        if (s == nblk - 1)
-            stamp(0, 5);
     }
+    stamp(0, 5);
 }
 
 // V = inverse of the 16x16 diagonal block `blk` of L11 (lower triangular) by 16 lanes: lane c

@@ -66,10 +66,20 @@ void launch_build(hipStream_t s, const cugo_edges& ev, const double* d_poses, co
 void launch_max_diagonal(hipStream_t s, const double* d_Hpp, int nP, const double* d_Hll, int nL,
                          ReduceScratch rs, double* d_out);
 
+// SchurRows (optional): the per-entry records of the pose-major edge list (launch_pose_rec) and the longest
+// block row of Hsc.  Given, the H-side and b-side of the Schur complement run as ONE kernel that forms the
+// whole block row of a pose (k_hsc_rows): T = Hpl invHll is never written or read (d_T may be NULL) and the
+// product lists of hs are not used; have_T then means "d_invHll already holds (Hll + lambda I)^-1".
+struct SchurRows
+{
+    const int32_t* d_pose_rec = nullptr; // [n][4]: slot, end of its landmark's slots, landmark, flags
+    int max_row_nnz = 0;
+};
+void launch_pose_rec(hipStream_t s, const cugo_edges& ev, int n, int32_t* d_rec);
 void launch_schur(hipStream_t s, const cugo_edges& ev, const cugo_hsc_struct& hs, double lambda,
                   int damp_hsc_diag, const double* d_Hpp, const double* d_bp, const double* d_Hll,
                   const double* d_bl, const void* d_Hpl, double* d_invHll, void* d_T,
-                  double* d_bsc, double* d_Hsc, bool have_T = false);
+                  double* d_bsc, double* d_Hsc, bool have_T = false, SchurRows rows = SchurRows());
 
 // lambda_pose: damping used in the pose part of the scale sum (0 on ranks > 0 of a sharded run
 // so that the all-reduced scale counts lambda*|xp|^2 once)

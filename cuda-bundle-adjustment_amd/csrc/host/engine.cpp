@@ -96,6 +96,9 @@ struct Engine::Impl : cugo_k::LaunchHook
     std::vector<int32_t> hsc_rowptr, hsc_colind;
 
     DevBuf<int32_t> d_e_pose, d_e_lm, d_lm_ptr, d_pose_ptr, d_pose_edge;
+    DevBuf<int32_t> d_pose_rec; // [n][4] per entry of the pose-major list: slot, end of its landmark, landmark, flags (k_hsc_rows)
+    bool rows_on = false;       // the Schur complement by block rows (k_hsc_rows; CUGO_HSC_ROWS=0: the gather kernels)
+    int max_row_nnz = 0;
     DevBuf<double> d_meas, d_omega, d_cams;
     DevBuf<uint8_t> d_flags;
     DevBuf<uint16_t> d_cam;
@@ -684,6 +687,20 @@ void Engine::initialize(FlatGraph& g)
     ev.d_cam = m.n_cams > 1 ? m.d_cam.data() : nullptr, ev.d_cams = m.d_cams.data();
     ev.n_cams = m.n_cams, ev.d_lm_ptr = m.d_lm_ptr.data(), ev.d_pose_ptr = m.d_pose_ptr.data();
     ev.d_pose_edge = m.d_pose_edge.data();
+    {
+        // opt-in (CUGO_HSC_ROWS=1): the Schur complement by whole block rows (k_hsc_rows).  Correct and
+        // list-free, but measured slower than the gather pair (355 vs 152 us per Schur complement on the
+        // kitti_00 shape): its per-product accumulation into LDS is a chain of dependent LDS round trips
+        // 
+        const char* env = std::getenv("CUGO_HSC_ROWS");
+        m.rows_on = !m.plan_only && env && env[0] == '1' && !std::getenv("CUGO_SCHUR_PLAN");
+        if (m.rows_on)
+        {
+            const int n = m.h_pose_ptr[m.Pall];
+            m.d_pose_rec.resize(4 * (size_t)std::max(n, 1) + 16);
+            cugo_k::launch_pose_rec(s, ev, n, m.d_pose_rec.data());
+        }
+    }
     // Re-use of the Hsc structure, ordering and symbolic factor across optimize() calls when
     // the topology is unchanged (ref: the isDirty logic of BlockSolver::buildStructure,
     // block_solver.cpp:151-216, which skips the rebuild for clean edge sets).  Decided by a
@@ -749,6 +766,9 @@ void Engine::fill_structure_stats(int B, double products, double offdiag_product
     // remember what this structure was built from (Engine::initialize compares on a hash hit)
     std::memcpy(m.sig_dims, m.pending_dims, sizeof m.sig_dims);
     m.sig_e_pose = m.h_e_pose, m.sig_e_lm = m.h_e_lm, m.sig_flags = m.h_flags, m.sig_cov_pose = m.cov_pose;
+    m.max_row_nnz = 0;
+    for (size_t q = 0; q + 1 < m.hsc_rowptr.size(); q++)
+        m.max_row_nnz = std::max(m.max_row_nnz, (int)(m.hsc_rowptr[q + 1] - m.hsc_rowptr[q]));
     sstats_.hsc_blocks = B;
     sstats_.products = products;
     sstats_.offdiag_products = offdiag_products;
@@ -1078,7 +1098,8 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
         // in LDS).  From the second iteration on the damping of the first trial is known when the build
         // is queued, and the build pass leaves invHll and T for it: that trial's Schur complement then
         // does not read the Hpl stream a second time (CUGO_FUSE_T=0: always the separate edge kernel).
-        if (!m.splan_on && m.d_T.size() == 0)
+        const bool use_rows = m.rows_on && cugo_k::schur_rows_usable(m.hs, m.max_row_nnz);
+        if (!m.splan_on && !use_rows && m.d_T.size() == 0)
             m.d_T.resize((m.ev.block_f32 ? 9 : 18) * (size_t)m.E + 16);
         const char* fuse_env = std::getenv("CUGO_FUSE_T");
         const bool fuse_allowed = !(fuse_env && fuse_env[0] == '0');
@@ -1088,7 +1109,8 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
             cugo_k::launch_build(s, m.ev, m.d_poses[m.cur].data(), m.d_lms[m.cur].data(), m.rk,
                                  m.d_Hpp.data(), m.bp(), m.d_Hll.data(), m.bl(), m.d_Hpl.data(),
                                  m.rs(), iteration == 0 ? m.d_scal.data() : nullptr, fused_T ? lambda : -1.0,
-                                 fused_T ? m.d_invHll.data() : nullptr, fused_T ? m.d_T.data() : nullptr);
+                                 fused_T ? m.d_invHll.data() : nullptr,
+                                 fused_T && !use_rows ? m.d_T.data() : nullptr);
         });
         sync_prof(PROF_BUILD_SYSTEM, tb);
         if (iteration == 0)
@@ -1129,7 +1151,8 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
             m.timed("schur", [&] {
                 cugo_k::launch_schur(s, m.ev, m.hs, lambda, 0, m.d_Hpp.data(), m.bp(),
                                      m.d_Hll.data(), m.bl(), m.d_Hpl.data(), m.d_invHll.data(),
-                                     m.splan_on ? nullptr : m.d_T.data(), m.bsc(), m.Hsc(), fused_T && q == 0);
+                                     m.splan_on || use_rows ? nullptr : m.d_T.data(), m.bsc(), m.Hsc(), fused_T && q == 0,
+                                     use_rows ? cugo_k::SchurRows{m.d_pose_rec.data(), m.max_row_nnz} : cugo_k::SchurRows());
             });
             if (sharded)
                 m.exchange(m.d_sys.data(), 36 * (size_t)m.hs.n_blocks + 6 * (size_t)m.P, 0);
@@ -1254,6 +1277,8 @@ std::vector<int32_t> Engine::reject_outliers()
         for (int i : slots)
             m.h_flags[i] |= CUGO_EDGE_INACTIVE;
         m.d_flags.upload(m.h_flags, s);
+        if (m.rows_on) // the records of the pose-major list carry the flags
+            cugo_k::launch_pose_rec(s, m.ev, m.h_pose_ptr[m.Pall], m.d_pose_rec.data());
         CUGO_HIP(hipStreamSynchronize(s));
         m.structure_dirty = true;
         E_global_ -= (int)out.size();

@@ -1340,6 +1340,14 @@ constexpr int HR_SH = 1 + HR_PM;    // blocks staged per edge: its own + partner
 // doubles of dynamic LDS besides the nnz_cap x 36 accumulators
 constexpr int hr_fixed_doubles() { return HR_E * 18 + HR_E * HR_SH * 18 + HR_E * 9 + HR_E * 3 + HR_W * 42 + HR_NEAR / 4 + HR_E * HR_PM / 2 + HR_E / 2 + 8; }
 
+} // namespace
+namespace cugo_k
+{
+bool schur_rows_usable(const cugo_hsc_struct& hs, int max_row_nnz);
+}
+namespace
+{
+using cugo_k::schur_rows_usable;
 // per entry of the pose-major edge list: {slot, end of its landmark's slots, landmark, flags}
 __global__ __launch_bounds__(BS) void k_pose_rec(EV ev, int n, int4* __restrict__ rec)
 {
@@ -1858,10 +1866,9 @@ static void launch_schur_t(hipStream_t s, const cugo_edges& e, const cugo_hsc_st
                         damp_hsc_diag ? lambda : 0.0, d_Hpp, d_bp, d_Hsc, d_bsc);
         return;
     }
-    if (rows.d_pose_rec && hs.d_rowptr && hs.d_colind)
+    if (rows.d_pose_rec && schur_rows_usable(hs, rows.max_row_nnz))
     {
         const size_t lds = (36 * (size_t)std::max(rows.max_row_nnz, 1) + hr_fixed_doubles()) * sizeof(double);
-        if (lds <= 150 * 1024)
         { // the whole block row of a pose in one workgroup: no T stream, no product lists (k_hsc_rows)
             if (ev.L > 0 && !have_T)
                 CUGO_LAUNCH(k_inv_hll, dim3(div_up(ev.L, BS)), dim3(BS), 0, s, ev.L, lambda, d_Hll, d_invHll);
@@ -1905,6 +1912,12 @@ void launch_schur(hipStream_t s, const cugo_edges& e, const cugo_hsc_struct& hs,
     else
         launch_schur_t(s, e, hs, lambda, damp_hsc_diag, d_Hpp, d_bp, d_Hll, d_bl,
                        static_cast<const double*>(d_Hpl), d_invHll, static_cast<double*>(d_T), d_bsc, d_Hsc, have_T, rows);
+}
+
+bool schur_rows_usable(const cugo_hsc_struct& hs, int max_row_nnz)
+{
+    const size_t lds = (36 * (size_t)std::max(max_row_nnz, 1) + hr_fixed_doubles()) * sizeof(double);
+    return hs.d_rowptr && hs.d_colind && lds <= 150 * 1024;
 }
 
 void launch_pose_rec(hipStream_t s, const cugo_edges& e, int n, int32_t* d_rec)

@@ -76,6 +76,9 @@ struct SchurRows
     int max_row_nnz = 0;
 };
 void launch_pose_rec(hipStream_t s, const cugo_edges& ev, int n, int32_t* d_rec);
+// false: the row kernel cannot take this structure (no pattern on the device, or a block row too long for
+// its LDS accumulators): launch_schur then runs the gather kernels, which need d_T
+bool schur_rows_usable(const cugo_hsc_struct& hs, int max_row_nnz);
 void launch_schur(hipStream_t s, const cugo_edges& ev, const cugo_hsc_struct& hs, double lambda,
                   int damp_hsc_diag, const double* d_Hpp, const double* d_bp, const double* d_Hll,
                   const double* d_bl, const void* d_Hpl, double* d_invHll, void* d_T,

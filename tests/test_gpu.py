@@ -398,9 +398,13 @@ def rmse(a, b):
     return float(np.sqrt(np.mean((a - b) ** 2)))
 
 
-@pytest.mark.parametrize("subtree_stage", [False, True, "lookahead", "two_phase"])
+@pytest.mark.parametrize("subtree_stage", [False, True, "lookahead", "two_phase", "hsc_rows", "potrf6"])
 def test_medium_synthetic_vs_oracle(oracle_lib, subtree_stage, monkeypatch):
-    if subtree_stage == "lookahead":  # the opt-in Cholesky schedule, end to end
+    if subtree_stage == "hsc_rows":  # the opt-in Schur complement by whole block rows (k_hsc_rows)
+        monkeypatch.setenv("CUGO_HSC_ROWS", "1")
+    elif subtree_stage == "potrf6":  # the 6-column LDS panels of rounds 1-2 instead of the register panels
+        monkeypatch.setenv("CUGO_PANEL16", "0")
+    elif subtree_stage == "lookahead":  # the opt-in Cholesky schedule, end to end
         monkeypatch.setenv("CUGO_LOOKAHEAD", "1")
     elif subtree_stage == "two_phase":  # every level in the form the widest levels take
         monkeypatch.setenv("CUGO_TWO_PHASE_MIN_TILES", "1")
@@ -561,10 +565,14 @@ def test_landmarks_with_more_than_256_edges_and_dense_schur(oracle_lib):
     assert out["stats"][-1]["chi2"] <= out["stats"][0]["chi2"]
 
 
+@pytest.mark.parametrize("rows", [False, True])
 @pytest.mark.parametrize("which", ["all_landmarks_fixed", "all_poses_fixed"])
-def test_degenerate_fixed_sets(oracle_lib, which):
+def test_degenerate_fixed_sets(oracle_lib, which, rows, monkeypatch):
     """pose-only BA (no free landmark: the Schur complement is just Hpp) and structure-only BA
-    (no free pose: an empty pose system, landmarks solved by their 3x3 blocks)"""
+    (no free pose: an empty pose system, landmarks solved by their 3x3 blocks); also with the opt-in
+    block-row Schur kernel, which has to hand such structures back to the gather kernels"""
+    if rows:
+        monkeypatch.setenv("CUGO_HSC_ROWS", "1")
     d, _ = synth_problem(oracle_lib, 30, 400, 1600, seed=5, lc=0)
     if which == "all_landmarks_fixed":
         d["lm_fixed"] = np.ones(400, np.uint8)

@@ -1088,6 +1088,18 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
         }
     };
 
+    // Speculative build (single process, CUGO_SPECULATE=0 turns it off): behind the error pass of a first
+    // trial the host queues the NEXT iteration's build pass at the trial's estimates before it waits for the
+    // trial's result — the 15-20 us the host needs to read F-hat, decide and queue again then overlap with
+    // the build instead of leaving the device idle.  The damping that build prepares T for is lambda / 3:
+    // what an accepted trial with rho near 1 gives (ref: cuda_graph_optimisation.cpp:97-99, the lower clamp).
+    // Accepted with another lambda: the Schur complement recomputes T (as without the fusion).  Rejected:
+    // H is rebuilt from the kept estimates before the retry.  Same arithmetic on the same data in every case.
+    const char* spec_env = std::getenv("CUGO_SPECULATE");
+    const bool speculate = !sharded && !m.profile && !(spec_env && spec_env[0] == '0');
+    bool have_build = false;      // the build pass of this iteration is already queued
+    double built_lambda = -1.0;   // ... with invHll / T for this damping (< 0: none)
+
     for (int iteration = 0; iteration < niterations; iteration++)
     {
         const auto it0 = Clock::now();
@@ -1103,7 +1115,9 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
             m.d_T.resize((m.ev.block_f32 ? 9 : 18) * (size_t)m.E + 16);
         const char* fuse_env = std::getenv("CUGO_FUSE_T");
         const bool fuse_allowed = !(fuse_env && fuse_env[0] == '0');
-        const bool fused_T = fuse_allowed && !m.splan_on && iteration > 0 && m.lm_in_one_group;
+        const bool can_fuse = fuse_allowed && !m.splan_on && m.lm_in_one_group;
+        const bool fused_T = have_build ? (can_fuse && built_lambda == lambda) : (can_fuse && iteration > 0);
+        if (!have_build)
         m.timed("build", [&] {
             // chi2 of the build pass is only consumed in the first iteration (see below)
             cugo_k::launch_build(s, m.ev, m.d_poses[m.cur].data(), m.d_lms[m.cur].data(), m.rk,
@@ -1112,6 +1126,7 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
                                  fused_T ? m.d_invHll.data() : nullptr,
                                  fused_T && !use_rows ? m.d_T.data() : nullptr);
         });
+        have_build = false, built_lambda = -1.0;
         sync_prof(PROF_BUILD_SYSTEM, tb);
         if (iteration == 0)
         {
@@ -1145,8 +1160,18 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
 
         int q = 0;
         double rho = -1.0;
+        bool spec_queued = false; // the next iteration's build went out behind this iteration's first trial
         for (; q < maxq && rho < 0; q++)
         {
+            if (spec_queued)
+            { // that trial was rejected: the speculative pass overwrote H, rebuild it from the kept estimates
+                m.timed("build", [&] {
+                    cugo_k::launch_build(s, m.ev, m.d_poses[m.cur].data(), m.d_lms[m.cur].data(), m.rk,
+                                         m.d_Hpp.data(), m.bp(), m.d_Hll.data(), m.bl(), m.d_Hpl.data(), m.rs(),
+                                         nullptr, -1.0, nullptr, nullptr);
+                });
+                spec_queued = false;
+            }
             auto ts = Clock::now();
             m.timed("schur", [&] {
                 cugo_k::launch_schur(s, m.ev, m.hs, lambda, 0, m.d_Hpp.data(), m.bp(),
@@ -1188,6 +1213,17 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
             });
             m.last_err_buf = nxt;
             sync_prof(PROF_COMPUTE_ERROR, te);
+            const double lambda_pred = lambda * (1.0 / 3.0);
+            if (speculate && q == 0 && iteration + 1 < niterations)
+            {
+                m.timed("build", [&] {
+                    cugo_k::launch_build(s, m.ev, m.d_poses[nxt].data(), m.d_lms[nxt].data(), m.rk, m.d_Hpp.data(),
+                                         m.bp(), m.d_Hll.data(), m.bl(), m.d_Hpl.data(), m.rs(), nullptr,
+                                         can_fuse ? lambda_pred : -1.0, can_fuse ? m.d_invHll.data() : nullptr,
+                                         can_fuse && !use_rows ? m.d_T.data() : nullptr);
+                });
+                spec_queued = true;
+            }
             if (sharded)
             {
                 m.exchange(m.d_scal.data() + 2, 2, 0);
@@ -1211,6 +1247,8 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
                 nu = 2.0;
                 F = Fhat;
                 m.cur = nxt; // accept: the trial buffer becomes the estimate (no pop needed)
+                if (spec_queued)
+                    have_build = true, built_lambda = can_fuse ? lambda_pred : -1.0;
                 break;
             }
             else

@@ -130,6 +130,14 @@ void cugo_chol::upload(hipStream_t s)
 
 void cugo_chol::analyze(int n, const int32_t* rowptr, const int32_t* colind)
 {
+    analyze_host(n, rowptr, colind);
+    if (ctx)
+        upload(ctx->stream);
+}
+
+// ordering + symbolic factorisation only (host); upload() brings the plan to the device
+void cugo_chol::analyze_host(int n, const int32_t* rowptr, const int32_t* colind)
+{
     chol_analyze(n, rowptr, colind, CholOptions::from_env(), plan);
     lookahead = std::getenv("CUGO_LOOKAHEAD") && std::atoi(std::getenv("CUGO_LOOKAHEAD")) != 0;
     trans32.assign(plan.blk_trans.begin(), plan.blk_trans.end());
@@ -138,8 +146,6 @@ void cugo_chol::analyze(int n, const int32_t* rowptr, const int32_t* colind)
         cugo_k::chol_lds_backward_bytes(plan.nc_max, plan.ld_max) > 160 * 1024)
         throw std::runtime_error("cugo: a front exceeds the LDS budget (nc=" +
                                  std::to_string(plan.nc_max) + ", ld=" + std::to_string(plan.ld_max) + ")");
-    if (ctx)
-        upload(ctx->stream);
     analyzed = true;
 }
 

@@ -25,6 +25,7 @@ struct cugo_chol
     cugo_host::DevBuf<double> d_fronts, d_xnew, d_junk, d_winv, d_l21;
 
     void analyze(int n, const int32_t* rowptr, const int32_t* colind);
+    void analyze_host(int n, const int32_t* rowptr, const int32_t* colind); // without upload()
     void upload(hipStream_t s);
     void factor_solve(const double* d_Hsc, double lambda, const double* d_bsc, double* d_x,
                       int32_t* d_fail);

@@ -119,6 +119,24 @@ struct Engine::Impl : cugo_k::LaunchHook
     // ... and the topology itself (compared on a hash hit), saved by build_structure()
     int sig_dims[8] = {0}, pending_dims[8] = {0};
     std::vector<int32_t> sig_e_pose, sig_e_lm, sig_cov_pose;
+    // The Hsc pattern, the ordering and the symbolic factor depend on the co-visibility lists alone.  When
+    // those change, initialize() starts their build on a helper thread and a second stream the moment the
+    // lists exist — the slot layout, the slot arrays, their upload and the topology hash then run beside
+    // it — and build_structure() (first optimize()) joins it, builds the contribution lists and uploads
+    // the plan.  CUGO_ASYNC_STRUCTURE=0: everything in build_structure(), as before.
+    std::thread pat_thread;
+    std::exception_ptr pat_err;
+    bool pat_async_ok = false;   // the helper finished a pattern + host plan for the current lists
+    bool pattern_dirty = true;   // the pattern / plan in gstruct / chol are not those of the current lists
+    bool plan_uploaded = false;
+    int pat_P = -1, pat_L = -1;
+    std::vector<int32_t> pat_cov_ptr, pat_cov_pose; // the lists the pattern in gstruct / chol was built from
+    hipStream_t s2 = nullptr;
+    void join_pattern()
+    {
+        if (pat_thread.joinable())
+            pat_thread.join();
+    }
     std::vector<uint8_t> sig_flags;
 
     // optional HIP-event timing of kernel groups
@@ -261,11 +279,16 @@ Engine::~Engine()
     {
         if (cugo_k::launch_hook() == impl_)
             cugo_k::set_launch_hook(nullptr);
-        hipStream_t s = impl_->ctx.stream;
+        impl_->join_pattern();
+        hipStream_t s = impl_->ctx.stream, s2 = impl_->s2;
         if (s)
             (void)hipStreamSynchronize(s);
+        if (s2)
+            (void)hipStreamSynchronize(s2);
         delete impl_;
         cache_stream_release(s); // back to the process-wide pool: creating one costs 1-2 ms
+        if (s2)
+            cache_stream_release(s2);
     }
 }
 
@@ -491,6 +514,52 @@ void Engine::initialize(FlatGraph& g)
                                      std::to_string(dup_lm.load()) + "): duplicate (pose, landmark) edges are not supported");
     }
     laps.lap("engine: co-visibility");
+    // ---- the co-visibility lists decide the Hsc pattern: if they changed, its build, the ordering and the
+    // symbolic factorisation start NOW, beside the rest of this function (see Impl::pat_thread)
+    m.join_pattern();
+    if (m.pat_err)
+    {
+        m.pat_err = nullptr; // a failed helper of an earlier call: that structure was never used
+        m.pattern_dirty = true;
+    }
+    {
+        auto same = [](const auto& a, const auto& b) {
+            return a.size() == b.size() && (a.empty() || std::memcmp(a.data(), b.data(), a.size() * sizeof(a[0])) == 0);
+        };
+        const bool pat_same = !m.pattern_dirty && !std::getenv("CUGO_NO_STRUCTURE_REUSE") && m.P == m.pat_P &&
+                              m.L == m.pat_L && same(m.cov_ptr, m.pat_cov_ptr) && same(m.cov_pose, m.pat_cov_pose);
+        m.pat_async_ok = false;
+        if (!pat_same)
+        {
+            m.pattern_dirty = true;
+            const char* env = std::getenv("CUGO_ASYNC_STRUCTURE");
+            const bool device_build = !m.plan_only && !std::getenv("CUGO_SCHUR_PLAN") && !std::getenv("CUGO_HOST_STRUCTURE");
+            if (device_build && !(env && env[0] == '0') && m.P > 0 && !m.cov_pose.empty())
+            {
+                if (!m.s2)
+                    m.s2 = cache_stream_acquire();
+                m.pat_thread = std::thread([this] {
+                    Impl& mm = *impl_;
+                    try
+                    {
+                        const auto t0p = Clock::now();
+                        if (!build_pattern_gpu(mm.s2, mm.P, mm.L, mm.cov_ptr.data(), mm.cov_pose.data(), mm.gstruct))
+                            return;
+                        mm.hsc_rowptr = mm.gstruct.h_rowptr, mm.hsc_colind = mm.gstruct.h_colind;
+                        prof_[PROF_BUILD_STRUCTURE] += ms_since(t0p);
+                        const auto t1p = Clock::now();
+                        mm.chol.analyze_host(mm.P, mm.hsc_rowptr.data(), mm.hsc_colind.data());
+                        prof_[PROF_SYMBOLIC] += ms_since(t1p);
+                        mm.pat_async_ok = true;
+                    }
+                    catch (...)
+                    {
+                        mm.pat_err = std::current_exception();
+                    }
+                });
+            }
+        }
+    }
     // ---- shard: contiguous landmark range balanced by edge count -----------------------
     int l0 = 0, l1 = m.Lall;
     shard_range(lm_cnt, m.rank, m.world, l0, l1);
@@ -827,14 +896,45 @@ void Engine::build_structure()
     // blocks; the same lists, in the same order, as the host passes below (which remain for plan-only
     // and forced runs).  A shard builds the pattern from the global co-visibility lists.
     const bool shard = m.world > 1 || m.comm; // local slots are a subset: the pattern comes from the global lists
-    if (!m.plan_only && (m.E > 0 || shard) && !std::getenv("CUGO_SCHUR_PLAN") && !std::getenv("CUGO_HOST_STRUCTURE"))
+    m.join_pattern();
+    if (m.pat_err)
     {
-        if (build_structure_gpu(s, m.E, P, m.Lall, m.d_e_pose.data(), m.d_flags.data(), m.d_lm_ptr.data(), m.gstruct,
-                                shard ? L : 0, shard ? m.cov_ptr.data() : nullptr, shard ? m.cov_pose.data() : nullptr))
+        std::exception_ptr e = m.pat_err;
+        m.pat_err = nullptr;
+        std::rethrow_exception(e);
+    }
+    if (!m.plan_only && (m.E > 0 || shard) && !std::getenv("CUGO_SCHUR_PLAN") && !std::getenv("CUGO_HOST_STRUCTURE") &&
+        P > 0 && !m.cov_pose.empty())
+    {
+        // phase 1 (unless the helper thread of initialize() has done it, or the lists are those of the
+        // pattern at hand): Hsc pattern from the co-visibility lists, ordering + symbolic factorisation
+        bool ok = true;
+        if (m.pattern_dirty && !m.pat_async_ok)
         {
-            laps.lap("structure: device build (pairs, sort, runs)");
-            m.gstruct.scratch.release();
-            m.hsc_rowptr = m.gstruct.h_rowptr, m.hsc_colind = m.gstruct.h_colind;
+            ok = build_pattern_gpu(s, P, L, m.cov_ptr.data(), m.cov_pose.data(), m.gstruct);
+            if (ok)
+            {
+                m.hsc_rowptr = m.gstruct.h_rowptr, m.hsc_colind = m.gstruct.h_colind;
+                prof_[PROF_BUILD_STRUCTURE] += ms_since(t0);
+                const auto t1g = Clock::now();
+                m.chol.analyze_host(P, m.hsc_rowptr.data(), m.hsc_colind.data());
+                prof_[PROF_SYMBOLIC] += ms_since(t1g);
+            }
+        }
+        laps.lap("structure: pattern + symbolic (unless done beside initialize)");
+        // phase 2: the contribution lists from the slots on the device
+        const auto t2 = Clock::now();
+        if (ok && build_lists_gpu(s, m.E, P, m.Lall, m.d_e_pose.data(), m.d_flags.data(), m.d_lm_ptr.data(), m.gstruct))
+        {
+            laps.lap("structure: contribution lists (device)");
+            if (m.pattern_dirty || !m.plan_uploaded)
+            {
+                m.chol.upload(s);
+                m.plan_uploaded = true;
+                m.pat_P = P, m.pat_L = L, m.pat_cov_ptr = m.cov_ptr, m.pat_cov_pose = m.cov_pose;
+            }
+            m.pattern_dirty = false;
+            m.gstruct.scratch.release(), m.gstruct.scratch2.release();
             const int B = m.gstruct.B;
             m.d_sys.resize(36 * (size_t)B + 6 * (size_t)P + 16);
             m.hs = cugo_hsc_struct{};
@@ -846,11 +946,8 @@ void Engine::build_structure()
             double nff = 0;
             for (int e = 0; e < m.E; e++)
                 nff += (m.h_flags[e] & (CUGO_EDGE_FIXED_L | CUGO_EDGE_FIXED_P | CUGO_EDGE_INACTIVE)) == 0;
-            prof_[PROF_BUILD_STRUCTURE] += ms_since(t0);
-            const auto t1g = Clock::now();
-            m.chol.analyze(P, m.hsc_rowptr.data(), m.hsc_colind.data());
-            prof_[PROF_SYMBOLIC] += ms_since(t1g);
-            laps.lap("structure: symbolic + plan upload");
+            prof_[PROF_BUILD_STRUCTURE] += ms_since(t2);
+            laps.lap("structure: plan upload");
             // all products of the graph (every free-free edge also has its diagonal one) / local off-diagonal ones
             fill_structure_stats(B, (double)m.gstruct.Mglobal + (shard ? (double)m.cov_pose.size() : nff),
                                  (double)m.gstruct.Moff);
@@ -858,7 +955,9 @@ void Engine::build_structure()
             m.structure_dirty = false;
             return;
         }
+        m.pattern_dirty = true, m.plan_uploaded = false; // the host build below starts from scratch
     }
+    m.pattern_dirty = true, m.plan_uploaded = false;
     // pose-major view of the global co-visibility
     std::vector<int32_t> pc_ptr(P + 1, 0), pc_lm(m.cov_pose.size());
     for (int32_t p : m.cov_pose)

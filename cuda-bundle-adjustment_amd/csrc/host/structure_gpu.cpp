@@ -166,22 +166,27 @@ __global__ __launch_bounds__(TB) void k_blocks(int P, int n_runs, size_t M, cons
                                                const int32_t* __restrict__ rowptr, int32_t* __restrict__ colind,
                                                int32_t* __restrict__ off_ptr)
 {
+    // colind == nullptr: only the list starts (second phase); off_ptr == nullptr: only the pattern (first phase)
     const int t = blockIdx.x * TB + threadIdx.x;
     if (t < n_runs)
     { // off-diagonal block of run t
         const int id = t + run_pa[t] + 1;
-        colind[id] = run_pb[t];
-        off_ptr[id] = run_start[t];
+        if (colind)
+            colind[id] = run_pb[t];
+        if (off_ptr)
+            off_ptr[id] = run_start[t];
     }
     else if (t < n_runs + P)
     { // diagonal block of row p: first in its row, empty list
         const int p = t - n_runs;
         const int id = rowptr[p];
         const int r = row_first[p];
-        colind[id] = p;
-        off_ptr[id] = r < n_runs ? run_start[r] : (int32_t)M;
+        if (colind)
+            colind[id] = p;
+        if (off_ptr)
+            off_ptr[id] = r < n_runs ? run_start[r] : (int32_t)M;
     }
-    else if (t == n_runs + P)
+    else if (t == n_runs + P && off_ptr)
         off_ptr[n_runs + P] = (int32_t)M;
 }
 } // namespace
@@ -320,6 +325,86 @@ bool build_structure_gpu(hipStream_t s, int E, int P, int Lall, const int32_t* d
     CUGO_HIP(hipStreamSynchronize(s));
     CUGO_HIP(hipGetLastError());
     out.B = B, out.Moff = M, out.Mglobal = Mg;
+    return true;
+}
+
+// ---- the same build in two phases (the engine overlaps the first with the rest of initialize()) ----
+// Phase 1, from the co-visibility lists alone (host arrays: free landmark -> its free poses, cov_ptr [L + 1]):
+// the Hsc pattern.  It is known as soon as the edges have been grouped by landmark — before the slot layout,
+// the slot arrays and their upload exist — and it is all the ordering + symbolic analysis needs.
+bool build_pattern_gpu(hipStream_t s, int P, int L, const int32_t* h_cov_ptr, const int32_t* h_cov_pose, GpuStructure& out)
+{
+    out.B = 0, out.Moff = 0, out.Mglobal = 0, out.n_runs = 0;
+    if (P <= 0 || L < 0)
+        return false;
+    int bits = 1;
+    while ((1ll << bits) < (long long)P + 1)
+        bits++;
+    out.bits = bits;
+    GpuStructureScratch& w = out.scratch;
+    const size_t ncov = (size_t)h_cov_ptr[L];
+    w.cov_ptr.resize((size_t)L + 1), w.cov_pose.resize(ncov + 1);
+    CUGO_HIP(hipMemcpyAsync(w.cov_ptr.data(), h_cov_ptr, sizeof(int32_t) * ((size_t)L + 1), hipMemcpyHostToDevice, s));
+    if (ncov > 0)
+        CUGO_HIP(hipMemcpyAsync(w.cov_pose.data(), h_cov_pose, sizeof(int32_t) * ncov, hipMemcpyHostToDevice, s));
+    size_t Mg = 0;
+    int n_runs = 0;
+    if (L > 0 && !sorted_pairs(s, L, w.cov_ptr.data(), nullptr, w.cov_pose.data(), bits, false, w, Mg, n_runs))
+        return false;
+    out.run_pa.resize((size_t)n_runs + 1), out.run_pb.resize((size_t)n_runs + 1);
+    if (Mg > 0)
+        hipLaunchKernelGGL(k_runs, dim3((unsigned)((Mg + TB - 1) / TB)), dim3(TB), 0, s, Mg, w.keys_b.data(),
+                           (const uint64_t*)nullptr, w.head.data(), w.rank.data(), bits, out.run_pa.data(),
+                           out.run_pb.data(), (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr,
+                           (uint64_t*)nullptr);
+    const int B = n_runs + P;
+    out.rowptr.resize((size_t)P + 1), out.colind.resize((size_t)B + 1), out.row_first.resize((size_t)P + 1);
+    hipLaunchKernelGGL(k_rows, dim3((P + 1 + TB - 1) / TB), dim3(TB), 0, s, P, n_runs, out.run_pa.data(),
+                       out.row_first.data(), out.rowptr.data());
+    hipLaunchKernelGGL(k_blocks, dim3((B + 1 + TB - 1) / TB), dim3(TB), 0, s, P, n_runs, (size_t)0, out.run_pa.data(),
+                       out.run_pb.data(), (const int32_t*)nullptr, out.row_first.data(), out.rowptr.data(),
+                       out.colind.data(), (int32_t*)nullptr);
+    out.h_rowptr.resize((size_t)P + 1), out.h_colind.resize((size_t)B);
+    CUGO_HIP(hipMemcpyAsync(out.h_rowptr.data(), out.rowptr.data(), sizeof(int32_t) * ((size_t)P + 1),
+                            hipMemcpyDeviceToHost, s));
+    CUGO_HIP(hipMemcpyAsync(out.h_colind.data(), out.colind.data(), sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, s));
+    CUGO_HIP(hipStreamSynchronize(s));
+    CUGO_HIP(hipGetLastError());
+    out.B = B, out.Mglobal = Mg, out.n_runs = n_runs;
+    return true;
+}
+
+// Phase 2, from the flattened landmark-major edge slots on the device: the contribution lists of the pattern's
+// blocks (stable sort: ascending landmark order inside a block, the host build's order), matched to the
+// pattern's runs by binary search — a block without local products (a shard) gets an empty list.
+bool build_lists_gpu(hipStream_t s, int E, int P, int Lall, const int32_t* d_e_pose, const uint8_t* d_flags,
+                     const int32_t* d_lm_ptr, GpuStructure& out)
+{
+    GpuStructureScratch& w = out.scratch2;
+    const int bits = out.bits, n_runs = out.n_runs, B = out.B;
+    size_t M = 0;
+    int n_lruns = 0;
+    if (E > 0 && !sorted_pairs(s, Lall, d_lm_ptr, d_flags, d_e_pose, bits, true, w, M, n_lruns))
+        return false;
+    const int nM = (int)((M + TB - 1) / TB);
+    out.off_ei.resize(M + 16), out.off_ej.resize(M + 16);
+    w.lrun_key.resize((size_t)n_lruns + 1), w.lrun_start.resize((size_t)n_lruns + 1);
+    w.run_start.resize((size_t)n_runs + 1);
+    if (M > 0)
+        hipLaunchKernelGGL(k_runs, dim3(nM), dim3(TB), 0, s, M, w.keys_b.data(), w.vals_b.data(), w.head.data(),
+                           w.rank.data(), bits, (int32_t*)nullptr, (int32_t*)nullptr, w.lrun_start.data(),
+                           out.off_ei.data(), out.off_ej.data(), w.lrun_key.data());
+    if (n_runs > 0)
+        hipLaunchKernelGGL(k_match_runs, dim3((n_runs + TB - 1) / TB), dim3(TB), 0, s, n_runs, out.run_pa.data(),
+                           out.run_pb.data(), bits, n_lruns, w.lrun_key.data(), w.lrun_start.data(), (int32_t)M,
+                           w.run_start.data());
+    out.off_ptr.resize((size_t)B + 1);
+    hipLaunchKernelGGL(k_blocks, dim3((B + 1 + TB - 1) / TB), dim3(TB), 0, s, P, n_runs, M, out.run_pa.data(),
+                       out.run_pb.data(), w.run_start.data(), out.row_first.data(), out.rowptr.data(),
+                       (int32_t*)nullptr, out.off_ptr.data());
+    CUGO_HIP(hipStreamSynchronize(s));
+    CUGO_HIP(hipGetLastError());
+    out.Moff = M;
     return true;
 }
 

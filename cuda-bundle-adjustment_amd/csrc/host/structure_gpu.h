@@ -37,6 +37,10 @@ struct GpuStructure
     size_t Moff = 0;   // products in the (local) lists
     size_t Mglobal = 0; // off-diagonal products of the whole graph (= Moff for a single process)
     GpuStructureScratch scratch; // transient; released by the caller when memory matters
+    // two-phase build (build_pattern_gpu / build_lists_gpu): what the second phase needs from the first
+    DevBuf<int32_t> run_pa, run_pb, row_first; // pose pair of every off-diagonal block of the pattern; first run of a row
+    int bits = 1, n_runs = 0;
+    GpuStructureScratch scratch2; // the second phase's own (the first may still be in flight on another stream)
 };
 
 // d_e_pose / d_flags: the flattened landmark-major edge slots, d_lm_ptr [Lall + 1].  Returns false
@@ -47,5 +51,11 @@ struct GpuStructure
 bool build_structure_gpu(hipStream_t s, int E, int P, int Lall, const int32_t* d_e_pose, const uint8_t* d_flags,
                          const int32_t* d_lm_ptr, GpuStructure& out, int L = 0, const int32_t* h_cov_ptr = nullptr,
                          const int32_t* h_cov_pose = nullptr);
+
+// The same build in two phases: the pattern from the co-visibility lists alone (host arrays, cov_ptr [L + 1]:
+// free landmark -> its free poses over ALL shards), then the contribution lists from the local slots.
+bool build_pattern_gpu(hipStream_t s, int P, int L, const int32_t* h_cov_ptr, const int32_t* h_cov_pose, GpuStructure& out);
+bool build_lists_gpu(hipStream_t s, int E, int P, int Lall, const int32_t* d_e_pose, const uint8_t* d_flags,
+                     const int32_t* d_lm_ptr, GpuStructure& out);
 
 } // namespace cugo_host

@@ -423,6 +423,37 @@ def test_medium_synthetic_vs_oracle(oracle_lib, subtree_stage, monkeypatch):
     assert out["stats"][-1]["chi2"] < out["stats"][0]["chi2"]
 
 
+def test_structure_build_beside_initialize_is_the_synchronous_one(oracle_lib, monkeypatch):
+    """a changed co-visibility starts the Hsc pattern, the ordering and the symbolic factorisation on a
+    helper thread inside initialize() (engine.cpp, Impl::pat_thread); CUGO_ASYNC_STRUCTURE=0 does all of it
+    in the first optimize().  Same structure, bitwise the same run — also over a sequence of calls in which
+    the topology changes, stays, and only a measurement changes (lists rebuilt, plan kept)"""
+    d, _ = synth_problem(oracle_lib, 150, 2200, 9000, seed=17, lc=60)
+    extra = cugo.synth(150, 2200, 9400, seed=18, n_loop_closures=60)
+    have = set(zip(d["e_pose"].tolist(), d["e_lm"].tolist()))
+    sel = [i for i in range(len(extra["e_pose"])) if (int(extra["e_pose"][i]), int(extra["e_lm"][i])) not in have][:300]
+    runs = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("CUGO_ASYNC_STRUCTURE", mode)
+        g = cugo.graph_from_arrays(d)
+        out = []
+        g.initialize(); g.optimize(3)
+        out.append(([s["chi2"] for s in g.stats()], g.poses().copy(), g.structure_stats()))
+        g.initialize(); g.optimize(2)                       # nothing changed: everything re-used
+        out.append(([s["chi2"] for s in g.stats()], g.poses().copy(), g.structure_stats()))
+        for dim in (2, 3):                                   # new edges: a new co-visibility
+            k = [i for i in sel if int(extra["e_stereo"][i]) == (dim == 3)]
+            g.add_edges(dim, extra["e_pose"][k], extra["e_lm"][k], extra["e_meas"][k][:, :dim], extra["e_omega"][k],
+                        extra["e_cam"][k])
+        g.initialize(); g.initialize(); g.optimize(3)        # (a second initialize() joins the first helper)
+        out.append(([s["chi2"] for s in g.stats()], g.poses().copy(), g.structure_stats()))
+        g.close()
+        runs.append(out)
+    for a, b in zip(*runs):
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    assert runs[0][2][2]["hsc_blocks"] >= runs[0][0][2]["hsc_blocks"]
+
+
 @pytest.mark.parametrize("shape", ["mixed_fixed", "medium", "dense_ring", "all_landmarks_fixed"])
 def test_device_structure_build_equals_host_build(oracle_lib, shape, monkeypatch):
     """the Hsc pattern and the contribution lists built on the device (pairs per landmark, stable

@@ -19,6 +19,9 @@ def main():
     reps = 30
     if "--workload" in a:
         i = a.index("--workload"); wl = a[i + 1]; del a[i:i + 2]
+    dirty = "--dirty" in a   # time the new-graph regime: full flattening + structure rebuild in every call
+    if dirty:
+        a.remove("--dirty")
     if "--reps" in a:
         i = a.index("--reps"); reps = int(a[i + 1]); del a[i:i + 2]
     var, vals = a[0], a[1:]
@@ -38,6 +41,9 @@ def main():
         g.initialize(); g.optimize(10)
         graphs.append(g)
     times = [[] for _ in vals]
+    if dirty:
+        os.environ["CUGO_NO_STRUCTURE_REUSE"] = "1"
+        os.environ["CUGO_NO_FLATTEN_REUSE"] = "1"
     for r in range(reps):
         for k, g in enumerate(graphs):
             put(vals[k])

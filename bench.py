@@ -156,7 +156,25 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")  # one node: RCCL's bootstrap over loopback
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        # every rank first checks — without entering a collective — that librccl loads and that it has a
+        # device of its own; only if ALL ranks can, they enter ncclCommInitRank together (a rank failing
+        # inside the collective would leave the others blocked in it)
+        import ctypes
+        can = 1.0
         try:
+            ctypes.CDLL("librccl.so.1")
+        except OSError:
+            try:
+                ctypes.CDLL("/opt/rocm/lib/librccl.so.1")
+            except OSError:
+                can = 0.0
+        if ndev < world:
+            can = 0.0   # RCCL refuses two ranks of one communicator on the same device
+        pre = torch.tensor([can])
+        dist.all_reduce(pre, op=dist.ReduceOp.MIN)
+        try:
+            if float(pre.item()) < 0.5:
+                raise RuntimeError("librccl or one GPU per rank not available on every rank")
             box = [cugo.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
             comm = cugo.Comm(box[0], rank, world)
@@ -184,7 +202,10 @@ def main():
         if t is None:
             t = views[(ptr, n)] = torch.as_tensor(_DevPtr(ptr, n), device="cuda")
         h = t.cpu()
-        dist.all_reduce(h, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX)
+        if op >= 2:   # broadcast from rank op - 2 (rank-owned elimination subtrees)
+            dist.broadcast(h, src=op - 2)
+        else:
+            dist.all_reduce(h, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX)
         t.copy_(h)
         torch.cuda.synchronize()
 
@@ -489,7 +510,7 @@ def main():
                        "timed_region": "initialize(); optimize(%d) per step, contiguous (ref "
                                        "samples/sample_ba_from_file/main.cpp:185-190), structure clean" % args.iters,
                        "parallelism": ("landmark-sharded x%d, RCCL all-reduce of [Hsc|bsc] per LM trial on the "
-                                       "solver's stream, replicated LL^T" % world) if world > 1 else "single GPU",
+                                       "solver's stream, LL^T by rank-owned elimination subtrees under a replicated top" % world) if world > 1 else "single GPU",
                        "lm_iterations_per_step": iters_total / args.steps,
                        "block_storage": "float (Hpl, Hpl*invHll streams; BASELINE config 5)" if args.float32 else "double"},
             "ba_10iter_seconds": elapsed / args.steps,
@@ -520,10 +541,17 @@ def main():
             out["exchange"] = {"form": exchange_form, "calls_per_step": xstats["calls"], "bytes_per_step": xstats["bytes"],
                                "payload_bytes_per_trial": 8.0 * (36 * sstats["hsc_blocks"] + 6 * (P - 1)) + 16.0,
                                "trials_per_step": trials,
-                               "amdahl": {"replicated_cholesky_share_of_single_gpu_step": chol_share,
-                                          "note": "the sparse LL^T is replicated on every rank: with s = its share of "
-                                                  "the single-GPU optimize() time the speed-up at N GPUs is bounded by "
-                                                  "1 / (s + (1 - s) / N), before the cost of the all-reduce"}}
+                               "cholesky": {"rank_flops": sstats.get("chol_rank_flops"),
+                                            "replicated_top_flops": sstats.get("chol_top_flops"),
+                                            "broadcast_bytes_per_trial": sstats.get("chol_bcast_bytes"),
+                                            "broadcasts_per_trial": sstats.get("chol_bcasts"),
+                                            "cholesky_share_of_step": chol_share,
+                                            "note": "the sparse LL^T runs by rank-owned elimination subtrees: a rank "
+                                                    "factors its own subtrees (rank_flops, rank 0's here) and the "
+                                                    "replicated top of the tree; only the top's share of the "
+                                                    "factorisation stays serial in the Amdahl sense, and on graphs "
+                                                    "whose levels are latency-bound (kitti_00) the per-level critical "
+                                                    "path does not shrink with fewer fronts per level"}}
         elif chol_share is not None:
             out["amdahl"] = {"replicated_cholesky_share_of_optimize": chol_share,
                              "max_speedup_8_gpus": 1.0 / (chol_share + (1 - chol_share) / 8)}

@@ -306,11 +306,12 @@ class Graph:
         return {names[i]: dict(ms=float(ms[i]), launches=int(cnt[i])) for i in range(n)}
 
     def structure_stats(self):
-        o = np.zeros(16)
-        n = lib().cugo_graph_structure_stats(self._g, _p(o, _f64p), 16)
+        o = np.zeros(24)
+        n = lib().cugo_graph_structure_stats(self._g, _p(o, _f64p), 24)
         keys = ["hsc_blocks", "products", "nnzL", "chol_flops", "supernodes", "stages", "front_bytes",
                 "offdiag_products", "up_potrf_flops", "up_trsm_flops", "up_syrk_flops", "up_ea_bytes",
-                "backward_bytes", "schur_slots"]
+                "backward_bytes", "schur_slots", "chol_rank_flops", "chol_top_flops", "chol_bcast_bytes",
+                "chol_bcasts"]
         return dict(zip(keys[:n], o[:n].tolist()))
 
 

@@ -138,7 +138,12 @@ void cugo_chol::analyze(int n, const int32_t* rowptr, const int32_t* colind)
 // ordering + symbolic factorisation only (host); upload() brings the plan to the device
 void cugo_chol::analyze_host(int n, const int32_t* rowptr, const int32_t* colind)
 {
-    chol_analyze(n, rowptr, colind, CholOptions::from_env(), plan);
+    CholOptions opt = CholOptions::from_env();
+    // CUGO_OWN_SUBTREES=0: every rank factors everything (the replicated form of rounds 1-2)
+    const char* own = std::getenv("CUGO_OWN_SUBTREES");
+    if (world > 1 && bcast && !(own && own[0] == '0'))
+        opt.rank = rank, opt.world = world;
+    chol_analyze(n, rowptr, colind, opt, plan);
     lookahead = std::getenv("CUGO_LOOKAHEAD") && std::atoi(std::getenv("CUGO_LOOKAHEAD")) != 0;
     trans32.assign(plan.blk_trans.begin(), plan.blk_trans.end());
     if (plan.nc_max > cugo_k::chol_max_pivot_cols() ||
@@ -193,6 +198,19 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
                                               d_wl_ptr + 3L * plan.syrk_ptr[st],
                                               plan.syrk_ptr[st + 1] - plan.syrk_ptr[st]);
         }
+        // update blocks that cross the ownership boundary: the subtree roots of this level whose parent is
+        // replicated go from their owner to every rank (columns 6 ncb .. of the front: one contiguous range)
+        for (size_t k = 0; k < plan.xu_front.size(); k++)
+            if (plan.xu_stage[k] == st)
+            {
+                const int f = plan.xu_front[k];
+                // from element (c0, c0) to the rhs-row entry of the last column: one contiguous range that stays
+                // inside the front's storage also when the front lives in its child's update block
+                const int64_t ld = plan.ldf[f], c0 = 6LL * plan.ncb[f], c1 = 6LL * plan.nb[f];
+                if (c1 > c0)
+                    bcast(d_fronts.data() + plan.off[f] + c0 * ld + c0, (size_t)((c1 - 1 - c0) * ld + c1 + 1 - c0),
+                          plan.xu_owner[k]);
+            }
     }
     if (npend > 0) // the last level's tiles (the rhs rows of the roots)
         cugo_k::launch_chol_potrf_la(s, dev, d_fronts.data(), 0, 0, d_wl_ptr + 3L * pend0, npend, pend_tile, d_fail);
@@ -209,6 +227,12 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
             CUGO_HIP(hipStreamSynchronize(s));
             CUGO_HIP(hipMemcpy(d_stamps + 48, d_stamps + 24, 8 * sizeof(long long), hipMemcpyDeviceToDevice));
         }
+    }
+    if (!plan.xx_lo.empty())
+    { // the solution of the other ranks' subtrees, then the un-permutation of the whole vector
+        for (size_t k = 0; k < plan.xx_lo.size(); k++)
+            bcast(d_xnew.data() + 6LL * plan.xx_lo[k], (size_t)(6LL * (plan.xx_hi[k] - plan.xx_lo[k])), plan.xx_owner[k]);
+        cugo_k::launch_chol_unpermute(s, dev, d_xnew.data(), d_x);
     }
     CUGO_HIP(hipGetLastError());
     if (dbg)

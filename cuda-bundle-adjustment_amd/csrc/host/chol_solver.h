@@ -3,6 +3,8 @@
 #include "chol_symbolic.h"
 #include "hip_util.h"
 
+#include <functional>
+
 // definition of the opaque cugo_chol of include/cugo_hip.h
 struct cugo_chol
 {
@@ -23,6 +25,13 @@ struct cugo_chol
     cugo_host::DevBuf<int64_t> d_pack64;
     const int32_t* d_wl_ptr = nullptr; // work-item triples inside d_pack32
     cugo_host::DevBuf<double> d_fronts, d_xnew, d_junk, d_winv, d_l21;
+
+    // rank-owned elimination subtrees of a landmark-sharded run (CholPlan::owner): this rank factors its own
+    // subtrees and the replicated top; update blocks that enter the top and the solution of the other ranks'
+    // subtrees arrive by `bcast(device pointer, doubles, root rank)` on the solver's stream
+    int rank = 0, world = 1;
+    std::function<void(double*, size_t, int)> bcast;
+    bool own_subtrees() const { return world > 1 && bcast && !plan.owner.empty(); }
 
     void analyze(int n, const int32_t* rowptr, const int32_t* colind);
     void analyze_host(int n, const int32_t* rowptr, const int32_t* colind); // without upload()

@@ -751,6 +751,85 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
         lvl[s] = l;
         max_lvl = std::max(max_lvl, l);
     }
+    // ---- 7a. ownership of elimination subtrees (world > 1): proportional mapping ------------------
+    P.owner.assign(ns, opt.world > 1 ? -1 : 0);
+    P.xu_front.clear(), P.xu_stage.clear(), P.xu_owner.clear();
+    P.xx_lo.clear(), P.xx_hi.clear(), P.xx_owner.clear();
+    if (opt.world > 1)
+    {
+        // children lists of the virtual root
+        std::vector<int> roots;
+        for (int s = 0; s < ns; s++)
+            if (P.sparent[s] < 0)
+                roots.push_back(s);
+        struct Item
+        {
+            std::vector<int> nodes; // sibling subtrees handled together
+            int r0, r1;             // rank range
+        };
+        std::vector<Item> stack;
+        stack.push_back({roots, 0, opt.world});
+        auto own_subtree = [&](int root, int r) {
+            // a subtree is a contiguous range of supernodes ending at its root (postorder)
+            std::vector<int> st2{root};
+            while (!st2.empty())
+            {
+                const int v = st2.back();
+                st2.pop_back();
+                P.owner[v] = r;
+                for (int k = P.child_ptr[v]; k < P.child_ptr[v + 1]; k++)
+                    st2.push_back(P.child[k]);
+            }
+        };
+        while (!stack.empty())
+        {
+            Item it = std::move(stack.back());
+            stack.pop_back();
+            if (it.nodes.empty())
+                continue;
+            const int nr = it.r1 - it.r0;
+            if (nr <= 1)
+            {
+                for (int v : it.nodes)
+                    own_subtree(v, it.r0);
+                continue;
+            }
+            if (it.nodes.size() == 1)
+            { // one subtree for several ranks: its root is replicated, the ranks go to its children
+                const int v = it.nodes[0];
+                P.owner[v] = -1;
+                std::vector<int> ch(P.child.begin() + P.child_ptr[v], P.child.begin() + P.child_ptr[v + 1]);
+                stack.push_back({ch, it.r0, it.r1});
+                continue;
+            }
+            // several subtrees, several ranks: two groups of balanced work (largest first, to the lighter
+            // group), the ranks split in proportion (at least one each)
+            std::vector<int> byw(it.nodes);
+            std::stable_sort(byw.begin(), byw.end(), [&](int a, int b) { return sub[a] > sub[b]; });
+            std::vector<int> ga, gb;
+            double wa = 0, wb = 0;
+            for (int v : byw)
+                if (wa <= wb)
+                    ga.push_back(v), wa += sub[v];
+                else
+                    gb.push_back(v), wb += sub[v];
+            int na = (int)std::lround(nr * wa / std::max(wa + wb, 1.0));
+            na = std::max(1, std::min(nr - 1, na));
+            stack.push_back({ga, it.r0, it.r0 + na});
+            stack.push_back({gb, it.r0 + na, it.r1});
+        }
+        for (int s = 0; s < ns; s++)
+        {
+            if (P.owner[s] < 0)
+                P.top_flops += work[s];
+            else if (P.owner[s] == opt.rank)
+                P.rank_flops += work[s];
+        }
+    }
+    else
+        for (int s = 0; s < ns; s++)
+            P.rank_flops += work[s];
+    auto mine = [&](int s) { return P.owner[s] < 0 || P.owner[s] == opt.rank; };
     // stage 0 tasks: maximal lower subtrees (root = lower front whose parent is not lower)
     std::vector<int> task_root_of(ns, -1);
     std::vector<std::vector<int>> stage_tasks(max_lvl + 1);
@@ -784,20 +863,59 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
         if (!lists.empty())
             P.stage_task_ptr.push_back((int)P.task_ptr.size() - 1);
     }
+    std::vector<int> stage_of(ns, 0);
     for (int l = 1; l <= max_lvl; l++)
     {
         bool any = false;
         for (int s = 0; s < ns; s++)
             if (!lower[s] && lvl[s] == l)
             {
+                stage_of[s] = (int)P.stage_task_ptr.size() - 1; // (a level of the tree is a stage on EVERY rank,
+                any = true;                                     // also one that holds none of this rank's fronts)
+                if (!mine(s))
+                    continue;
                 P.task_fronts.push_back(s);
                 P.task_ptr.push_back((int)P.task_fronts.size());
-                any = true;
             }
         if (any)
             P.stage_task_ptr.push_back((int)P.task_ptr.size() - 1);
     }
     P.n_stages = (int)P.stage_task_ptr.size() - 1;
+    if (opt.world > 1)
+    {
+        for (int s = 0; s < ns; s++)
+            if (P.owner[s] >= 0 && P.sparent[s] >= 0 && P.owner[P.sparent[s]] < 0)
+                P.xu_front.push_back(s), P.xu_stage.push_back(stage_of[s]), P.xu_owner.push_back(P.owner[s]);
+        // maximal owned subtrees = maximal runs of columns solved by one rank
+        for (int s = 0; s < ns; s++)
+            if (P.owner[s] >= 0 && (P.sparent[s] < 0 || P.owner[P.sparent[s]] < 0))
+            { // root of an owned subtree: its columns are those of the supernode range ending at s
+                int first = s;
+                std::vector<int> st2{s};
+                while (!st2.empty())
+                {
+                    const int v = st2.back();
+                    st2.pop_back();
+                    first = std::min(first, v);
+                    for (int k = P.child_ptr[v]; k < P.child_ptr[v + 1]; k++)
+                        st2.push_back(P.child[k]);
+                }
+                P.xx_lo.push_back(P.col0[first]), P.xx_hi.push_back(P.col0[s] + P.ncb[s]), P.xx_owner.push_back(P.owner[s]);
+            }
+        // the ranges the solver will hand to the broadcast must lie inside the buffers (checked here, on the
+        // host, where a mistake is an exception and not a device fault)
+        for (size_t k = 0; k < P.xu_front.size(); k++)
+        {
+            const int f = P.xu_front[k];
+            const int64_t ld = P.ldf[f], c0 = 6LL * P.ncb[f], c1 = 6LL * P.nb[f];
+            const int64_t a = P.off[f] + c0 * ld + c0, b = a + (c1 - 1 - c0) * ld + c1 + 1 - c0;
+            if (c1 > c0 && (a < 0 || b > P.front_doubles))
+                throw std::runtime_error("cugo: symbolic: update block of front " + std::to_string(f) + " outside the front buffer");
+        }
+        for (size_t k = 0; k < P.xx_lo.size(); k++)
+            if (P.xx_lo[k] < 0 || P.xx_hi[k] > n || P.xx_lo[k] >= P.xx_hi[k])
+                throw std::runtime_error("cugo: symbolic: solution range of an owned subtree outside the matrix");
+    }
     for (int s = 0; s < ns; s++)
     {
         const double nc = 6.0 * P.ncb[s], nr = 6.0 * (P.nb[s] - P.ncb[s]);
@@ -947,7 +1065,7 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
                 for (int k = P.child_ptr[f]; k < P.child_ptr[f + 1]; k++)
                 {
                     const int c = P.child[k];
-                    if (lower[c])
+                    if (lower[c] || !mine(c))
                         continue;
                     const int nbr = P.nb[c] - P.ncb[c];
                     int npb = 0;
@@ -1057,7 +1175,7 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
     P.clr0 = (int)P.wl.size() / 3;
     P.nclr = 0;
     for (int f = 0; f < ns; f++)
-        if (P.alias_of[f] < 0)
+        if (P.alias_of[f] < 0 && mine(f)) // (another rank's fronts are never read here, except through a broadcast)
             for (int c0 = 0; c0 < 6 * P.nb[f]; c0 += 16)
             {
                 P.wl.push_back(f), P.wl.push_back(c0), P.wl.push_back(std::min(6 * P.nb[f], c0 + 16));

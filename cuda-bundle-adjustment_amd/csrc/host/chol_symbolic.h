@@ -25,6 +25,9 @@ struct CholOptions
     int two_phase_min_tiles = 128; // (swept: 128-256 equal on the kitti_00 shape, 64-128 best on the 10k-pose graph)
     bool xcd_affinity = true; // tile items of a front share an index class mod 8, i.e. an XCD and its L2 (CUGO_XCD_AFFINITY=0: listed front by front)
     int tile32_max_tiles = 64; // a level with at most this many 64x64 tiles is cut into 32x32 tiles (0: never)
+    // landmark-sharded run (one process per GPU): this rank's schedule holds the fronts of the elimination
+    // subtrees it OWNS plus the replicated top of the tree (CholPlan::owner); world == 1: everything
+    int rank = 0, world = 1;
     static CholOptions from_env();
 };
 
@@ -85,6 +88,20 @@ struct CholPlan
     // ea = extend-add of the pivot block columns (before potrf), eab = of the boundary columns
     // (same launch as trsm)
     int nc_max = 6; // widest pivot block in scalars (LDS sizing)
+
+    // ---- rank-owned elimination subtrees (world > 1) -------------------------------------------------
+    // owner[f] = rank that factors front f, or -1: the front belongs to the replicated top of the tree
+    // (every rank factors it).  Proportional mapping: the ranks of a node are split over its children by
+    // subtree work; a node whose range is down to one rank is owned, subtree and all, by that rank.
+    // The schedule of THIS rank (task lists, work items) holds only the fronts it owns or replicates.
+    std::vector<int32_t> owner;
+    // update blocks that cross the ownership boundary: fronts (front, stage, owner) owned by one rank whose
+    // parent is replicated — their update block (columns 6 ncb .. of the front, contiguous) is broadcast from
+    // the owner after `stage` so that every rank can run the parent's extend-add
+    std::vector<int32_t> xu_front, xu_stage, xu_owner;
+    // solution ranges that cross it: block columns [lo, hi) (new ordering) solved by `owner` alone
+    std::vector<int32_t> xx_lo, xx_hi, xx_owner;
+    double rank_flops = 0, top_flops = 0; // factorisation work of this rank's own subtrees / of the replicated top
 
     std::vector<int32_t> blk_front, blk_row, blk_col; // per Hsc block
     std::vector<uint8_t> blk_trans;

@@ -239,6 +239,37 @@ struct Engine::Impl : cugo_k::LaunchHook
         CUGO_HIP(hipStreamSynchronize(ctx.stream));
         xfn(d, n, op, xuser);
     }
+    // the sparse LL^T of a sharded run: each rank factors the elimination subtrees it owns and the replicated
+    // top of the tree (chol_symbolic: CholPlan::owner) and gets what crosses the boundary by broadcast
+    void bind_solver_exchange()
+    {
+        chol.rank = rank, chol.world = world;
+        if (world > 1)
+            chol.bcast = [this](double* d, size_t n, int root) { broadcast(d, n, root); };
+        else
+            chol.bcast = nullptr;
+        pattern_dirty = true; // the plan depends on (rank, world)
+    }
+    // broadcast of n doubles at d from rank `root` (update blocks / solution ranges of rank-owned elimination
+    // subtrees).  Callback form: op code 2 + root.
+    double bcast_bytes = 0;
+    int bcast_calls = 0;
+    void broadcast(double* d, size_t n, int root)
+    {
+        if (world <= 1 && !comm)
+            return;
+        bcast_bytes += 8.0 * (double)n;
+        bcast_calls++;
+        if (comm)
+        {
+            timed("exchange", [&] { comm->broadcast(d, n, root, ctx.stream); });
+            return;
+        }
+        if (!xfn)
+            throw std::runtime_error("cugo: sharded run without a communicator or an exchange function");
+        CUGO_HIP(hipStreamSynchronize(ctx.stream));
+        xfn(d, n, 2 + root, xuser);
+    }
 };
 
 const char* Engine::profile_name(int i)
@@ -312,6 +343,7 @@ void Engine::set_shard(int rank, int world, cugo_exchange_fn fn, void* user)
         throw std::runtime_error("cugo: bad shard");
     impl_->comm.reset();
     impl_->rank = rank, impl_->world = world, impl_->xfn = fn, impl_->xuser = user;
+    impl_->bind_solver_exchange();
 }
 
 void Engine::set_comm(std::shared_ptr<RcclComm> comm)
@@ -320,6 +352,7 @@ void Engine::set_comm(std::shared_ptr<RcclComm> comm)
         throw std::runtime_error("cugo: null communicator");
     impl_->rank = comm->rank(), impl_->world = comm->world(), impl_->xfn = nullptr, impl_->xuser = nullptr;
     impl_->comm = std::move(comm);
+    impl_->bind_solver_exchange();
 }
 
 void Engine::exchange_stats(double& bytes, int& calls) const
@@ -846,6 +879,21 @@ void Engine::fill_structure_stats(int B, double products, double offdiag_product
     sstats_.supernodes = m.chol.plan.n_super;
     sstats_.stages = m.chol.plan.n_stages;
     sstats_.front_bytes = 8.0 * (double)m.chol.plan.front_doubles;
+    {
+        const auto& pl = m.chol.plan;
+        sstats_.chol_rank_flops = pl.rank_flops, sstats_.chol_top_flops = pl.top_flops;
+        double bytes = 0;
+        for (size_t k = 0; k < pl.xu_front.size(); k++)
+        {
+            const int f = pl.xu_front[k];
+            const int64_t c0 = 6LL * pl.ncb[f], c1 = 6LL * pl.nb[f];
+            if (c1 > c0)
+                bytes += 8.0 * (double)((c1 - 1 - c0) * pl.ldf[f] + c1 + 1 - c0);
+        }
+        for (size_t k = 0; k < pl.xx_lo.size(); k++)
+            bytes += 8.0 * 6.0 * (pl.xx_hi[k] - pl.xx_lo[k]);
+        sstats_.chol_bcast_bytes = bytes, sstats_.chol_bcasts = (double)(pl.xu_front.size() + pl.xx_lo.size());
+    }
     sstats_.up_potrf_flops = m.chol.plan.up_potrf_flops;
     sstats_.up_trsm_flops = m.chol.plan.up_trsm_flops;
     sstats_.up_syrk_flops = m.chol.plan.up_syrk_flops;
@@ -1323,15 +1371,22 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
                 });
                 spec_queued = true;
             }
+            const bool flag_summed = sharded && m.chol.own_subtrees();
             if (sharded)
             {
-                m.exchange(m.d_scal.data() + 2, 2, 0);
+                // ranks that factor different subtrees see different zero-pivot flags: as a double the flag
+                // rides in the same sum all-reduce as F-hat and the scale
+                if (flag_summed)
+                    cugo_k::launch_flag_to_double(s, d_fail);
+                m.exchange(m.d_scal.data() + 2, flag_summed ? 3 : 2, 0);
                 CUGO_HIP(hipMemcpyAsync(m.h_scal.data() + 2, m.d_scal.data() + 2, 3 * sizeof(double),
                                         hipMemcpyDeviceToHost, s));
             }
             CUGO_HIP(hipStreamSynchronize(s));
             int32_t fail_flag;
             std::memcpy(&fail_flag, m.h_scal.data() + 4, sizeof fail_flag);
+            if (flag_summed)
+                fail_flag = m.h_scal[4] > 0.5 ? 1 : 0;
             const bool success = fail_flag == 0;
             const double Fhat = m.h_scal[2];
             const double scale = (success ? m.h_scal[3] : 0.0) + 1e-3;

@@ -47,6 +47,10 @@ struct StructureStats
     double hsc_blocks = 0, products = 0, nnzL = 0, chol_flops = 0, supernodes = 0, stages = 0,
            front_bytes = 0, offdiag_products = 0, up_potrf_flops = 0, up_trsm_flops = 0,
            up_syrk_flops = 0, up_ea_bytes = 0, backward_bytes = 0, schur_slots = 0;
+    // sharded run with rank-owned elimination subtrees: factorisation work of this rank's own subtrees / of the
+    // replicated top (same unit as chol_flops' model), bytes this rank's factorisation exchanges per trial
+    // (update blocks into the top + solution ranges), number of those broadcasts
+    double chol_rank_flops = 0, chol_top_flops = 0, chol_bcast_bytes = 0, chol_bcasts = 0;
 };
 
 enum ProfItem

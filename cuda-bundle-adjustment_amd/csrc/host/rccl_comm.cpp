@@ -23,6 +23,7 @@ struct Api
     decltype(&ncclCommInitRank) comm_init_rank = nullptr;
     decltype(&ncclCommDestroy) comm_destroy = nullptr;
     decltype(&ncclAllReduce) all_reduce = nullptr;
+    decltype(&ncclBroadcast) broadcast = nullptr;
     decltype(&ncclGetErrorString) error_string = nullptr;
 };
 
@@ -42,6 +43,7 @@ Api& api()
         a.comm_init_rank = reinterpret_cast<decltype(a.comm_init_rank)>(dlsym(a.handle, "ncclCommInitRank"));
         a.comm_destroy = reinterpret_cast<decltype(a.comm_destroy)>(dlsym(a.handle, "ncclCommDestroy"));
         a.all_reduce = reinterpret_cast<decltype(a.all_reduce)>(dlsym(a.handle, "ncclAllReduce"));
+        a.broadcast = reinterpret_cast<decltype(a.broadcast)>(dlsym(a.handle, "ncclBroadcast"));
         a.error_string = reinterpret_cast<decltype(a.error_string)>(dlsym(a.handle, "ncclGetErrorString"));
     });
     if (!a.handle || !a.get_unique_id || !a.comm_init_rank || !a.comm_destroy || !a.all_reduce)
@@ -86,6 +88,13 @@ void RcclComm::all_reduce(double* d_buf, size_t n, int op, hipStream_t s)
     check(api().all_reduce(d_buf, d_buf, n, ncclDouble, op == 0 ? ncclSum : ncclMax,
                            static_cast<ncclComm_t>(comm_), s),
           "ncclAllReduce");
+}
+
+void RcclComm::broadcast(double* d_buf, size_t n, int root, hipStream_t s)
+{
+    if (!api().broadcast)
+        throw std::runtime_error("cugo: librccl.so has no ncclBroadcast");
+    check(api().broadcast(d_buf, d_buf, n, ncclDouble, root, static_cast<ncclComm_t>(comm_), s), "ncclBroadcast");
 }
 
 } // namespace cugo_host

@@ -22,6 +22,8 @@ public:
     RcclComm& operator=(const RcclComm&) = delete;
     // in-place all-reduce of n doubles on `s` (op 0 = sum, 1 = max); asynchronous, no host sync
     void all_reduce(double* d_buf, size_t n, int op, hipStream_t s);
+    // in-place broadcast of n doubles from rank `root` on `s`; asynchronous
+    void broadcast(double* d_buf, size_t n, int root, hipStream_t s);
     int rank() const { return rank_; }
     int world() const { return world_; }
 

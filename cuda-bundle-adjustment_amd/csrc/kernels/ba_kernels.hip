@@ -1661,12 +1661,15 @@ __global__ __launch_bounds__(BS) void k_backsubst_landmarks(
     const int e = ebase + t;
     { // stream the block's Hpl slots into LDS (zeros past the end)
         const long nvalid = 9L * max(0, min(BS, ev.E - ebase));
+        // a workgroup past the last edge slot (the launch also covers the landmarks without edges; a SHARD
+        // can hold fewer slots than the graph has landmarks) reads slot 0: in bounds, never used
+        const size_t pbase = nvalid > 0 ? 9 * (size_t)ebase : 0;
         double2 v[9];
 #pragma unroll
         for (int i = 0; i < 9; i++)
         {
             const int idx = i * BS + t;
-            v[i] = ld_pair(Hpl, 9 * (size_t)ebase + (size_t)min((long)idx, max(nvalid - 1, 0L)));
+            v[i] = ld_pair(Hpl, pbase + (size_t)min((long)idx, max(nvalid - 1, 0L)));
         }
 #pragma unroll
         for (int i = 0; i < 9; i++)

@@ -2246,6 +2246,22 @@ __global__ __launch_bounds__(BIG) void k_backward_stage(CholPlanDev p,
     stamp(3, 7);
 }
 
+// x[perm[j]] = xnew[j] for all block rows (after the solution ranges of other ranks' subtrees have arrived)
+__global__ __launch_bounds__(CBS) void k_unpermute(CholPlanDev p, const double* __restrict__ xnew, double* __restrict__ xout)
+{
+    const int i = blockIdx.x * CBS + threadIdx.x;
+    if (i < 6 * p.n)
+        xout[6L * p.perm[i / 6] + i % 6] = xnew[i];
+}
+
+// the zero-pivot flag (int32 in an 8-byte slot) as a double in the same slot: ranks that factor different
+// subtrees see different flags, and the flag then rides in the sum all-reduce of the trial's scalars
+__global__ void k_flag_to_double(int32_t* __restrict__ flag)
+{
+    const int v = *flag;
+    *reinterpret_cast<double*>(flag) = v ? 1.0 : 0.0;
+}
+
 void ensure_lds(const void* fn, size_t bytes)
 {
     if (bytes > 48 * 1024)
@@ -2372,6 +2388,14 @@ void launch_chol_lead(hipStream_t s, const CholPlanDev& p, double* d_fronts, con
     ensure_lds(reinterpret_cast<const void*>(k_up_lead), trsyrk_lds() * sizeof(double));
     CUGO_LAUNCH(k_up_lead, dim3(nlead + neap + neab), dim3(BIG), trsyrk_lds() * sizeof(double), s, p,
                 d_fronts, d_lead, nlead, d_eap, neap, d_eab);
+}
+
+void launch_flag_to_double(hipStream_t s, int32_t* d_flag) { CUGO_LAUNCH(k_flag_to_double, dim3(1), dim3(1), 0, s, d_flag); }
+
+void launch_chol_unpermute(hipStream_t s, const CholPlanDev& p, const double* d_xnew, double* d_x)
+{
+    if (p.n > 0)
+        CUGO_LAUNCH(k_unpermute, dim3((6 * p.n + CBS - 1) / CBS), dim3(CBS), 0, s, p, d_xnew, d_x);
 }
 
 void launch_chol_backward_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,

@@ -194,6 +194,8 @@ void launch_chol_backward_stage(hipStream_t s, const CholPlanDev& p, double* d_f
                                 int ntasks, size_t lds_bytes, double* d_xnew, double* d_x,
                                 const int32_t* d_wl_gemv, int ngemv);
 // LDS bytes of the factor kernels (L11 + one 64-row tile) and of the backward kernel
+void launch_flag_to_double(hipStream_t s, int32_t* d_flag); // int32 0 / 1 -> double 0.0 / 1.0 in the same 8-byte slot
+void launch_chol_unpermute(hipStream_t s, const CholPlanDev& p, const double* d_xnew, double* d_x);
 void set_debug_stamps(long long* d_buf); // diagnostic s_memtime stamps (nullptr = off)
 size_t chol_lds_factor_bytes(int nc_max);
 size_t chol_lds_backward_bytes(int nc_max, long ld_max);

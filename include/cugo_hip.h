@@ -258,7 +258,9 @@ int cugo_graph_set_information(cugo_graph* g, int dim, double info);
 int cugo_graph_set_robust_kernel(cugo_graph* g, int dim, int type, double delta);
 /* multi-GPU: this process handles shard `rank` of `world` (landmark ranges).  exchange() is
  * called on the host with a DEVICE buffer that must be all-reduced in place over all ranks
- * (op 0 = sum, 1 = max) before it returns (RCCL via torch.distributed in bench.py). */
+ * (op 0 = sum, 1 = max) before it returns, or — op >= 2 — overwritten on every rank with rank
+ * (op - 2)'s content (a broadcast: the update blocks and solution ranges of the elimination subtrees a
+ * rank owns in the sparse LL^T; CUGO_OWN_SUBTREES=0 keeps the factorisation replicated and never asks). */
 typedef void (*cugo_exchange_fn)(void* d_buf, size_t n_doubles, int op, void* user);
 /* ref: EdgeSet::setOutlierThreshold (src/optimisable_graph.h:737-740) + updateEdges
  * (optimisable_graph.hpp:603-640): at the end of cugo_graph_optimize every edge of the set (dim 2

@@ -882,9 +882,12 @@ def run_sharded_in_threads(d, world, niter, want_sstats=False):
             with lock:
                 bufs[rank] = host
             barrier.wait()
-            tot = bufs[0].copy()
-            for r in range(1, world):  # fixed rank order
-                tot = tot + bufs[r] if op == 0 else np.maximum(tot, bufs[r])
+            if op >= 2:  # broadcast from rank op - 2 (rank-owned elimination subtrees)
+                tot = bufs[op - 2].copy()
+            else:
+                tot = bufs[0].copy()
+                for r in range(1, world):  # fixed rank order
+                    tot = tot + bufs[r] if op == 0 else np.maximum(tot, bufs[r])
             barrier.wait()
             cugo.check(cugo.lib().cugo_memcpy_h2d(ctxs[rank].h, C.c_void_p(ptr), tot.ctypes.data_as(C.c_void_p), 8 * n))
         return fn
@@ -904,6 +907,59 @@ def run_sharded_in_threads(d, world, niter, want_sstats=False):
     for c in ctxs:
         c.close()
     return results
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_rank_owned_elimination_subtrees_match_unsharded(oracle_lib, world, monkeypatch):
+    """a sharded run factors the sparse LL^T by rank-owned elimination subtrees (chol_symbolic.cpp:
+    CholPlan::owner): every rank factors its own subtrees and the replicated top of the tree, the update
+    blocks that enter the top and the other ranks' solution ranges arrive by broadcast.  Same trajectory
+    as the unsharded run and as the replicated form (CUGO_OWN_SUBTREES=0); the work really is split."""
+    d, prob = synth_problem(oracle_lib, 700, 12000, 50000, seed=21, lc=150)
+    single = run_graph(d, 6)
+    res = run_sharded_in_threads(d, world, 6, want_sstats=True)
+    ref = prob.optimize(6)
+    total = None
+    for r in range(world):
+        assert_trajectories_match(res[r]["stats"], single["stats"], 1e-11)
+        assert_trajectories_match(res[r]["stats"], ref, 1e-10)
+        assert rmse(res[r]["pose"], single["pose"]) < 1e-11 and rmse(res[r]["lm"], single["lm"]) < 1e-10
+        ss = res[r]["sstats"]
+        assert ss["chol_bcasts"] >= 2 and ss["chol_bcast_bytes"] > 0
+        assert ss["chol_top_flops"] == res[0]["sstats"]["chol_top_flops"]
+        total = (total or 0.0) + ss["chol_rank_flops"]
+    top = res[0]["sstats"]["chol_top_flops"]
+    own = [res[r]["sstats"]["chol_rank_flops"] for r in range(world)]
+    assert all(o > 0 for o in own) and max(own) < 0.75 * (total + top)   # nobody factors (nearly) everything
+    assert [s["chi2"] for s in res[0]["stats"]] == [s["chi2"] for s in res[1]["stats"]]  # ranks agree bitwise
+    monkeypatch.setenv("CUGO_OWN_SUBTREES", "0")
+    rep = run_sharded_in_threads(d, world, 6, want_sstats=True)
+    assert rep[0]["sstats"]["chol_bcasts"] == 0
+    assert_trajectories_match(rep[0]["stats"], res[0]["stats"], 1e-11)
+
+
+def test_synth10k_eight_shards_with_owned_subtrees():
+    """BASELINE config 4 (10 000 poses / 1 M landmarks / 5 M edges) in the form it runs on 8 GPUs — eight
+    landmark shards, the LL^T split into rank-owned elimination subtrees below a replicated top — emulated
+    with eight optimisers in threads on one GPU: the first LM iterations match the unsharded run at 1e-10,
+    and per rank the Cholesky work and the bytes exchanged are what the plan says."""
+    d = cugo.synth(10000, 1000000, 5000000, seed=10000, n_loop_closures=0, stereo_fraction=0.0)
+    single = run_graph(d, 2)
+    res = run_sharded_in_threads(d, 8, 2, want_sstats=True)
+    top = res[0]["sstats"]["chol_top_flops"]
+    own = [res[r]["sstats"]["chol_rank_flops"] for r in range(8)]
+    whole = top + sum(own)
+    for r in range(8):
+        assert_trajectories_match(res[r]["stats"], single["stats"], 1e-10)
+        assert res[r]["sstats"]["chol_top_flops"] == top
+        # a rank's factorisation: its own subtrees + the replicated top — well under the whole
+        assert own[r] + top < 0.45 * whole
+        assert res[r]["sstats"]["chol_bcast_bytes"] < 0.5 * 8 * 36 * res[r]["sstats"]["hsc_blocks"]
+    assert max(own) < 1.6 * (sum(own) / 8)   # balanced within 60 %
+    print("config 4, 8 shards: replicated top %.1f %% of the factorisation, own shares %s %%; broadcast %.1f MB per trial "
+          "(all-reduce payload %.1f MB)" % (100 * top / whole, [round(100 * o / whole, 1) for o in own],
+                                            res[0]["sstats"]["chol_bcast_bytes"] / 1e6,
+                                            8 * 36 * res[0]["sstats"]["hsc_blocks"] / 1e6))
 
 
 def test_kitti00_two_shards_match_unsharded(kitti00):

@@ -394,3 +394,29 @@ def test_changing_the_shard_forces_a_full_initialize(lib):
     f.initialize()
     assert part0 == int(f.structure_stats()["offdiag_products"]) and 0 < part0 < offdiag
     f.close()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_plan_only_rank_owned_subtrees_partition_the_factorisation(lib, world):
+    """rank-owned elimination subtrees of a sharded run (chol_symbolic.cpp, CholPlan::owner), host side only:
+    every rank sees the same replicated top, the ranks' own shares add up with it to the whole factorisation
+    (the unsharded plan's), and no rank keeps (nearly) all of it"""
+    d = cugo.synth(900, 16000, 66000, seed=4, n_loop_closures=200)
+    g = cugo.graph_from_arrays(d, plan_only=True)
+    g.initialize()
+    whole = g.structure_stats()
+    g.close()
+    assert whole["chol_top_flops"] == 0 and whole["chol_rank_flops"] > 0
+    own, top = [], None
+    for r in range(world):
+        g = cugo.graph_from_arrays(d, plan_only=True)
+        g.set_shard(r, world, lambda ptr, n, op: None)
+        g.initialize()
+        s = g.structure_stats()
+        g.close()
+        assert s["supernodes"] == whole["supernodes"] and s["nnzL"] == whole["nnzL"]
+        top = s["chol_top_flops"] if top is None else top
+        assert s["chol_top_flops"] == top and s["chol_bcasts"] >= 1
+        own.append(s["chol_rank_flops"])
+    assert abs(sum(own) + top - whole["chol_rank_flops"]) <= 1e-9 * whole["chol_rank_flops"]
+    assert all(o > 0 for o in own) and max(own) + top < 0.9 * whole["chol_rank_flops"]

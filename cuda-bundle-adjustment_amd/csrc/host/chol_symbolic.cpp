@@ -757,66 +757,48 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
     P.xx_lo.clear(), P.xx_hi.clear(), P.xx_owner.clear();
     if (opt.world > 1)
     {
-        // children lists of the virtual root
-        std::vector<int> roots;
+        // Candidates = subtrees that will go to one rank each; start from the roots of the forest.  While
+        // the heaviest candidate is more than half of a rank's fair share, it is replaced by its children
+        // (its root joins the replicated top): the candidates become many and small compared with a rank's
+        // load.  Then largest first, each to the least loaded rank (ties: the lower rank).  Deterministic,
+        // the same on every rank.
+        double total_work = 0;
+        for (int s = 0; s < ns; s++)
+            total_work += work[s];
+        const double fair = total_work / opt.world;
+        std::vector<int> cand;
         for (int s = 0; s < ns; s++)
             if (P.sparent[s] < 0)
-                roots.push_back(s);
-        struct Item
+                cand.push_back(s);
+        for (;;)
         {
-            std::vector<int> nodes; // sibling subtrees handled together
-            int r0, r1;             // rank range
-        };
-        std::vector<Item> stack;
-        stack.push_back({roots, 0, opt.world});
-        auto own_subtree = [&](int root, int r) {
-            // a subtree is a contiguous range of supernodes ending at its root (postorder)
-            std::vector<int> st2{root};
+            int big = -1;
+            for (size_t i = 0; i < cand.size(); i++)
+                if (P.child_ptr[cand[i] + 1] > P.child_ptr[cand[i]] && (big < 0 || sub[cand[i]] > sub[cand[big]]))
+                    big = (int)i;
+            if (big < 0 || sub[cand[big]] <= 0.5 * fair)
+                break;
+            const int v = cand[big];
+            cand.erase(cand.begin() + big);
+            P.owner[v] = -1; // (the default; spelled out: v is replicated)
+            for (int k = P.child_ptr[v]; k < P.child_ptr[v + 1]; k++)
+                cand.push_back(P.child[k]);
+        }
+        std::stable_sort(cand.begin(), cand.end(), [&](int a2, int b2) { return sub[a2] != sub[b2] ? sub[a2] > sub[b2] : a2 < b2; });
+        std::vector<double> load(opt.world, 0.0);
+        for (int v : cand)
+        {
+            const int r = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+            load[r] += sub[v];
+            std::vector<int> st2{v};
             while (!st2.empty())
             {
-                const int v = st2.back();
+                const int u = st2.back();
                 st2.pop_back();
-                P.owner[v] = r;
-                for (int k = P.child_ptr[v]; k < P.child_ptr[v + 1]; k++)
+                P.owner[u] = r;
+                for (int k = P.child_ptr[u]; k < P.child_ptr[u + 1]; k++)
                     st2.push_back(P.child[k]);
             }
-        };
-        while (!stack.empty())
-        {
-            Item it = std::move(stack.back());
-            stack.pop_back();
-            if (it.nodes.empty())
-                continue;
-            const int nr = it.r1 - it.r0;
-            if (nr <= 1)
-            {
-                for (int v : it.nodes)
-                    own_subtree(v, it.r0);
-                continue;
-            }
-            if (it.nodes.size() == 1)
-            { // one subtree for several ranks: its root is replicated, the ranks go to its children
-                const int v = it.nodes[0];
-                P.owner[v] = -1;
-                std::vector<int> ch(P.child.begin() + P.child_ptr[v], P.child.begin() + P.child_ptr[v + 1]);
-                stack.push_back({ch, it.r0, it.r1});
-                continue;
-            }
-            // several subtrees, several ranks: two groups of balanced work (largest first, to the lighter
-            // group), the ranks split in proportion (at least one each)
-            std::vector<int> byw(it.nodes);
-            std::stable_sort(byw.begin(), byw.end(), [&](int a, int b) { return sub[a] > sub[b]; });
-            std::vector<int> ga, gb;
-            double wa = 0, wb = 0;
-            for (int v : byw)
-                if (wa <= wb)
-                    ga.push_back(v), wa += sub[v];
-                else
-                    gb.push_back(v), wb += sub[v];
-            int na = (int)std::lround(nr * wa / std::max(wa + wb, 1.0));
-            na = std::max(1, std::min(nr - 1, na));
-            stack.push_back({ga, it.r0, it.r0 + na});
-            stack.push_back({gb, it.r0 + na, it.r1});
         }
         for (int s = 0; s < ns; s++)
         {

@@ -1309,6 +1309,135 @@ __global__ __launch_bounds__(BS) void k_hsc_offdiag(int nblocks,
         Hsc[36 * (size_t)k + lane] = -acc;
 }
 
+// ---------------------------------------------------------------- Schur: off-diagonal, row strips
+// The same sums as k_hsc_offdiag — same products, same order, bit for bit — with ONE workgroup per block
+// row p of Hsc instead of one wave per block anywhere.  Every product of the row has its T operand among
+// the edges of pose p (T_e Hpl_e'^T: e an edge of p, e' the edge of e's landmark seen by the column's pose),
+// so the T blocks of the pose's ~420 edges are staged in LDS ONCE per row (61 KB: each T block is read from
+// memory once per Schur complement instead of once per product, 2.6x less on the kitti_00 shape) and only the
+// Hpl operands are gathered per product — half the gather instructions and lines of the block-per-wave form,
+// and the rows of a neighbourhood (same XCD: xcd_contiguous_item) gather the same Hpl blocks out of L2.
+// The lists carry, beside the slot of the T edge, its position in the pose's edge list (off_pi, built once
+// per structure: k_list_pos).  A row whose pose has more edges than fit (HS_CAP) gathers T as before.
+constexpr int HS_BS = 1024;
+constexpr int HS_W = HS_BS / 64;
+constexpr int HS_CAP = 704; // T blocks of a pose that fit the LDS stage (99 KB)
+constexpr size_t hs_lds_bytes() { return (size_t)HS_CAP * 18 * sizeof(double) + (size_t)HS_W * (OD_CH * 9 + 1) * sizeof(double2) + (size_t)HS_W * 16 * sizeof(int32_t); }
+
+// pos[e] = position of slot e in the edge list of its pose
+__global__ __launch_bounds__(BS) void k_pose_pos(EV ev, int n, int32_t* __restrict__ pos)
+{
+    const int i = blockIdx.x * BS + threadIdx.x;
+    if (i >= n)
+        return;
+    const int e = ev.pose_edge[i];
+    pos[e] = i - ev.pose_ptr[ev.pose[e]];
+}
+__global__ __launch_bounds__(BS) void k_list_pos(size_t M, const int32_t* __restrict__ off_ei,
+                                                 const int32_t* __restrict__ pos, int32_t* __restrict__ off_pi)
+{
+    const size_t i = (size_t)blockIdx.x * BS + threadIdx.x;
+    if (i < M)
+        off_pi[i] = pos[off_ei[i]];
+}
+
+template <typename S>
+__global__ __launch_bounds__(HS_BS) void k_hsc_offdiag_strip(EV ev, const int32_t* __restrict__ rowptr,
+                                                            const int32_t* __restrict__ off_ptr,
+                                                            const int32_t* __restrict__ off_ei,
+                                                            const int32_t* __restrict__ off_pi,
+                                                            const int32_t* __restrict__ off_ej,
+                                                            const S* __restrict__ Hpl, const S* __restrict__ T,
+                                                            double* __restrict__ Hsc)
+{
+    extern __shared__ double hs_lds[];
+    double* sTrow = hs_lds;                                                        // [HS_CAP][18]
+    double2* stage = reinterpret_cast<double2*>(hs_lds + (size_t)HS_CAP * 18);     // [HS_W][OD_CH*9+1]
+    int32_t* spi = reinterpret_cast<int32_t*>(stage + HS_W * (OD_CH * 9 + 1));     // [HS_W][16]
+    const int p = xcd_contiguous_item(ev.P);
+    if (p >= ev.P)
+        return;
+    const int b0 = rowptr[p] + 1, b1 = rowptr[p + 1]; // the row's off-diagonal blocks
+    if (b0 >= b1)
+        return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int i0 = ev.pose_ptr[p], np = ev.pose_ptr[p + 1] - i0;
+    const bool in_lds = np <= HS_CAP; // (uniform)
+    if (in_lds)
+    { // the T blocks of the pose's edges, in list order: pair `q` of list entry `i` (9 pairs per 144-B block)
+        double2* dst = reinterpret_cast<double2*>(sTrow);
+        for (int idx = tid; idx < 9 * np; idx += HS_BS)
+        {
+            const int i = idx / 9, q = idx - 9 * i;
+            dst[idx] = ld_pair(T, 9 * (size_t)ev.pose_edge[i0 + i] + q);
+        }
+    }
+    __syncthreads();
+    const int lc = lane < 36 ? lane : 35; // idle lanes shadow lane 35
+    const int r = lc % 6, c = lc / 6;
+    const int pj = min(lane / 9, 6), part = lane - 9 * (lane / 9); // lane 63 shadows product 6
+    const bool writer = lane < 63;
+    double2* st = stage + w * (OD_CH * 9 + 1);
+    const double* sH = reinterpret_cast<const double*>(st);
+    int32_t* pis = spi + w * 16;
+    for (int k = b0 + w; k < b1; k += HS_W)
+    {
+        const int beg = off_ptr[k], end = off_ptr[k + 1];
+        double acc = 0;
+        // software pipeline as in k_hsc_offdiag: Hpl operands one chunk ahead, list entries two ahead
+        int j0 = min(beg + pj, end - 1), j1 = min(beg + pj + 7, end - 1);
+        int ej0 = off_ej[j0], ej1 = off_ej[j1];
+        int pi0 = in_lds ? off_pi[j0] : off_ei[j0], pi1 = in_lds ? off_pi[j1] : off_ei[j1];
+        double2 hv0 = ld_pair(Hpl, 9 * (size_t)ej0 + part), hv1 = ld_pair(Hpl, 9 * (size_t)ej1 + part);
+        int pw0 = pi0, pw1 = pi1;
+        j0 = min(beg + OD_CH + pj, end - 1), j1 = min(beg + OD_CH + pj + 7, end - 1);
+        ej0 = off_ej[j0], ej1 = off_ej[j1];
+        pi0 = in_lds ? off_pi[j0] : off_ei[j0], pi1 = in_lds ? off_pi[j1] : off_ei[j1];
+        for (int idx = beg; idx < end; idx += OD_CH)
+        {
+            if (writer)
+            {
+                st[9 * pj + part] = hv0, st[63 + 9 * pj + part] = hv1;
+                if (part == 0)
+                    pis[pj] = pw0, pis[7 + pj] = pw1;
+            }
+            if (idx + OD_CH < end)
+            {
+                hv0 = ld_pair(Hpl, 9 * (size_t)ej0 + part), hv1 = ld_pair(Hpl, 9 * (size_t)ej1 + part);
+                pw0 = pi0, pw1 = pi1;
+                j0 = min(idx + 2 * OD_CH + pj, end - 1), j1 = min(idx + 2 * OD_CH + pj + 7, end - 1);
+                ej0 = off_ej[j0], ej1 = off_ej[j1];
+                pi0 = in_lds ? off_pi[j0] : off_ei[j0], pi1 = in_lds ? off_pi[j1] : off_ei[j1];
+            }
+            wave_sync_lds();
+            const int n = min(OD_CH, end - idx);
+#pragma unroll
+            for (int u = 0; u < OD_CH; u++)
+                if (u < n) // wave-uniform
+                {
+                    double t0, t1, t2;
+                    if (in_lds)
+                    {
+                        const double* Tt = sTrow + 18 * pis[u];
+                        t0 = Tt[r], t1 = Tt[6 + r], t2 = Tt[12 + r];
+                    }
+                    else
+                    { // (a pose with more edges than the stage holds: its T blocks straight from memory)
+                        const S* Tg = T + 18 * (size_t)pis[u];
+                        t0 = (double)Tg[r], t1 = (double)Tg[6 + r], t2 = (double)Tg[12 + r];
+                    }
+                    double s = t0 * sH[18 * u + c];
+                    s = fma(t1, sH[18 * u + 6 + c], s);
+                    s = fma(t2, sH[18 * u + 12 + c], s);
+                    acc += s;
+                }
+            wave_sync_lds(); // the slot is rewritten by the next iteration
+        }
+        if (lane < 36)
+            Hsc[36 * (size_t)k + lane] = -acc;
+    }
+}
+
 // ---------------------------------------------------------------- Schur: pose rows ------
 // The whole block row p of the Schur complement in ONE workgroup (round 3; replaces k_schur_edges' T
 // stream, k_hsc_offdiag and k_hsc_diag when the engine asks for it):
@@ -1895,7 +2024,19 @@ static void launch_schur_t(hipStream_t s, const cugo_edges& e, const cugo_hsc_st
     if (ev.E > 0 && !have_T) // have_T: the build pass left invHll and T for this lambda (launch_build)
         CUGO_LAUNCH_T(k_schur_edges, S, dim3(div_up(ev.E, BS)), dim3(BS), 0, s, ev, lambda, d_Hll,
                       d_Hpl, d_invHll, d_T);
-    if (hs.n_blocks > 0)
+    if (hs.n_blocks > 0 && rows.d_off_pi && hs.d_rowptr && ev.P > 0)
+    { // one workgroup per block row, the row's T blocks staged in LDS (k_hsc_offdiag_strip)
+        static bool attr_set[2] = {false, false};
+        if (!attr_set[sizeof(S) == 4])
+        {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_hsc_offdiag_strip<S>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)hs_lds_bytes());
+            attr_set[sizeof(S) == 4] = true;
+        }
+        CUGO_LAUNCH_T(k_hsc_offdiag_strip, S, dim3(xcd_grid(ev.P)), dim3(HS_BS), hs_lds_bytes(), s, ev, hs.d_rowptr,
+                      hs.d_off_ptr, hs.d_off_ei, rows.d_off_pi, hs.d_off_ej, d_Hpl, (const S*)d_T, d_Hsc);
+    }
+    else if (hs.n_blocks > 0)
         CUGO_LAUNCH_T(k_hsc_offdiag, S, dim3(div_up(hs.n_blocks, BS / 64)), dim3(BS), 0, s,
                       hs.n_blocks, hs.d_off_ptr, hs.d_off_ei, hs.d_off_ej, d_Hpl, (const S*)d_T, d_Hsc);
     if (ev.P > 0)
@@ -1921,6 +2062,17 @@ bool schur_rows_usable(const cugo_hsc_struct& hs, int max_row_nnz)
 {
     const size_t lds = (36 * (size_t)std::max(max_row_nnz, 1) + hr_fixed_doubles()) * sizeof(double);
     return hs.d_rowptr && hs.d_colind && lds <= 150 * 1024;
+}
+
+void launch_list_pos(hipStream_t s, const cugo_edges& e, int n_list, size_t M, const int32_t* d_off_ei,
+                     int32_t* d_pose_pos, int32_t* d_off_pi)
+{
+    const EV ev = make_ev(e);
+    if (n_list > 0)
+        CUGO_LAUNCH(k_pose_pos, dim3(div_up(n_list, BS)), dim3(BS), 0, s, ev, n_list, d_pose_pos);
+    if (M > 0)
+        CUGO_LAUNCH(k_list_pos, dim3((unsigned)((M + BS - 1) / BS)), dim3(BS), 0, s, M, d_off_ei, (const int32_t*)d_pose_pos,
+                    d_off_pi);
 }
 
 void launch_pose_rec(hipStream_t s, const cugo_edges& e, int n, int32_t* d_rec)

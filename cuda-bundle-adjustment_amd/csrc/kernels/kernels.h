@@ -74,7 +74,14 @@ struct SchurRows
 {
     const int32_t* d_pose_rec = nullptr; // [n][4]: slot, end of its landmark's slots, landmark, flags
     int max_row_nnz = 0;
+    // row-strip form of the gather kernels (k_hsc_offdiag_strip): per product, the position of its T edge in
+    // the edge list of its pose (launch_list_pos).  Given, the off-diagonal blocks are formed one block row per
+    // workgroup with the row's T blocks staged in LDS once; same sums, bit for bit
+    const int32_t* d_off_pi = nullptr;
 };
+// d_pose_pos [n_edges] scratch/out: position of every slot in its pose's list; d_off_pi [M] out
+void launch_list_pos(hipStream_t s, const cugo_edges& ev, int n_list, size_t M, const int32_t* d_off_ei,
+                     int32_t* d_pose_pos, int32_t* d_off_pi);
 void launch_pose_rec(hipStream_t s, const cugo_edges& ev, int n, int32_t* d_rec);
 // false: the row kernel cannot take this structure (no pattern on the device, or a block row too long for
 // its LDS accumulators): launch_schur then runs the gather kernels, which need d_T

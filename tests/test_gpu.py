@@ -398,9 +398,11 @@ def rmse(a, b):
     return float(np.sqrt(np.mean((a - b) ** 2)))
 
 
-@pytest.mark.parametrize("subtree_stage", [False, True, "lookahead", "two_phase", "hsc_rows", "potrf6"])
+@pytest.mark.parametrize("subtree_stage", [False, True, "lookahead", "two_phase", "hsc_rows", "hsc_strip", "potrf6"])
 def test_medium_synthetic_vs_oracle(oracle_lib, subtree_stage, monkeypatch):
-    if subtree_stage == "hsc_rows":  # the opt-in Schur complement by whole block rows (k_hsc_rows)
+    if subtree_stage == "hsc_strip":  # the opt-in row-strip form of the off-diagonal gather (k_hsc_offdiag_strip)
+        monkeypatch.setenv("CUGO_HSC_STRIP", "1")
+    elif subtree_stage == "hsc_rows":  # the opt-in Schur complement by whole block rows (k_hsc_rows)
         monkeypatch.setenv("CUGO_HSC_ROWS", "1")
     elif subtree_stage == "potrf6":  # the 6-column LDS panels of rounds 1-2 instead of the register panels
         monkeypatch.setenv("CUGO_PANEL16", "0")

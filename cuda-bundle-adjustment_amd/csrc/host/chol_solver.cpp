@@ -118,7 +118,7 @@ void cugo_chol::upload(hipStream_t s)
         const char* e = std::getenv("CUGO_EA_LDS");
         D.ea_lds = !(e && e[0] == '0');
         const char* e16 = std::getenv("CUGO_PANEL16");
-        D.panel16 = (e16 && e16[0] == '0') ? 0 : (e16 && e16[0] == '2') ? 2 : 1;
+        D.panel16 = !(e16 && e16[0] == '0');
     }
     D.l21off = b64 + o_l21off, D.l21 = d_l21.data();
     D.ldf = b64 + o_ldf, D.alias_of = b32 + o_alias, D.bw_np = b32 + o_bwnp, D.la_np = b32 + o_lanp;

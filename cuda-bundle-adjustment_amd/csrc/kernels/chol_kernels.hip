@@ -933,7 +933,7 @@ __device__ __forceinline__ void p16_utask(const double* __restrict__ Ls, const d
 // F11 (ncp x ncp in LDS, lower triangle, identity padding) -> W = F11^-1/2-inverse in global memory.
 // lds: Ls | invd | rsv | Vs | Ub  (p16::LDS_DOUBLES doubles)
 __device__ __forceinline__ void dev_potrf16(int ncp, double* __restrict__ lds, double* __restrict__ Wg,
-                                            int32_t* __restrict__ fail, int variant = 1)
+                                            int32_t* __restrict__ fail)
 {
     double* Ls = lds;
     double* invd = lds + p16::OFF_INV;
@@ -988,10 +988,8 @@ __device__ __forceinline__ void dev_potrf16(int ncp, double* __restrict__ lds, d
         }
         else
         {
-            // (variant 2, experiment: the other waves start a little later, so that the panel's 16 loads are at
-            // the head of the CU's LDS queue instead of behind ~150 operand loads issued in the same cycle)
-            if (variant == 2)
-                __builtin_amdgcn_s_sleep(3);
+            // (measured, not kept: the other waves starting ~200 cycles later so that the panel's 16 loads sit at the
+            // head of the CU's LDS queue — 11.55 vs 11.54 ms per step)
             // one task per wave: the s + 1 blocks of row s of U, then the remaining trailing tiles.
             // Waves w and w + 4 share a SIMD (observed placement; speed only): the tasks go first to the
             // waves that do not sit beside a panel wave (2, 3 mod 4), the heavy ones (U blocks) first
@@ -2019,7 +2017,7 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
     }
     if (p.panel16)
     { // 16-column L D L^T panels, W built behind them (dev_potrf16)
-        dev_potrf16(ncp, lds, p.winv + fwoff, fail, p.panel16);
+        dev_potrf16(ncp, lds, p.winv + fwoff, fail);
         stamp_value(0, 6, ncs);
         stamp(0, 7);
         return;

@@ -3,7 +3,7 @@
 # trace domains besides --kernel-trace).  Afterwards: tools/collect_profiles.sh copies the summaries
 # into profiles/.   gpurun --timeout 1100 -- bash tools/refresh_profiles.sh
 set -e
-R=r02
+R=${R:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests.log 2>&1
@@ -21,13 +21,4 @@ for W in kitti00 synth10k; do
   done
   python tools/pmc_summary.py gpurun_out/pmc_${W}_FETCH_SIZE gpurun_out/pmc_${W}_WRITE_SIZE > gpurun_out/pmc_${W}_summary.txt 2>&1
 done
-# the landmark-major Schur plan (opt-in): its traffic and L2 behaviour next to the default gather kernels
-for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
-  tag=$(echo $c | tr ' ' '_')
-  rm -rf gpurun_out/pmc_plan_$tag
-  CUGO_SCHUR_PLAN=1 timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc_plan_$tag -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/pmc_plan_$tag.json 2> gpurun_out/pmc_plan_$tag.err
-done
-rm -rf gpurun_out/pmc_kitti00_TCC
-timeout -k 10 400 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/pmc_kitti00_TCC -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/pmc_kitti00_TCC.json 2> gpurun_out/pmc_kitti00_TCC.err
-python tools/pmc_summary.py gpurun_out/pmc_plan_FETCH_SIZE gpurun_out/pmc_plan_WRITE_SIZE gpurun_out/pmc_plan_TCC_HIT_sum_TCC_MISS_sum gpurun_out/pmc_kitti00_TCC > gpurun_out/pmc_plan_summary.txt 2>&1
 tail -2 gpurun_out/gpu_tests.log

@@ -84,6 +84,9 @@ def compulsory_bytes(E, Em, Es, P, L, B, f32):
         # SURVEY 8(d) counts 288 E + 288 B for the whole H-side: split over the two kernels
         "k_hsc_offdiag": blk * E + 288.0 * max(B - P, 0),
         "k_hsc_diag": blk * E + 288.0 * P + 288.0 * P + 48.0 * P + 24.0 * L,
+        # the same two kernels on the matrix cores (the default): same arrays, same bytes
+        "k_hsc_offdiag_mfma": blk * E + 288.0 * max(B - P, 0),
+        "k_hsc_diag_mfma": blk * E + 288.0 * P + 288.0 * P + 48.0 * P + 24.0 * L,
         "k_hsc_landmarks": 2 * blk * E + 8.0 * E,
         "k_hsc_reduce": 288.0 * B + 288.0 * P,
         "k_backsubst_landmarks": blk * E + 5.0 * E + 72.0 * L + 24.0 * L + 24.0 * L + 48.0 * L,

@@ -269,7 +269,18 @@ int cugo_chol_plan_array(cugo_chol* s, const char* name, const int32_t** out)
     CUGO_PLAN_FIELD(blk_front);
     CUGO_PLAN_FIELD(blk_row);
     CUGO_PLAN_FIELD(blk_col);
+    CUGO_PLAN_FIELD(alias_of);
+    CUGO_PLAN_FIELD(asm_map);
+    CUGO_PLAN_FIELD(wl);
 #undef CUGO_PLAN_FIELD
+    if (n == "asm_info")
+    { // [first assembly item in wl, items, then per front: offset of its map in asm_map or -1]
+        s->asm_info.assign(1, P.asm0);
+        s->asm_info.push_back(P.nasm);
+        for (int64_t o : P.asm_off)
+            s->asm_info.push_back((int32_t)o);
+        v = &s->asm_info;
+    }
     if (n == "blk_trans")
         v = &s->trans32;
     if (!v)

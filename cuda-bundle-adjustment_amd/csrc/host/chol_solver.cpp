@@ -9,13 +9,14 @@
 
 using namespace cugo_host;
 
-void cugo_chol::upload(hipStream_t s)
+// host half of upload(): the plan's index arrays and per-task / per-item records packed into two vectors (done
+// by analyze_host, i.e. beside initialize() when the structure is analysed on the helper thread)
+void cugo_chol::pack()
 {
     const CholPlan& P = plan;
     // All index arrays of the plan travel in TWO host-to-device copies (a pageable copy costs
     // ~20 us whatever its size, and there are 23 arrays: 0.4 ms of a cold call on a small graph)
-    std::vector<int32_t> pack32;
-    std::vector<int64_t> pack64;
+    pack32.clear(), pack64.clear();
     auto put32 = [&pack32](const std::vector<int32_t>& v) {
         const size_t o = pack32.size();
         pack32.insert(pack32.end(), v.begin(), v.end());
@@ -82,13 +83,45 @@ void cugo_chol::upload(hipStream_t s)
         m[3] = 6 * P.ncb[f], m[4] = 6 * (P.nb[f] - P.ncb[f]);
         const int64_t q[4] = {P.off[f], P.ldf[f], P.woff[f], P.l21off[f]};
         std::memcpy(m + 8, q, sizeof q);
+        if ((int)i >= P.asm0 && (int)i < P.asm0 + P.nasm)
+        { // assembly item: block rows of the front, where its map starts, and whether these block columns hold
+          // anything but zeros (most of them are fill / update block: those need no map and no Hsc loads)
+            const int64_t nb = P.nb[f], mo = P.asm_off[f];
+            m[5] = (int32_t)nb;
+            std::memcpy(m + 6, &mo, sizeof mo);
+            bool any = false;
+            for (int64_t cb = m[1]; cb < m[2]; cb++)
+            {
+                any = any || P.asm_map[mo + cb] >= 0;
+                const int64_t c0 = mo + nb + cb * nb - cb * (cb - 1) / 2;
+                for (int64_t k = 0; k < nb - cb && !any; k++)
+                    any = P.asm_map[c0 + k] >= 0;
+            }
+            m[4] = any ? 1 : 0;
+        }
     }
     const size_t o_fat = put32(fat);
+    const size_t o_asm_map = put32(P.asm_map);
     const size_t o_trans = pack32.size(); // bytes
     pack32.resize(o_trans + (P.blk_trans.size() + 3) / 4 + 4, 0);
     if (!P.blk_trans.empty())
         std::memcpy(pack32.data() + o_trans, P.blk_trans.data(), P.blk_trans.size());
+    const size_t o_asm_off = put64(P.asm_off);
     const size_t o_off = put64(P.off), o_woff = put64(P.woff), o_l21off = put64(P.l21off), o_ldf = put64(P.ldf);
+    po = {o_ncb, o_nb, o_col0, o_alias, o_bwnp, o_lanp, o_rows_ptr, o_rows, o_child_ptr, o_child, o_rel_ptr, o_rel,
+          o_task_ptr, o_task_fronts, o_blk_front, o_blk_row, o_blk_col, o_perm, o_col_front, o_wl, o_ea1, o_tmeta,
+          o_fat, o_asm_map, o_trans, o_asm_off, o_off, o_woff, o_l21off, o_ldf};
+}
+
+void cugo_chol::upload(hipStream_t s)
+{
+    const CholPlan& P = plan;
+    const size_t o_ncb = po[0], o_nb = po[1], o_col0 = po[2], o_alias = po[3], o_bwnp = po[4], o_lanp = po[5];
+    const size_t o_rows_ptr = po[6], o_rows = po[7], o_child_ptr = po[8], o_child = po[9], o_rel_ptr = po[10];
+    const size_t o_rel = po[11], o_task_ptr = po[12], o_task_fronts = po[13], o_blk_front = po[14], o_blk_row = po[15];
+    const size_t o_blk_col = po[16], o_perm = po[17], o_col_front = po[18], o_wl = po[19], o_ea1 = po[20];
+    const size_t o_tmeta = po[21], o_fat = po[22], o_asm_map = po[23], o_trans = po[24], o_asm_off = po[25];
+    const size_t o_off = po[26], o_woff = po[27], o_l21off = po[28], o_ldf = po[29];
     d_pack32.upload(pack32, s), d_pack64.upload(pack64, s);
     d_fronts.resize((size_t)P.front_doubles + 16);
     d_fronts.zero(s); // once: afterwards only the lower triangles are cleared (k_clear_fronts)
@@ -124,6 +157,11 @@ void cugo_chol::upload(hipStream_t s)
     D.ldf = b64 + o_ldf, D.alias_of = b32 + o_alias, D.bw_np = b32 + o_bwnp, D.la_np = b32 + o_lanp;
     d_wl_ptr = b32 + o_wl;
     D.wl_base = d_wl_ptr, D.fat = b32 + o_fat, D.ea1 = b32 + o_ea1;
+    D.asm_map = b32 + o_asm_map, D.asm_off = b64 + o_asm_off;
+    {
+        const char* e = std::getenv("CUGO_ASM_FRONTS"); // 0: clear + scatter (two launches)
+        asm_fronts = !(e && e[0] == '0');
+    }
     lds_factor = cugo_k::chol_lds_factor_bytes(P.nc_max);
     lds_backward = cugo_k::chol_lds_backward_bytes(P.nc_max, P.ld_max);
 }
@@ -146,6 +184,7 @@ void cugo_chol::analyze_host(int n, const int32_t* rowptr, const int32_t* colind
     chol_analyze(n, rowptr, colind, opt, plan);
     lookahead = std::getenv("CUGO_LOOKAHEAD") && std::atoi(std::getenv("CUGO_LOOKAHEAD")) != 0;
     trans32.assign(plan.blk_trans.begin(), plan.blk_trans.end());
+    pack();
     if (plan.nc_max > cugo_k::chol_max_pivot_cols() ||
         cugo_k::chol_lds_factor_bytes(plan.nc_max) > 160 * 1024 ||
         cugo_k::chol_lds_backward_bytes(plan.nc_max, plan.ld_max) > 160 * 1024)
@@ -167,7 +206,8 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
         cugo_k::set_debug_stamps(d_stamps);
     }
     cugo_k::launch_chol_assemble(s, dev, d_fronts.data(), (size_t)plan.front_doubles, d_Hsc, lambda, d_bsc, d_fail,
-                                 d_wl_ptr + 3L * plan.clr0, plan.nclr);
+                                 d_wl_ptr + 3L * plan.clr0, plan.nclr, asm_fronts ? d_wl_ptr + 3L * plan.asm0 : nullptr,
+                                 plan.nasm);
     int pend0 = 0, npend = 0, pend_tile = 64; // update tiles of the previous level, not launched yet
     for (int st = 0; st < plan.n_stages; st++)
     {

@@ -3,6 +3,7 @@
 #include "chol_symbolic.h"
 #include "hip_util.h"
 
+#include <array>
 #include <functional>
 
 // definition of the opaque cugo_chol of include/cugo_hip.h
@@ -12,6 +13,7 @@ struct cugo_chol
     bool analyzed = false;
     cugo_host::CholPlan plan;
     std::vector<int32_t> trans32; // blk_trans widened for cugo_chol_plan_array
+    std::vector<int32_t> asm_info; // (cugo_chol_plan_array)
     cugo_k::CholPlanDev dev{};
     size_t lds_factor = 0, lds_backward = 0;
     // CUGO_LOOKAHEAD=1 at analyze(): the bulk of a level's update matrix is computed while the next level
@@ -19,8 +21,12 @@ struct cugo_chol
     // (kitti_00 shape: 17.5 vs 14.7 ms per step, profiles/r02_lookahead_timeline.txt): the lead workgroup
     // that the next potrf waits for costs as much as a whole single-round tile launch.  Kept under test.
     bool lookahead = false;
+    bool asm_fronts = true; // one assembly launch that writes every entry (k_assemble_fronts) instead of clear + scatter
 
     // the plan's index arrays, packed (chol_solver.cpp: upload)
+    std::vector<int32_t> pack32;
+    std::vector<int64_t> pack64;
+    std::array<size_t, 30> po{}; // offsets of the arrays inside the packs (pack)
     cugo_host::DevBuf<int32_t> d_pack32;
     cugo_host::DevBuf<int64_t> d_pack64;
     const int32_t* d_wl_ptr = nullptr; // work-item triples inside d_pack32
@@ -35,6 +41,7 @@ struct cugo_chol
 
     void analyze(int n, const int32_t* rowptr, const int32_t* colind);
     void analyze_host(int n, const int32_t* rowptr, const int32_t* colind); // without upload()
+    void pack(); // host half of upload() (analyze_host calls it)
     void upload(hipStream_t s);
     void factor_solve(const double* d_Hsc, double lambda, const double* d_bsc, double* d_x,
                       int32_t* d_fail);

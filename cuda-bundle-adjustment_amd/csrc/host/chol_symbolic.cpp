@@ -1163,6 +1163,55 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
                 P.wl.push_back(f), P.wl.push_back(c0), P.wl.push_back(std::min(6 * P.nb[f], c0 + 16));
                 P.nclr++;
             }
+    // the assembly that makes that clear unnecessary: every lower-triangle entry of a stored front is written
+    // once, with its Hsc entry (+ lambda), its right-hand side entry or zero
+    P.asm0 = (int)P.wl.size() / 3;
+    P.nasm = 0;
+    P.asm_off.assign(ns, -1);
+    P.asm_map.clear();
+    {
+        std::vector<int32_t> root(ns), shift(ns); // storage owner of a front, its origin inside (block rows)
+        for (int f = 0; f < ns; f++)
+        {
+            int o = f;
+            while (P.alias_of[o] >= 0)
+                o = P.alias_of[o];
+            const int64_t delta = P.off[f] - P.off[o], ld = P.ldf[o];
+            if (P.ldf[f] != ld || delta % (ld + 1) != 0 || (delta / (ld + 1)) % 6 != 0 ||
+                delta / (ld + 1) / 6 + P.nb[f] != P.nb[o])
+                throw std::runtime_error("cugo: a front stored inside another one is not on its diagonal");
+            root[f] = o, shift[f] = (int)(delta / (ld + 1) / 6);
+        }
+        for (int f = 0; f < ns; f++)
+            if (P.alias_of[f] < 0 && mine(f))
+            {
+                const int64_t nb = P.nb[f];
+                P.asm_off[f] = (int64_t)P.asm_map.size();
+                P.asm_map.resize(P.asm_map.size() + nb + nb * (nb + 1) / 2, -1);
+                for (int cb = 0; cb < nb; cb += 2)
+                {
+                    P.wl.push_back(f), P.wl.push_back(cb), P.wl.push_back((int)std::min<int64_t>(nb, cb + 2));
+                    P.nasm++;
+                }
+            }
+        for (int f = 0; f < ns; f++)
+            if (P.asm_off[root[f]] >= 0)
+                for (int c = 0; c < P.ncb[f]; c++)
+                    P.asm_map[P.asm_off[root[f]] + shift[f] + c] = P.col0[f] + c;
+        for (size_t k = 0; k < P.blk_front.size(); k++)
+        {
+            const int f = P.blk_front[k], o = root[f];
+            if (P.asm_off[o] < 0)
+                continue;
+            const int64_t nb = P.nb[o], rb = P.blk_row[k] + shift[f], cb = P.blk_col[k] + shift[f];
+            if (rb < cb || rb >= nb)
+                throw std::runtime_error("cugo: an Hsc block outside the lower triangle of its front");
+            int32_t& e = P.asm_map[P.asm_off[o] + nb + cb * nb - cb * (cb - 1) / 2 + (rb - cb)];
+            if (e != -1)
+                throw std::runtime_error("cugo: two Hsc blocks in one front position");
+            e = 2 * (int32_t)k + (rb != cb && P.blk_trans[k] ? 1 : 0);
+        }
+    }
     for (auto& v : P.lead_ptr)
         v += (int)P.wl.size() / 3;
     P.wl.insert(P.wl.end(), lead.begin(), lead.end());

@@ -74,6 +74,13 @@ struct CholPlan
     // (leading boundary block rows inside the parent's pivot columns), items lead: (front, -, -) per
     // front with lead rows, sb: the syrk tiles that are not wholly inside the lead block
     int clr0 = 0, nclr = 0; // items (front, first column, past-last column) of the lower-triangle clear
+    // assembly that leaves nothing to clear (k_assemble_fronts): items (front, first block column, past-last
+    // block column) over the fronts with storage of their own; asm_map at asm_off[front] (-1: no storage):
+    // [nb entries: the permuted block column whose right-hand side sits in this column's rhs row, or -1]
+    // [packed lower triangle of blocks, column-major: 2 * Hsc block + transposed, or -1 = fill]
+    int asm0 = 0, nasm = 0;
+    std::vector<int32_t> asm_map;
+    std::vector<int64_t> asm_off;
     std::vector<int32_t> la_np;
     std::vector<int32_t> lead_ptr, sb_ptr;
     // edge of the syrk tiles of each stage: 64, or 32 where a level has so few 64-tiles that the

@@ -97,6 +97,7 @@ struct Engine::Impl : cugo_k::LaunchHook
 
     DevBuf<int32_t> d_e_pose, d_e_lm, d_lm_ptr, d_pose_ptr, d_pose_edge;
     DevBuf<int32_t> d_pose_rec; // [n][4] per entry of the pose-major list: slot, end of its landmark, landmark, flags (k_hsc_rows)
+    hipEvent_t trial_ev = nullptr; // end of a trial whose successor build is already queued (optimize)
     bool rows_on = false;       // the Schur complement by block rows (k_hsc_rows; CUGO_HSC_ROWS=0: the gather kernels)
     DevBuf<int32_t> d_pose_pos, d_off_pi; // row-strip form of the off-diagonal gather (k_hsc_offdiag_strip)
     bool strip_on = false;
@@ -318,6 +319,8 @@ Engine::~Engine()
             (void)hipStreamSynchronize(s);
         if (s2)
             (void)hipStreamSynchronize(s2);
+        if (impl_->trial_ev)
+            (void)hipEventDestroy(impl_->trial_ev);
         delete impl_;
         cache_stream_release(s); // back to the process-wide pool: creating one costs 1-2 ms
         if (s2)
@@ -577,6 +580,8 @@ void Engine::initialize(FlatGraph& g)
                     Impl& mm = *impl_;
                     try
                     {
+                        // (the current device is per thread: a rank of a multi-GPU job runs on LOCAL_RANK, not 0)
+                        CUGO_HIP(hipSetDevice(mm.ctx.device));
                         const auto t0p = Clock::now();
                         if (!build_pattern_gpu(mm.s2, mm.P, mm.L, mm.cov_ptr.data(), mm.cov_pose.data(), mm.gstruct))
                             return;
@@ -712,6 +717,49 @@ void Engine::initialize(FlatGraph& g)
     // independent per slot: split over a few host threads for big graphs
     parallel_chunks((size_t)E, 100000, [&](size_t a, size_t b, unsigned) { fill_slots((int)a, (int)b); });
     laps.lap("engine: fill slots");
+    // ---- upload of the slot arrays and the estimates: copies from pageable memory block their caller, so a
+    // helper thread issues them while this one builds the pose-major view and hashes the topology (a plan-only
+    // engine has no device: it skips to the topology signature)
+    struct Joiner
+    {
+        std::thread t;
+        ~Joiner()
+        {
+            if (t.joinable())
+                t.join();
+        }
+    } uploader;
+    std::exception_ptr up_err;
+    if (!m.plan_only)
+    {
+        m.d_e_pose.resize(m.h_e_pose.size()), m.d_e_lm.resize(m.h_e_lm.size()), m.d_flags.resize(m.h_flags.size());
+        m.d_meas.resize(meas.size()), m.d_omega.resize(omega.size()), m.d_cams.resize(g.cams.size());
+        if (m.n_cams > 1)
+            m.d_cam.resize(cam.size());
+        m.d_lm_ptr.resize(m.h_lm_ptr.size());
+        for (int k = 0; k < 2; k++)
+            m.d_poses[k].resize(g.poses.size()), m.d_lms[k].resize(g.lms.size());
+        uploader.t = std::thread([&] {
+            try
+            {
+                CUGO_HIP(hipSetDevice(m.ctx.device)); // (the current device is per thread)
+                m.d_e_pose.upload(m.h_e_pose, s), m.d_e_lm.upload(m.h_e_lm, s), m.d_flags.upload(m.h_flags, s);
+                m.d_lm_ptr.upload(m.h_lm_ptr, s);
+                m.d_meas.upload(meas, s), m.d_omega.upload(omega, s), m.d_cams.upload(g.cams, s);
+                if (m.n_cams > 1)
+                    m.d_cam.upload(cam, s);
+                for (int k = 0; k < 2; k++)
+                {
+                    m.d_poses[k].upload(g.poses, s);
+                    m.d_lms[k].upload(g.lms, s);
+                }
+            }
+            catch (...)
+            {
+                up_err = std::current_exception();
+            }
+        });
+    }
     // ---- pose-major view (stable counting sort => ascending landmark inside a pose) ----
     // threads own slot ranges: a histogram per thread, then offsets per (pose, thread) in thread
     // order, so every thread places its own slots and the slot order inside a pose is kept
@@ -751,17 +799,8 @@ void Engine::initialize(FlatGraph& g)
     // ---- upload (a plan-only engine has no device: it skips to the topology signature) -----
     if (!m.plan_only)
     {
-    m.d_e_pose.upload(m.h_e_pose, s), m.d_e_lm.upload(m.h_e_lm, s), m.d_flags.upload(m.h_flags, s);
-    m.d_meas.upload(meas, s), m.d_omega.upload(omega, s), m.d_cams.upload(g.cams, s);
-    if (m.n_cams > 1)
-        m.d_cam.upload(cam, s);
-    m.d_lm_ptr.upload(m.h_lm_ptr, s), m.d_pose_ptr.upload(m.h_pose_ptr, s);
+    m.d_pose_ptr.upload(m.h_pose_ptr, s);
     m.d_pose_edge.upload(m.h_pose_edge, s);
-    for (int k = 0; k < 2; k++)
-    {
-        m.d_poses[k].upload(g.poses, s);
-        m.d_lms[k].upload(g.lms, s);
-    }
     m.cur = 0;
     m.d_Hpp.resize(36 * (size_t)m.P + 16), m.d_b.resize(6 * (size_t)m.P + 3 * (size_t)m.L + 16);
     m.d_Hll.resize(9 * (size_t)m.L + 16), m.d_invHll.resize(9 * (size_t)m.L + 16);
@@ -779,9 +818,16 @@ void Engine::initialize(FlatGraph& g)
     m.d_x.zero(s);
     m.ctx.scratch.resize(cugo_k::reduce_scratch_doubles(E, m.P, m.L));
     laps.lap("engine: enqueue uploads");
-    CUGO_HIP(hipStreamSynchronize(s)); // host staging vectors go out of scope
-    laps.lap("engine: upload sync");
     }
+    auto finish_uploads = [&] {
+        if (uploader.t.joinable())
+        {
+            uploader.t.join();
+            if (up_err)
+                std::rethrow_exception(up_err);
+            CUGO_HIP(hipStreamSynchronize(s)); // host staging vectors go out of scope
+        }
+    };
 
     cugo_edges& ev = m.ev;
     ev.n_edges = E, ev.n_poses_total = m.Pall, ev.n_landmarks_total = m.Lall;
@@ -800,6 +846,7 @@ void Engine::initialize(FlatGraph& g)
         m.rows_on = !m.plan_only && env && env[0] == '1' && !std::getenv("CUGO_SCHUR_PLAN");
         if (m.rows_on)
         {
+            finish_uploads();
             const int n = m.h_pose_ptr[m.Pall];
             m.d_pose_rec.resize(4 * (size_t)std::max(n, 1) + 16);
             cugo_k::launch_pose_rec(s, ev, n, m.d_pose_rec.data());
@@ -859,6 +906,8 @@ void Engine::initialize(FlatGraph& g)
         std::memcpy(m.pending_dims, dims, sizeof dims);
     }
     laps.lap("engine: topology hash");
+    finish_uploads();
+    laps.lap("engine: upload sync");
     prof_[PROF_INITIALIZE] += ms_since(t0);
     if (m.plan_only && m.structure_dirty)
         build_structure(); // no optimize() will follow: the structure is all there is to do
@@ -869,7 +918,18 @@ void Engine::fill_structure_stats(int B, double products, double offdiag_product
     Impl& m = *impl_;
     // remember what this structure was built from (Engine::initialize compares on a hash hit)
     std::memcpy(m.sig_dims, m.pending_dims, sizeof m.sig_dims);
-    m.sig_e_pose = m.h_e_pose, m.sig_e_lm = m.h_e_lm, m.sig_flags = m.h_flags, m.sig_cov_pose = m.cov_pose;
+    {
+        // (7 MB on the kitti_00 shape, on the path of a new graph's first optimize(): copied by the pool)
+        auto copy = [](auto& dst, const auto& src) {
+            dst.resize(src.size());
+            const size_t bytes = src.size() * sizeof(src[0]);
+            const char* from = reinterpret_cast<const char*>(src.data());
+            char* to = reinterpret_cast<char*>(dst.data());
+            parallel_chunks(bytes, 1u << 18, [&](size_t a, size_t b, unsigned) { std::memcpy(to + a, from + a, b - a); });
+        };
+        copy(m.sig_e_pose, m.h_e_pose), copy(m.sig_e_lm, m.h_e_lm), copy(m.sig_flags, m.h_flags);
+        copy(m.sig_cov_pose, m.cov_pose);
+    }
     // row strips, opt-in (CUGO_HSC_STRIP=1; default: one wave per block anywhere): per product the position of
     // its T edge in the edge list of its pose.  Bit for bit the gather kernel's sums with each T block read once,
     // but one 16-wave workgroup per CU cannot hide the gather latency the way 32 independent waves do:
@@ -1010,8 +1070,17 @@ void Engine::build_structure()
             m.hs.d_off_ej = m.gstruct.off_ej.data();
             m.splan_on = false;
             double nff = 0;
-            for (int e = 0; e < m.E; e++)
-                nff += (m.h_flags[e] & (CUGO_EDGE_FIXED_L | CUGO_EDGE_FIXED_P | CUGO_EDGE_INACTIVE)) == 0;
+            {
+                std::vector<int64_t> part(kMaxHostThreads, 0);
+                parallel_chunks((size_t)m.E, 100000, [&](size_t a, size_t b, unsigned t) {
+                    int64_t c = 0;
+                    for (size_t e = a; e < b; e++)
+                        c += (m.h_flags[e] & (CUGO_EDGE_FIXED_L | CUGO_EDGE_FIXED_P | CUGO_EDGE_INACTIVE)) == 0;
+                    part[t] = c;
+                });
+                for (int64_t c : part)
+                    nff += (double)c;
+            }
             prof_[PROF_BUILD_STRUCTURE] += ms_since(t2);
             laps.lap("structure: plan upload");
             // all products of the graph (every free-free edge also has its diagonal one) / local off-diagonal ones
@@ -1262,6 +1331,8 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
     // H is rebuilt from the kept estimates before the retry.  Same arithmetic on the same data in every case.
     const char* spec_env = std::getenv("CUGO_SPECULATE");
     const bool speculate = !sharded && !m.profile && !(spec_env && spec_env[0] == '0');
+    const char* tev_env = std::getenv("CUGO_TRIAL_EVENT"); // 0: wait for the whole stream (A/B)
+    const bool trial_event = !(tev_env && tev_env[0] == '0');
     bool have_build = false;      // the build pass of this iteration is already queued
     double built_lambda = -1.0;   // ... with invHll / T for this damping (< 0: none)
 
@@ -1382,6 +1453,9 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
             const double lambda_pred = lambda * (1.0 / 3.0);
             if (speculate && q == 0 && iteration + 1 < niterations)
             {
+                if (!m.trial_ev)
+                    CUGO_HIP(hipEventCreateWithFlags(&m.trial_ev, hipEventDisableTiming));
+                CUGO_HIP(hipEventRecord(m.trial_ev, s));
                 m.timed("build", [&] {
                     cugo_k::launch_build(s, m.ev, m.d_poses[nxt].data(), m.d_lms[nxt].data(), m.rk, m.d_Hpp.data(),
                                          m.bp(), m.d_Hll.data(), m.bl(), m.d_Hpl.data(), m.rs(), nullptr,
@@ -1401,7 +1475,12 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
                 CUGO_HIP(hipMemcpyAsync(m.h_scal.data() + 2, m.d_scal.data() + 2, 3 * sizeof(double),
                                         hipMemcpyDeviceToHost, s));
             }
-            CUGO_HIP(hipStreamSynchronize(s));
+            // behind a speculative build the host waits for the trial's own last launch only: it then
+            // decides and queues the next Schur complement while the build pass still runs
+            if (spec_queued && trial_event)
+                CUGO_HIP(hipEventSynchronize(m.trial_ev));
+            else
+                CUGO_HIP(hipStreamSynchronize(s));
             int32_t fail_flag;
             std::memcpy(&fail_flag, m.h_scal.data() + 4, sizeof fail_flag);
             if (flag_summed)

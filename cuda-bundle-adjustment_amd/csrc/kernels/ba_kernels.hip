@@ -1113,6 +1113,7 @@ __global__ __launch_bounds__(BS) void k_hsc_reduce(int nblocks, const int32_t* _
 // instruction), staged in a per-wave LDS slot, and LANE = OUTPUT ELEMENT: lanes 0..20 own the
 // 21 upper-triangle entries of the 6x6 sum, lanes 21..26 the 6 entries of the rhs sum.  The
 // per-wave partial sums are added in wave order: fixed order, bit-reproducible.
+typedef double hsc_d4 __attribute__((ext_vector_type(4)));
 constexpr int HD_CH = 7;
 constexpr int HD_BS = 1024; // 16 waves per pose: the per-wave chain of dependent loads is what costs
 constexpr int HD_W = HD_BS / 64;
@@ -1225,6 +1226,148 @@ __global__ __launch_bounds__(HD_BS) void k_hsc_diag(EV ev, const int32_t* __rest
     }
 }
 
+// The same sums on the matrix cores (see k_hsc_offdiag_mfma for the why: the vector form is bound by the LDS
+// port, six 8-byte reads per edge and lane).  A wave takes 14 edges per chunk: A = the T blocks (group 0 in tile
+// rows 0..5, group 1 in rows 6..11), B = per K column [H(0..5, kk) | bl[kk]]: tile columns 0..5 / 6..11 the
+// Hpl blocks of the two groups, columns 12 / 13 their bl entries.  Result of a wave:
+// D[0:6,0:6] + D[6:12,6:12] and D[0:6,12] + D[6:12,13]; the waves' partial sums are added in wave order.
+constexpr int HM_BS = 1024, HM_W = HM_BS / 64, HM_CH = 14;
+constexpr int HM_ZT = 252, HM_ZU = 294; // a zero behind the staged chunk (doubles)
+template <typename S>
+__global__ __launch_bounds__(HM_BS, 8) void k_hsc_diag_mfma(EV ev, const int32_t* __restrict__ rowptr,
+                                                      double lambda_diag,
+                                                      const double* __restrict__ Hpp,
+                                                      const double* __restrict__ bp,
+                                                      const double* __restrict__ bl,
+                                                      const S* __restrict__ Hpl,
+                                                      const S* __restrict__ T,
+                                                      double* __restrict__ Hsc,
+                                                      double* __restrict__ bsc)
+{
+    __shared__ double2 sT2[HM_W][128];  // T blocks as loaded: group g at double2 63 g; later the wave's D tile
+    __shared__ double sU[HM_W][296];    // group g at 147 g: per edge 3 rows of [H[6m..6m+5], bl[m]]
+    __shared__ double part[HM_W][28];
+    const int p = xcd_contiguous_item(ev.P);
+    if (p >= ev.P)
+        return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int pj = min(lane / 9, 6), part9 = lane - 9 * (lane / 9);
+    const bool writer = lane < 63;
+    double* sT = reinterpret_cast<double*>(sT2[w]);
+    double* su = sU[w];
+    // operands of this lane in MFMA step q (K slot kq: column 4 q + kq of a group)
+    const int m = lane & 15, kq = lane >> 4, h = m / 6, i = m - 6 * h;
+    int offA[6], offB[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++)
+    {
+        const int col = 4 * q + kq;
+        offA[q] = (m < 12 && col < 21) ? 126 * h + 6 * col + i : HM_ZT;
+        offB[q] = col >= 21 ? HM_ZU : m < 12 ? 147 * h + 7 * col + i : m < 14 ? 147 * (m - 12) + 7 * col + 6 : HM_ZU;
+    }
+    if (lane < 2)
+        sT[HM_ZT + lane] = 0.0, su[HM_ZU + lane] = 0.0;
+    const int i0 = ev.pose_ptr[p], i1 = ev.pose_ptr[p + 1];
+    const int nch = (i1 - i0 + HM_CH - 1) / HM_CH;
+    hsc_d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+    int ea_next = 0, eb_next = 0;
+    if (w < nch)
+    {
+        ea_next = ev.pose_edge[min(i0 + HM_CH * w + pj, i1 - 1)];
+        eb_next = ev.pose_edge[min(i0 + HM_CH * w + 7 + pj, i1 - 1)];
+    }
+    for (int ch = w; ch < nch; ch += HM_W)
+    {
+        const int ia = i0 + HM_CH * ch + pj, ib = ia + 7;
+        const int ea = ea_next, eb = eb_next;
+        if (ch + HM_W < nch)
+        {
+            ea_next = ev.pose_edge[min(ia + HM_CH * HM_W, i1 - 1)];
+            eb_next = ev.pose_edge[min(ib + HM_CH * HM_W, i1 - 1)];
+        }
+        const uint8_t fa = ev.flags[ea], fb = ev.flags[eb];
+        const int la = ev.lm[ea], lb = ev.lm[eb];
+        const bool acta = ia < i1 && !(fa & (CUGO_EDGE_FIXED_L | CUGO_EDGE_FIXED_P | CUGO_EDGE_INACTIVE));
+        const bool actb = ib < i1 && !(fb & (CUGO_EDGE_FIXED_L | CUGO_EDGE_FIXED_P | CUGO_EDGE_INACTIVE));
+        // fixed-landmark edges have l >= L: no bl entry (and they are never active)
+        double2 ta = ld_pair(T, 9 * (size_t)ea + part9), tb = ld_pair(T, 9 * (size_t)eb + part9);
+        const double2 ha = ld_pair(Hpl, 9 * (size_t)ea + part9), hb = ld_pair(Hpl, 9 * (size_t)eb + part9);
+        const double ba = bl[3 * (size_t)(acta ? la : 0) + min(part9, 2)];
+        const double bb = bl[3 * (size_t)(actb ? lb : 0) + min(part9, 2)];
+        if (!acta)
+            ta = make_double2(0, 0); // the edge contributes nothing
+        if (!actb)
+            tb = make_double2(0, 0);
+        if (writer)
+        {
+            sT2[w][9 * pj + part9] = ta, sT2[w][63 + 9 * pj + part9] = tb;
+            const int k0 = 2 * part9, k1 = k0 + 1;
+            const int u0 = 21 * pj + 7 * (k0 / 6) + k0 % 6, u1 = 21 * pj + 7 * (k1 / 6) + k1 % 6;
+            su[u0] = ha.x, su[u1] = ha.y;
+            su[147 + u0] = hb.x, su[147 + u1] = hb.y;
+            if (part9 < 3)
+                su[21 * pj + 7 * part9 + 6] = ba, su[147 + 21 * pj + 7 * part9 + 6] = bb;
+        }
+        wave_sync_lds0();
+        double a[6], b[6];
+#pragma unroll
+        for (int q = 0; q < 6; q++)
+            a[q] = sT[offA[q]], b[q] = su[offB[q]];
+#pragma unroll
+        for (int q = 0; q < 6; q += 2)
+        {
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q + 1], b[q + 1], acc1, 0, 0, 0);
+        }
+        wave_sync_lds0(); // the slot is rewritten by the next chunk
+    }
+    // D[row][col]: row = (lane >> 4) + 4 reg, col = lane & 15
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        sT[16 * (kq + 4 * q) + m] = acc0[q] + acc1[q];
+    wave_sync_lds0();
+    if (lane < 27)
+    {
+        int r = 0, cc = 12; // lane < 21 -> (r, cc) of the upper triangle, else rhs row r
+        if (lane < 21)
+        {
+            int k = lane;
+            while (k >= 6 - r)
+            {
+                k -= 6 - r;
+                r++;
+            }
+            cc = r + k;
+        }
+        else
+            r = lane - 21;
+        part[w][lane] = lane < 21 ? sT[16 * r + cc] + sT[16 * (6 + r) + 6 + cc] : sT[16 * r + 12] + sT[16 * (6 + r) + 13];
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < 36)
+    {
+        const int rr = t % 6, c = t / 6;
+        const int a = rr < c ? rr : c, b = rr < c ? c : rr;
+        const int k = tri6(a, b);
+        double sum = 0;
+        for (int q = 0; q < HM_W; q++)
+            sum += part[q][k];
+        double val = Hpp[36 * (size_t)p + t] - sum;
+        if (rr == c)
+            val += lambda_diag;
+        Hsc[36 * (size_t)rowptr[p] + t] = val;
+    }
+    else if (t < 42)
+    {
+        const int k = 21 + (t - 36);
+        double sum = 0;
+        for (int q = 0; q < HM_W; q++)
+            sum += part[q][k];
+        bsc[6 * (size_t)p + (t - 36)] = bp[6 * (size_t)p + (t - 36)] - sum;
+    }
+}
+
 // ---------------------------------------------------------------- Schur: off-diagonal --
 // one wave per Hsc block k: Hsc[k] = - sum_{(ei,ej)} T[ei] Hpl[ej]^T
 // (ref: computeHschureKernel .cu:1327-1345, which uses 36 atomics per product instead).
@@ -1307,6 +1450,109 @@ __global__ __launch_bounds__(BS) void k_hsc_offdiag(int nblocks,
     }
     if (lane < 36)
         Hsc[36 * (size_t)k + lane] = -acc;
+}
+
+// ---------------------------------------------------------------- Schur: off-diagonal, matrix cores
+// The sum over a block's products IS a small GEMM: Hsc[k] = -[T_1 T_2 ...] [H_1 H_2 ...]^T with the 6x3 blocks
+// side by side, K = 3 x products.  k_hsc_offdiag forms it on the vector lanes from LDS: six 8-byte LDS reads
+// per product and lane, and the 128 B/clk LDS port of the CU is what bounds it (14 products: 84 reads x 4 clk
+// for every wave of the CU).  Here the staged chunk goes through v_mfma_f64_16x16x4: the 7 products of load
+// group 0 in rows / columns 0..5 of the 16x16 tile, the 7 of group 1 in rows / columns 6..11 (a split of K in
+// two: the result is D[0:6,0:6] + D[6:12,6:12]; the other entries of D are by-products nobody reads), 21
+// columns of K per group = 6 MFMA steps with one LDS read per operand, lane and step — 12 reads per chunk
+// instead of 84.  Fetch, staging and list order as in k_hsc_offdiag; the sum of a block runs in another
+// (fixed) order, so the two kernels agree to rounding, not bit for bit.
+template <typename S, bool XCD>
+__global__ __launch_bounds__(BS) void k_hsc_offdiag_mfma(int nblocks,
+                                                         const int32_t* __restrict__ off_ptr,
+                                                         const int32_t* __restrict__ off_ei,
+                                                         const int32_t* __restrict__ off_ej,
+                                                         const S* __restrict__ Hpl,
+                                                         const S* __restrict__ T,
+                                                         double* __restrict__ Hsc)
+{
+    __shared__ double2 stage[BS / 64][2][OD_CH * 9 + 2];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // XCD: every XCD (workgroups congruent mod 8) takes a contiguous range of blocks — rows of Hsc whose
+    // blocks share their T operands then meet in one L2
+    const int wg = XCD ? xcd_contiguous_item((int)gridDim.x) : (int)blockIdx.x;
+    const int k = wg * (BS / 64) + w;
+    if (k >= nblocks)
+        return; // whole wave
+    const int pj = min(lane / 9, 6), part = lane - 9 * (lane / 9); // lane 63 shadows product 6
+    const bool writer = lane < 63;
+    const int beg = off_ptr[k], end = off_ptr[k + 1];
+    double* sT = reinterpret_cast<double*>(stage[w][0]);
+    double* sH = reinterpret_cast<double*>(stage[w][1]);
+    if (beg >= end)
+    {
+        if (lane < 36)
+            Hsc[36 * (size_t)k + lane] = 0.0;
+        return;
+    }
+    // operand of this lane in MFMA step q: row (A) / column (B) m of the tile, K slot kq: column 4q + kq of
+    // group h = m / 6, element i = m % 6 of that column.  Slots past the 21 columns of a group and the tile
+    // rows 12..15 read a zero kept behind the chunk.
+    constexpr int ZERO = 2 * (OD_CH * 9); // doubles
+    const int m = lane & 15, kq = lane >> 4, h = m / 6, i = m - 6 * h;
+    int off[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++)
+        off[q] = (m < 12 && 4 * q + kq < 21) ? 126 * h + 6 * (4 * q + kq) + i : ZERO;
+    if (lane < 2)
+        sT[ZERO + lane] = 0.0, sH[ZERO + lane] = 0.0;
+    // software pipeline: index pairs two chunks ahead, operands one chunk ahead
+    int j0 = min(beg + pj, end - 1), j1 = min(beg + pj + 7, end - 1); // clamped: surplus lanes re-read the last product
+    int ei0 = off_ei[j0], ej0 = off_ej[j0], ei1 = off_ei[j1], ej1 = off_ej[j1];
+    double2 tv0 = ld_pair(T, 9 * (size_t)ei0 + part), hv0 = ld_pair(Hpl, 9 * (size_t)ej0 + part);
+    double2 tv1 = ld_pair(T, 9 * (size_t)ei1 + part), hv1 = ld_pair(Hpl, 9 * (size_t)ej1 + part);
+    j0 = min(beg + OD_CH + pj, end - 1), j1 = min(beg + OD_CH + pj + 7, end - 1);
+    ei0 = off_ei[j0], ej0 = off_ej[j0], ei1 = off_ei[j1], ej1 = off_ej[j1];
+    double2* w0 = &stage[w][0][9 * pj + part];
+    double2* w1 = &stage[w][1][9 * pj + part];
+    hsc_d4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+    for (int idx = beg; idx < end; idx += OD_CH)
+    {
+        // a product past the end of the list contributes a zero T block (its clamped re-read is finite)
+        if (idx + pj >= end)
+            tv0 = make_double2(0, 0);
+        if (idx + pj + 7 >= end)
+            tv1 = make_double2(0, 0);
+        if (writer)
+        {
+            w0[0] = tv0, w1[0] = hv0;
+            w0[63] = tv1, w1[63] = hv1;
+        }
+        if (idx + OD_CH < end)
+        {
+            tv0 = ld_pair(T, 9 * (size_t)ei0 + part), hv0 = ld_pair(Hpl, 9 * (size_t)ej0 + part);
+            tv1 = ld_pair(T, 9 * (size_t)ei1 + part), hv1 = ld_pair(Hpl, 9 * (size_t)ej1 + part);
+            j0 = min(idx + 2 * OD_CH + pj, end - 1), j1 = min(idx + 2 * OD_CH + pj + 7, end - 1);
+            ei0 = off_ei[j0], ej0 = off_ej[j0], ei1 = off_ei[j1], ej1 = off_ej[j1];
+        }
+        wave_sync_lds();
+        double a[6], b[6];
+#pragma unroll
+        for (int q = 0; q < 6; q++)
+            a[q] = sT[off[q]], b[q] = sH[off[q]];
+#pragma unroll
+        for (int q = 0; q < 6; q += 2)
+        {
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q + 1], b[q + 1], acc1, 0, 0, 0);
+        }
+        wave_sync_lds(); // the slot is rewritten by the next iteration
+    }
+    // D[row][col]: row = (lane >> 4) + 4 reg, col = lane & 15; out(r, c) = D[r][c] + D[6 + r][6 + c]
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        sT[16 * (kq + 4 * q) + m] = acc0[q] + acc1[q];
+    wave_sync_lds();
+    if (lane < 36)
+    {
+        const int r = lane % 6, c = lane / 6;
+        Hsc[36 * (size_t)k + lane] = -(sT[16 * r + c] + sT[16 * (6 + r) + 6 + c]);
+    }
 }
 
 // ---------------------------------------------------------------- Schur: off-diagonal, row strips
@@ -1979,6 +2225,14 @@ void launch_max_diagonal(hipStream_t s, const double* d_Hpp, int nP, const doubl
     CUGO_LAUNCH(k_max_partials, dim3(1), dim3(BS), 0, s, rs.d_partials, nb, d_out);
 }
 
+// CUGO_HSC_MFMA=0: the off-diagonal blocks of Hsc on the vector lanes (k_hsc_offdiag) instead of the matrix cores
+// (2: only the off-diagonal kernel)
+static int hsc_mfma()
+{
+    const char* e = std::getenv("CUGO_HSC_MFMA"); // (read per call: the A/B tool switches it inside one process)
+    return !e ? 1 : e[0] == '0' ? 0 : e[0] == '2' ? 2 : 1;
+}
+
 template <typename S>
 static void launch_schur_t(hipStream_t s, const cugo_edges& e, const cugo_hsc_struct& hs, double lambda,
                            int damp_hsc_diag, const double* d_Hpp, const double* d_bp, const double* d_Hll,
@@ -2036,10 +2290,29 @@ static void launch_schur_t(hipStream_t s, const cugo_edges& e, const cugo_hsc_st
         CUGO_LAUNCH_T(k_hsc_offdiag_strip, S, dim3(xcd_grid(ev.P)), dim3(HS_BS), hs_lds_bytes(), s, ev, hs.d_rowptr,
                       hs.d_off_ptr, hs.d_off_ei, rows.d_off_pi, hs.d_off_ej, d_Hpl, (const S*)d_T, d_Hsc);
     }
+    else if (hs.n_blocks > 0 && hsc_mfma())
+    {
+        // a contiguous range of blocks per XCD (CUGO_HSC_XCD=0: dispatch order).  In-process A/B: 39.35 vs 41.80 ms
+        // per step on the 10k-pose graph, 11.38 vs 11.36 ms on the kitti_00 shape — with the LDS port out of the
+        // way the kernel is bound by its L2 misses, and rows that share T operands now meet in one L2 (the
+        // vector-lane kernel, bound by LDS reads, was slower with this mapping: 123 vs 112 us)
+        const char* ex = std::getenv("CUGO_HSC_XCD");
+        ::cugo_k::LaunchScope _scope("k_hsc_offdiag_mfma", s);
+        if (!(ex && ex[0] == '0'))
+            hipLaunchKernelGGL((k_hsc_offdiag_mfma<S, true>), dim3(xcd_grid(div_up(hs.n_blocks, BS / 64))), dim3(BS), 0, s,
+                               hs.n_blocks, hs.d_off_ptr, hs.d_off_ei, hs.d_off_ej, d_Hpl, (const S*)d_T, d_Hsc);
+        else
+            hipLaunchKernelGGL((k_hsc_offdiag_mfma<S, false>), dim3(div_up(hs.n_blocks, BS / 64)), dim3(BS), 0, s,
+                               hs.n_blocks, hs.d_off_ptr, hs.d_off_ei, hs.d_off_ej, d_Hpl, (const S*)d_T, d_Hsc);
+    }
     else if (hs.n_blocks > 0)
         CUGO_LAUNCH_T(k_hsc_offdiag, S, dim3(div_up(hs.n_blocks, BS / 64)), dim3(BS), 0, s,
                       hs.n_blocks, hs.d_off_ptr, hs.d_off_ei, hs.d_off_ej, d_Hpl, (const S*)d_T, d_Hsc);
-    if (ev.P > 0)
+    if (ev.P > 0 && hsc_mfma() == 1)
+        CUGO_LAUNCH_T(k_hsc_diag_mfma, S, dim3(xcd_grid(ev.P)), dim3(HM_BS), 0, s, ev,
+                      hs.d_rowptr, damp_hsc_diag ? lambda : 0.0, d_Hpp, d_bp, d_bl, d_Hpl, (const S*)d_T,
+                      d_Hsc, d_bsc);
+    else if (ev.P > 0)
         CUGO_LAUNCH_T(k_hsc_diag, S, dim3(xcd_grid(ev.P)), dim3(HD_BS), 0, s, ev,
                       hs.d_rowptr, damp_hsc_diag ? lambda : 0.0, d_Hpp, d_bp, d_bl, d_Hpl, (const S*)d_T,
                       d_Hsc, d_bsc);

@@ -54,14 +54,14 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------- assembly -------------
 // workgroups [0, nblk): the Hsc blocks (+lambda on the diagonal); the ones after them: the right-hand
 // side and the reset of the zero-pivot flag (one launch instead of two)
-__global__ __launch_bounds__(CBS) void k_assemble_blocks(CholPlanDev p, double* __restrict__ fronts,
-                                                         const double* __restrict__ Hsc,
-                                                         double lambda, const double* __restrict__ bsc,
-                                                         int32_t* __restrict__ fail, int nblk)
+__device__ __forceinline__ void assemble_scatter(const CholPlanDev& p, double* __restrict__ fronts,
+                                                 const double* __restrict__ Hsc, double lambda,
+                                                 const double* __restrict__ bsc, int32_t* __restrict__ fail, int nblk,
+                                                 int bid)
 {
-    if ((int)blockIdx.x >= nblk)
+    if (bid >= nblk)
     {
-        const int j = ((int)blockIdx.x - nblk) * CBS + threadIdx.x;
+        const int j = (bid - nblk) * CBS + threadIdx.x;
         if (j == 0)
             *fail = 0; // the zero-pivot flag of this factorisation
         if (j >= 6 * p.n)
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(CBS) void k_assemble_blocks(CholPlanDev p, double* 
         fronts[p.off[f] + lc * ld + 6L * p.nb[f]] = bsc[6L * p.perm[jb] + comp]; // rhs row = row 6*nb
         return;
     }
-    const long idx = (long)blockIdx.x * CBS + threadIdx.x;
+    const long idx = (long)bid * CBS + threadIdx.x;
     if (idx >= 36L * p.n_hsc_blocks)
         return;
     const int k = (int)(idx / 36), t = (int)(idx % 36);
@@ -97,6 +97,14 @@ __global__ __launch_bounds__(CBS) void k_assemble_blocks(CholPlanDev p, double* 
         F[(6L * cb + r) * ld + 6L * rb + c] = v;
 }
 
+__global__ __launch_bounds__(CBS) void k_assemble_blocks(CholPlanDev p, double* __restrict__ fronts,
+                                                         const double* __restrict__ Hsc,
+                                                         double lambda, const double* __restrict__ bsc,
+                                                         int32_t* __restrict__ fail, int nblk)
+{
+    assemble_scatter(p, fronts, Hsc, lambda, bsc, fail, nblk, (int)blockIdx.x);
+}
+
 // lower triangle (rows >= column) of 16 columns of one front := 0.  The strict upper triangles are
 // cleared once, when the plan is uploaded, and never written afterwards (every global store of the
 // factorisation is masked to row >= column), so this is the whole-buffer memset at half the bytes.
@@ -113,6 +121,58 @@ __global__ __launch_bounds__(CBS) void k_clear_fronts(CholPlanDev p, double* __r
         for (int c = c0; c < c1; c++)
             if (r >= c)
                 F[(long)c * ld + r] = 0.0;
+}
+
+// Assembly that leaves nothing to clear, in ONE launch: the first `nzero` workgroups write zeros to every
+// lower-triangle entry of the stored fronts that no Hsc block and no right-hand side entry lands on (two block
+// columns of a front each; CholPlan::asm_map says which block positions are taken — most items hold none and
+// need no map), the others scatter the Hsc blocks (+lambda) and the right-hand side as k_assemble_blocks does.
+// The two kinds write disjoint entries, so no order between them is needed: every entry is written once
+// instead of cleared by one launch and patched by the next.
+// One 64-byte record per zero item (CholPlanDev::fat): front, block columns, "some position taken", block
+// rows, map offset, storage offset, leading dimension.
+__global__ __launch_bounds__(CBS) void k_assemble_fronts(CholPlanDev p, double* __restrict__ fronts,
+                                                         const double* __restrict__ Hsc, double lambda,
+                                                         const double* __restrict__ bsc, int32_t* __restrict__ fail,
+                                                         int item0, int nzero, int nblk)
+{
+    if ((int)blockIdx.x >= nzero)
+    {
+        assemble_scatter(p, fronts, Hsc, lambda, bsc, fail, nblk, (int)blockIdx.x - nzero);
+        return;
+    }
+    const int32_t* it = p.fat + 16L * (item0 + (int)blockIdx.x);
+    const int4 h0 = *reinterpret_cast<const int4*>(it), h1 = *reinterpret_cast<const int4*>(it + 4);
+    const long off = *reinterpret_cast<const int64_t*>(it + 8), ld = *reinterpret_cast<const int64_t*>(it + 10);
+    const int cb0 = h0.y, cb1 = h0.z, nb = h1.y;
+    const int nrows = 6 * nb + 1;
+    double* F = fronts + off;
+    if (!h1.x)
+    { // no position of these columns is taken
+        for (int r = 6 * cb0 + threadIdx.x; r < nrows; r += CBS)
+            for (int c = 6 * cb0; c < 6 * cb1; c++)
+                if (r >= c)
+                    F[(long)c * ld + r] = 0.0;
+        return;
+    }
+    const int32_t* map = p.asm_map + (long)(uint32_t)h1.z + ((long)h1.w << 32);
+    for (int r = 6 * cb0 + threadIdx.x; r < nrows; r += CBS)
+    {
+        const int rb = r / 6, i = r - 6 * rb;
+        for (int cb = cb0; cb < cb1; cb++)
+        {
+            if (rb < cb)
+                continue;
+            const int taken = rb == nb ? map[cb] : map[nb + cb * nb - cb * (cb - 1) / 2 + (rb - cb)];
+            if (taken >= 0)
+                continue; // the scatter writes this block / these rhs entries
+            double* Fc = F + 6L * cb * ld + r;
+#pragma unroll
+            for (int c = 0; c < 6; c++)
+                if (rb > cb || i >= c)
+                    Fc[c * ld] = 0.0;
+        }
+    }
 }
 
 // Diagnostic phase stamps: only in a build with -DCUGO_STAMPS (make STAMPS=1) and run with
@@ -2310,8 +2370,17 @@ void set_debug_stamps(long long* d_buf)
 
 void launch_chol_assemble(hipStream_t s, const CholPlanDev& p, double* d_fronts,
                           size_t front_doubles, const double* d_Hsc, double lambda,
-                          const double* d_bsc, int32_t* d_fail, const int32_t* d_clear_items, int nclear)
+                          const double* d_bsc, int32_t* d_fail, const int32_t* d_clear_items, int nclear,
+                          const int32_t* d_asm_items, int nasm)
 {
+    if (d_asm_items && nasm > 0)
+    {
+        const long n = 36L * p.n_hsc_blocks;
+        const int nblk = (int)((n + CBS - 1) / CBS), nrhs = std::max(1, (6 * p.n + CBS - 1) / CBS);
+        CUGO_LAUNCH(k_assemble_fronts, dim3(nasm + nblk + nrhs), dim3(CBS), 0, s, p, d_fronts, d_Hsc, lambda, d_bsc,
+                    d_fail, (int)((d_asm_items - p.wl_base) / 3), nasm, nblk);
+        return;
+    }
     if (nclear > 0)
         CUGO_LAUNCH(k_clear_fronts, dim3(nclear), dim3(CBS), 0, s, p, d_fronts, d_clear_items);
     else

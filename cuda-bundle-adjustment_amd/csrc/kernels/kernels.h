@@ -150,6 +150,9 @@ struct CholPlanDev
                                // dimension (int64)} — the potrf workgroup's extend-add into F11 (tmeta[16..17])
     const int32_t* tmeta;      // [n_tasks_total][20] (16..17: range in ea1, 18..19 unused): {fronts in the task, first front, its ncb, nb, col0, bw_np,
                                // rows_ptr, has-children-to-add flag, off, ldf, woff, l21off (four int64)} (potrf, backward substitution)
+    // k_assemble_fronts (chol_symbolic.h: CholPlan::asm_map): per stored front its map at asm_off[front]
+    const int32_t* asm_map;
+    const int64_t* asm_off;
     const int32_t* wl_base;    // the work-item triples (chol_symbolic.h: CholPlan::wl) ...
     const int32_t* fat;        // ... and one 64-byte record per item for the tile kernels (TileItem)
     const int32_t* task_ptr;   // [n_tasks_total+1] into task_fronts
@@ -173,7 +176,8 @@ struct CholPlanDev
 // nclear == 0: the whole buffer), scatters Hsc (+lambda) and bsc into them and resets *d_fail
 void launch_chol_assemble(hipStream_t s, const CholPlanDev& p, double* d_fronts, size_t front_doubles,
                           const double* d_Hsc, double lambda, const double* d_bsc, int32_t* d_fail,
-                          const int32_t* d_clear_items, int nclear);
+                          const int32_t* d_clear_items, int nclear, const int32_t* d_asm_items = nullptr,
+                          int nasm = 0);
 void launch_chol_subtree_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,
                                int ntasks, size_t lds_bytes, int32_t* d_fail);
 // one etree level: extend-add(pivot columns) / potrf (+ extend-add of the boundary columns) /

@@ -304,7 +304,10 @@ def test_float32_block_kernels_vs_oracle(ctx, oracle_lib):
                                   "CUGO_MAX_SUPER_COLS": "5"},
                                  # the 6-column LDS panels of rounds 1-2 (the default is the 16-column register panel)
                                  {"CUGO_PANEL16": "0"},
-                                 {"CUGO_PANEL16": "0", "CUGO_MIN_SUBTREE_TASKS": "0", "CUGO_MAX_SUPER_COLS": "5"}])
+                                 {"CUGO_PANEL16": "0", "CUGO_MIN_SUBTREE_TASKS": "0", "CUGO_MAX_SUPER_COLS": "5"},
+                                 # clear + scatter (two launches) instead of the assembly that writes every entry
+                                 {"CUGO_ASM_FRONTS": "0"},
+                                 {"CUGO_ASM_FRONTS": "0", "CUGO_ALIAS_CHAINS": "0", "CUGO_MAX_SUPER_COLS": "5"}])
 def test_sparse_cholesky_vs_numpy(ctx, env, monkeypatch):
     from test_host import covis_pattern, patterns, random_spd_bsr
     for k, v in env.items():

@@ -212,6 +212,94 @@ def patterns():
 
 
 @pytest.mark.parametrize("name", list(patterns().keys()) + ["synthetic"])
+def test_one_pass_assembly_map_equals_clear_plus_scatter(lib, name):
+    """k_assemble_fronts (chol_kernels.hip) writes every lower-triangle entry of every stored front once, from
+    CholPlan::asm_map; replayed here in numpy it must leave the fronts exactly as clearing them and scattering
+    the Hsc blocks + right-hand side through blk_front / blk_row / blk_col / blk_trans does — fronts stored
+    inside their child's update block included."""
+    rng = np.random.default_rng(5)
+    if name == "synthetic":
+        d = cugo.synth(120, 1500, 6200, seed=3, n_loop_closures=60)
+        ep = d["e_pose"].astype(np.int64) - 1
+        ep[ep < 0] = 10**6
+        rowptr, colind = covis_pattern(119, ep, d["e_lm"])
+    else:
+        rows = patterns()[name]
+        rowptr = np.array([0] + list(np.cumsum([len(r) for r in rows])), np.int32)
+        colind = np.array([c for r in rows for c in r], np.int32)
+    n = len(rowptr) - 1
+    _, vals = random_spd_bsr(rowptr, colind, rng)
+    s = C.c_void_p()
+    assert lib.cugo_chol_create(None, C.byref(s)) == 0
+    assert lib.cugo_chol_analyze(s, n, rowptr.ctypes.data_as(C.POINTER(C.c_int32)),
+                                 colind.ctypes.data_as(C.POINTER(C.c_int32))) == 0, lib.cugo_last_error()
+    pl = plan_arrays(lib, s)
+    for nm in ["alias_of", "asm_map", "wl", "asm_info"]:
+        p = C.POINTER(C.c_int32)()
+        k = lib.cugo_chol_plan_array(s, nm.encode(), C.byref(p))
+        assert k >= 0, nm
+        pl[nm] = np.ctypeslib.as_array(p, shape=(k,)).copy()
+    ns = len(pl["ncb"])
+    ld, off, total = np.zeros(ns, np.int64), np.zeros(ns, np.int64), 0
+    for f in range(ns):  # storage as chol_symbolic.cpp lays it out (5b)
+        c = pl["alias_of"][f]
+        if c >= 0:
+            ld[f], off[f] = ld[c], off[c] + 6 * pl["ncb"][c] * (ld[c] + 1)
+        else:
+            ld[f], off[f] = 6 * pl["nb"][f] + 1, total
+            total += ld[f] * 6 * pl["nb"][f]
+    if name == "synthetic":
+        assert (pl["alias_of"] >= 0).any()
+    lam, b, H = 0.5, rng.normal(size=6 * n), vals.reshape(-1)
+    old, lower = np.zeros(total), np.zeros(total, bool)
+    for f in range(ns):
+        if pl["alias_of"][f] < 0:
+            for c in range(6 * pl["nb"][f]):
+                lower[off[f] + c * ld[f] + c:off[f] + (c + 1) * ld[f]] = True
+    r6, c6 = np.arange(36) % 6, np.arange(36) // 6
+    for k in range(len(pl["blk_front"])):
+        f, rb, cb, tr = pl["blk_front"][k], pl["blk_row"][k], pl["blk_col"][k], pl["blk_trans"][k]
+        v = H[36 * k:36 * k + 36].copy()
+        if rb == cb:
+            v[r6 == c6] += lam
+            keep = r6 >= c6
+            old[off[f] + (6 * cb + c6[keep]) * ld[f] + 6 * rb + r6[keep]] = v[keep]
+        elif not tr:
+            old[off[f] + (6 * cb + c6) * ld[f] + 6 * rb + r6] = v
+        else:
+            old[off[f] + (6 * cb + r6) * ld[f] + 6 * rb + c6] = v
+    for jb in range(n):
+        f = pl["col_front"][jb]
+        old[off[f] + (6 * (jb - pl["col0"][f]) + np.arange(6)) * ld[f] + 6 * pl["nb"][f]] = b[6 * pl["perm"][jb] + np.arange(6)]
+    new = np.full(total, np.nan)
+    asm0, nasm, aoff, mp = pl["asm_info"][0], pl["asm_info"][1], pl["asm_info"][2:], pl["asm_map"]
+    assert ((aoff >= 0) == (pl["alias_of"] < 0)).all()
+    for it in range(nasm):
+        f, cb0, cb1 = pl["wl"][3 * (asm0 + it):3 * (asm0 + it) + 3]
+        nb, m = pl["nb"][f], mp[aoff[f]:]
+        for cb in range(cb0, cb1):
+            for rb in range(cb, nb + 1):
+                for i in range(6 if rb < nb else 1):
+                    base = off[f] + 6 * cb * ld[f] + 6 * rb + i
+                    for c in range(6):
+                        if rb == nb:
+                            jb = m[cb]
+                            v = 0.0 if jb < 0 else b[6 * pl["perm"][jb] + c]
+                        elif rb > cb or i >= c:
+                            src = m[nb + cb * nb - cb * (cb - 1) // 2 + rb - cb]
+                            v = 0.0 if src < 0 else (H[36 * (src >> 1) + 6 * i + c] if src & 1 else H[36 * (src >> 1) + i + 6 * c])
+                            if rb == cb and i == c and src >= 0:
+                                v += lam
+                        else:
+                            continue
+                        assert np.isnan(new[base + c * ld[f]])  # written once
+                        new[base + c * ld[f]] = v
+    assert (~np.isnan(new) == lower).all()      # every lower-triangle entry of the stored fronts, nothing else
+    assert (new[lower] == old[lower]).all() and not old[~lower].any()
+    lib.cugo_chol_destroy(s)
+
+
+@pytest.mark.parametrize("name", list(patterns().keys()) + ["synthetic"])
 @pytest.mark.parametrize("env", [{}, {"CUGO_ND_LEAF": "4", "CUGO_MAX_SUPER_COLS": "3", "CUGO_TARGET_TASKS": "4"},
                                  {"CUGO_ND_LEAF": "1000", "CUGO_MAX_SUPER_COLS": "1", "CUGO_TARGET_TASKS": "100000"}])
 def test_symbolic_plan_replay_solves_the_system(lib, name, env, monkeypatch):

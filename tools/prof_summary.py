@@ -9,7 +9,7 @@ for r in csv.DictReader(open(f)):
 if len(sys.argv) > 2:
     f = max(glob.glob(d + '/*/*_kernel_trace.csv'), key=__import__('os').path.getmtime)
     rows = list(csv.DictReader(open(f)))
-    idx = [i for i, r in enumerate(rows) if 'k_assemble_blocks' in r['Kernel_Name']]
+    idx = [i for i, r in enumerate(rows) if 'k_assemble_blocks' in r['Kernel_Name'] or 'k_assemble_fronts' in r['Kernel_Name']]
     a, b = idx[-2], idx[-1]
     t0 = int(rows[a]['Start_Timestamp'])
     for r in rows[a - 2:b]:

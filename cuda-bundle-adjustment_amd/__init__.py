@@ -311,7 +311,7 @@ class Graph:
         keys = ["hsc_blocks", "products", "nnzL", "chol_flops", "supernodes", "stages", "front_bytes",
                 "offdiag_products", "up_potrf_flops", "up_trsm_flops", "up_syrk_flops", "up_ea_bytes",
                 "backward_bytes", "schur_slots", "chol_rank_flops", "chol_top_flops", "chol_bcast_bytes",
-                "chol_bcasts"]
+                "chol_bcasts", "trial_sync_retries"]
         return dict(zip(keys[:n], o[:n].tolist()))
 
 

@@ -17,13 +17,13 @@ void cugo_chol::pack()
     // All index arrays of the plan travel in TWO host-to-device copies (a pageable copy costs
     // ~20 us whatever its size, and there are 23 arrays: 0.4 ms of a cold call on a small graph)
     pack32.clear(), pack64.clear();
-    auto put32 = [&pack32](const std::vector<int32_t>& v) {
+    auto put32 = [this](const std::vector<int32_t>& v) {
         const size_t o = pack32.size();
         pack32.insert(pack32.end(), v.begin(), v.end());
         pack32.resize((pack32.size() + 3) & ~size_t(3)); // keep every array 16-byte aligned
         return o;
     };
-    auto put64 = [&pack64](const std::vector<int64_t>& v) {
+    auto put64 = [this](const std::vector<int64_t>& v) {
         const size_t o = pack64.size();
         pack64.insert(pack64.end(), v.begin(), v.end());
         pack64.resize((pack64.size() + 1) & ~size_t(1));

@@ -97,6 +97,7 @@ struct Engine::Impl : cugo_k::LaunchHook
 
     DevBuf<int32_t> d_e_pose, d_e_lm, d_lm_ptr, d_pose_ptr, d_pose_edge;
     DevBuf<int32_t> d_pose_rec; // [n][4] per entry of the pose-major list: slot, end of its landmark, landmark, flags (k_hsc_rows)
+    uint64_t trial_seq = 0;        // sequence number of the last LM trial whose result the host waited for
     hipEvent_t trial_ev = nullptr; // end of a trial whose successor build is already queued (optimize)
     bool rows_on = false;       // the Schur complement by block rows (k_hsc_rows; CUGO_HSC_ROWS=0: the gather kernels)
     DevBuf<int32_t> d_pose_pos, d_off_pi; // row-strip form of the off-diagonal gather (k_hsc_offdiag_strip)
@@ -739,7 +740,7 @@ void Engine::initialize(FlatGraph& g)
         m.d_lm_ptr.resize(m.h_lm_ptr.size());
         for (int k = 0; k < 2; k++)
             m.d_poses[k].resize(g.poses.size()), m.d_lms[k].resize(g.lms.size());
-        uploader.t = std::thread([&] {
+        auto uploads = [&] {
             try
             {
                 CUGO_HIP(hipSetDevice(m.ctx.device)); // (the current device is per thread)
@@ -758,7 +759,16 @@ void Engine::initialize(FlatGraph& g)
             {
                 up_err = std::current_exception();
             }
-        });
+        };
+        const char* env = std::getenv("CUGO_UPLOAD_THREAD"); // 0: the copies are issued by this thread
+        if (env && env[0] == '0')
+        {
+            uploads();
+            if (up_err)
+                std::rethrow_exception(up_err);
+        }
+        else
+            uploader.t = std::thread(uploads);
     }
     // ---- pose-major view (stable counting sort => ascending landmark inside a pose) ----
     // threads own slot ranges: a histogram per thread, then offsets per (pose, thread) in thread
@@ -815,18 +825,22 @@ void Engine::initialize(FlatGraph& g)
     m.d_x.resize(6 * (size_t)m.P + 3 * (size_t)m.L + 16);
     m.d_tmp.resize(36 * (size_t)m.P + 16);
     m.d_scal.resize(16), m.d_fail.resize(4), m.h_scal.resize(16), m.h_fail.resize(4);
+    m.d_fail.zero(s); // [0] zero-pivot flag, [2] arrival counter of the trial's last launch
+    m.h_scal[5] = -1.0;
     m.d_x.zero(s);
     m.ctx.scratch.resize(cugo_k::reduce_scratch_doubles(E, m.P, m.L));
     laps.lap("engine: enqueue uploads");
     }
+    bool uploads_done = m.plan_only;
     auto finish_uploads = [&] {
+        if (uploads_done)
+            return;
         if (uploader.t.joinable())
-        {
             uploader.t.join();
-            if (up_err)
-                std::rethrow_exception(up_err);
-            CUGO_HIP(hipStreamSynchronize(s)); // host staging vectors go out of scope
-        }
+        if (up_err)
+            std::rethrow_exception(up_err);
+        CUGO_HIP(hipStreamSynchronize(s)); // host staging vectors go out of scope
+        uploads_done = true;
     };
 
     cugo_edges& ev = m.ev;
@@ -1446,7 +1460,8 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
                 else
                     cugo_k::launch_errors_tail(s, m.ev, m.d_poses[nxt].data(), m.d_lms[nxt].data(), m.rk, m.rs(),
                                                n_scale_part, m.d_scal.data() + 2, m.d_scal.data() + 4,
-                                               m.h_scal.data() + 2);
+                                               m.h_scal.data() + 2, (double)++m.trial_seq,
+                                               reinterpret_cast<unsigned*>(m.d_fail.data() + 2));
             });
             m.last_err_buf = nxt;
             sync_prof(PROF_COMPUTE_ERROR, te);
@@ -1481,6 +1496,18 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
                 CUGO_HIP(hipEventSynchronize(m.trial_ev));
             else
                 CUGO_HIP(hipStreamSynchronize(s));
+            if (!sharded)
+            { // the three words in the pinned block are this trial's (see k_sum_partials2)
+                const volatile double* seq = m.h_scal.data() + 5;
+                for (long spin = 0; *seq != (double)m.trial_seq; spin++)
+                {
+                    if (spin == 0)
+                        sstats_.trial_sync_retries += 1;
+                    if (spin > 2000000000L)
+                        throw std::runtime_error("cugo: the result of an LM trial never arrived");
+                }
+                std::atomic_thread_fence(std::memory_order_acquire);
+            }
             int32_t fail_flag;
             std::memcpy(&fail_flag, m.h_scal.data() + 4, sizeof fail_flag);
             if (flag_summed)

@@ -51,6 +51,7 @@ struct StructureStats
     // replicated top (same unit as chol_flops' model), bytes this rank's factorisation exchanges per trial
     // (update blocks into the top + solution ranges), number of those broadcasts
     double chol_rank_flops = 0, chol_top_flops = 0, chol_bcast_bytes = 0, chol_bcasts = 0;
+    double trial_sync_retries = 0; // waits for an LM trial that returned before its result was there (expected: 0)
 };
 
 enum ProfItem

@@ -3,6 +3,8 @@
 // src/async_vector.h:18-193) — support code, not graded math.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <type_traits>
 
 #include <cstdio>
 #include <cstring>
@@ -41,6 +43,12 @@ void cache_free(void* p);
 hipStream_t cache_stream_acquire(); // a non-blocking stream of the current device
 void cache_stream_release(hipStream_t s); // the stream must be idle
 
+inline bool poison_alloc()
+{
+    static const bool on = std::getenv("CUGO_POISON_ALLOC") != nullptr;
+    return on;
+}
+
 template <typename T>
 class DevBuf
 {
@@ -67,6 +75,10 @@ public:
             size_t got = 0;
             p_ = static_cast<T*>(cache_alloc((n + 16) * sizeof(T), false, &got));
             cap_ = got / sizeof(T);
+            // debugging aid (CUGO_POISON_ALLOC=1): a fresh floating-point buffer starts as NaNs, so a result that
+            // depends on memory nobody wrote shows up as NaN instead of as a run-to-run difference
+            if (std::is_floating_point<T>::value && poison_alloc())
+                CUGO_HIP(hipMemset(p_, 0xFF, got));
         }
         n_ = n;
     }

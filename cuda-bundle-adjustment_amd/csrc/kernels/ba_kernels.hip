@@ -183,7 +183,8 @@ __global__ __launch_bounds__(SP_BS) void k_sum_partials(const double* __restrict
 __global__ __launch_bounds__(SP_BS) void k_sum_partials2(const double* __restrict__ partA, int nA,
                                                          const double* __restrict__ partB, int nB,
                                                          double* __restrict__ out, const double* __restrict__ flag,
-                                                         double* __restrict__ host_out)
+                                                         double* __restrict__ host_out, double seq,
+                                                         unsigned* __restrict__ done)
 {
     __shared__ double sm[SP_BS / 64];
     const double* part = blockIdx.x == 0 ? partA : partB;
@@ -206,6 +207,15 @@ __global__ __launch_bounds__(SP_BS) void k_sum_partials2(const double* __restric
             host_out[blockIdx.x] = v;
             if (blockIdx.x == 0)
                 host_out[2] = *flag; // 8 bytes holding the int32 zero-pivot flag
+            // the trial's sequence number follows the three words (system-scope release; the second of the two
+            // workgroups to get here writes it): the host checks it after its wait, so a wait that returned
+            // early could never hand it the previous trial's numbers
+            __threadfence_system();
+            if (atomicAdd(done, 1u) == 1u)
+            {
+                *done = 0u;
+                __hip_atomic_store(host_out + 3, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
 }
@@ -2148,7 +2158,7 @@ void launch_errors(hipStream_t s, const cugo_edges& e, const double* d_poses, co
 
 void launch_errors_tail(hipStream_t s, const cugo_edges& e, const double* d_poses, const double* d_lms,
                         cugo_robust rk, ReduceScratch rs, int n_scale_partials, double* d_out,
-                        const double* d_flag, double* h_out)
+                        const double* d_flag, double* h_out, double seq, unsigned* d_done)
 {
     const EV ev = make_ev(e);
     const int nb = div_up(ev.E, BS);
@@ -2159,7 +2169,7 @@ void launch_errors_tail(hipStream_t s, const cugo_edges& e, const double* d_pose
         CUGO_LAUNCH(k_errors, dim3(nb), dim3(BS), 0, s, ev, d_poses, d_lms,
                            Robust2{{rk.type, rk.delta}, {rk.type_stereo, rk.delta_stereo}}, d_chi_part);
     CUGO_LAUNCH(k_sum_partials2, dim3(2), dim3(SP_BS), 0, s, d_chi_part, nb, rs.d_partials, n_scale_partials,
-                d_out, d_flag, h_out);
+                d_out, d_flag, h_out, seq, d_done);
 }
 
 void launch_edge_chi(hipStream_t s, const cugo_edges& e, const double* d_poses, const double* d_lms,

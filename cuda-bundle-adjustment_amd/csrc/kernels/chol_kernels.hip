@@ -375,14 +375,10 @@ __device__ __forceinline__ double ldg32(const double* __restrict__ base, unsigne
 // block (W = L11^-1 is built from 16-column blocks).  The LDS copy always has leading dimension
 // LLD = 113 (odd: column walks are conflict-free) whatever nc is, so that every LDS address in
 // the factorisation is `base + compile-time offset` — one instruction per access.
-__device__ __forceinline__ void dev_load_l11(const double* __restrict__ F, long ld, int nc, double* __restrict__ Ls)
+__device__ __forceinline__ void l11_issue(const double* __restrict__ F, long ld, int nc, double (&v)[3][3])
 {
-    // 1024 threads cover the full NC_MAX x NC_MAX LDS matrix, 9 elements each: all global loads (6 per
-    // thread: clamped addresses, no branch) are issued before the first LDS store; everything outside
-    // the nc x nc lower triangle becomes identity / zero
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const unsigned uld = (unsigned)ld;
-    double v[3][3];
 #pragma unroll
     for (int u = 0; u < 3; u++)
 #pragma unroll
@@ -392,6 +388,10 @@ __device__ __forceinline__ void dev_load_l11(const double* __restrict__ F, long 
             // (q < u: rows 32q.. lie above columns 32u.. for every thread — nothing of the lower triangle)
             v[u][q] = q < u ? 0.0 : ldg32(F, (unsigned)min(c, nc - 1) * uld + (unsigned)min(r, nc - 1));
         }
+}
+__device__ __forceinline__ void l11_store(int nc, const double (&v)[3][3], double* __restrict__ Ls)
+{
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll
     for (int u = 0; u < 3; u++)
 #pragma unroll
@@ -401,6 +401,15 @@ __device__ __forceinline__ void dev_load_l11(const double* __restrict__ F, long 
             const double x = (c < nc && r < nc) ? (r >= c ? v[u][q] : 0.0) : (r == c ? 1.0 : 0.0);
             Ls[c * LLD + r] = x;
         }
+}
+__device__ __forceinline__ void dev_load_l11(const double* __restrict__ F, long ld, int nc, double* __restrict__ Ls)
+{
+    // 1024 threads cover the full NC_MAX x NC_MAX LDS matrix, 9 elements each: all global loads (6 per
+    // thread: clamped addresses, no branch) are issued before the first LDS store; everything outside
+    // the nc x nc lower triangle becomes identity / zero
+    double v[3][3];
+    l11_issue(F, ld, nc, v);
+    l11_store(nc, v, Ls);
 }
 
 // Factor the 6-column panel starting at (j0,j0) of the LDS matrix Ls by ONE wave, in registers.
@@ -2072,7 +2081,11 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
     dev_potrf_load(fronts + foff, fld, ncs, Ls, dinv);
     stamp(0, 1);
     if (kids && p.ea_lds)
-    { // straight into the LDS copy (Vs: unused until the W phase, serves as the masked lanes' sink)
+    { // straight into the LDS copy (Vs: unused until the W phase, serves as the masked lanes' sink).
+      // (Measured, not kept: the rel entries and update-block entries of two children fetched into registers
+      // before / beside the loads of F11 — every global load of the phase in flight at once, only the LDS adds
+      // child after child: 11.57 vs 11.22 ms per step on the kitti_00 shape, 38.1 vs 37.5 ms on the 10k-pose
+      // graph.  The phase is not bound by the latency of its loads.)
         dev_extend_add_lead(p, fronts, tm[16], tm[17], Ls, Vs + threadIdx.x);
     }
     if (p.panel16)

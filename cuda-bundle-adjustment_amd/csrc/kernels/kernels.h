@@ -105,7 +105,7 @@ int launch_backsubst_update(hipStream_t s, const cugo_edges& ev, double lambda, 
 // null) receives {chi2, scale, the 8 bytes at d_flag}: readable after the stream has been waited for
 void launch_errors_tail(hipStream_t s, const cugo_edges& ev, const double* d_poses, const double* d_lms,
                         cugo_robust rk, ReduceScratch rs, int n_scale_partials, double* d_out,
-                        const double* d_flag, double* h_out);
+                        const double* d_flag, double* h_out, double seq, unsigned* d_done);
 
 size_t reduce_scratch_doubles(int n_edges, int n_poses, int n_landmarks);
 

@@ -166,6 +166,13 @@ void cugo_chol::upload(hipStream_t s)
     lds_backward = cugo_k::chol_lds_backward_bytes(P.nc_max, P.ld_max);
 }
 
+// CUGO_OWN_MIN_GFLOP (default 3): below this much work per factorisation every rank factors everything
+static double own_min_flops()
+{
+    const char* e = std::getenv("CUGO_OWN_MIN_GFLOP");
+    return 1e9 * (e ? std::atof(e) : 3.0);
+}
+
 void cugo_chol::analyze(int n, const int32_t* rowptr, const int32_t* colind)
 {
     analyze_host(n, rowptr, colind);
@@ -179,9 +186,19 @@ void cugo_chol::analyze_host(int n, const int32_t* rowptr, const int32_t* colind
     CholOptions opt = CholOptions::from_env();
     // CUGO_OWN_SUBTREES=0: every rank factors everything (the replicated form of rounds 1-2)
     const char* own = std::getenv("CUGO_OWN_SUBTREES");
+    // unset: rank-owned subtrees only where the factorisation has work to divide.  On a graph whose levels all
+    // run at the latency floor of their launches (kitti_00 shape: 1.6 GFLOP over 17 levels, every level 18-45 us
+    // whatever its number of fronts) a rank that factors an eighth of a level's fronts finishes the level no
+    // sooner, and the broadcasts at the ownership boundary come on top; CUGO_OWN_SUBTREES=1 forces the form
+    const bool own_forced = own && own[0] == '1';
     if (world > 1 && bcast && !(own && own[0] == '0'))
         opt.rank = rank, opt.world = world;
     chol_analyze(n, rowptr, colind, opt, plan);
+    if (opt.world > 1 && !own_forced && plan.flops < own_min_flops())
+    {
+        opt.rank = 0, opt.world = 1;
+        chol_analyze(n, rowptr, colind, opt, plan);
+    }
     lookahead = std::getenv("CUGO_LOOKAHEAD") && std::atoi(std::getenv("CUGO_LOOKAHEAD")) != 0;
     trans32.assign(plan.blk_trans.begin(), plan.blk_trans.end());
     pack();
@@ -240,9 +257,12 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
         }
         // update blocks that cross the ownership boundary: the subtree roots of this level whose parent is
         // replicated go from their owner to every rank (columns 6 ncb .. of the front: one contiguous range)
+        bool grouped = false;
         for (size_t k = 0; k < plan.xu_front.size(); k++)
             if (plan.xu_stage[k] == st)
             {
+                if (!grouped && bcast_group)
+                    bcast_group(true), grouped = true;
                 const int f = plan.xu_front[k];
                 // from element (c0, c0) to the rhs-row entry of the last column: one contiguous range that stays
                 // inside the front's storage also when the front lives in its child's update block
@@ -251,6 +271,8 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
                     bcast(d_fronts.data() + plan.off[f] + c0 * ld + c0, (size_t)((c1 - 1 - c0) * ld + c1 + 1 - c0),
                           plan.xu_owner[k]);
             }
+        if (grouped)
+            bcast_group(false);
     }
     if (npend > 0) // the last level's tiles (the rhs rows of the roots)
         cugo_k::launch_chol_potrf_la(s, dev, d_fronts.data(), 0, 0, d_wl_ptr + 3L * pend0, npend, pend_tile, d_fail);
@@ -270,8 +292,12 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
     }
     if (!plan.xx_lo.empty())
     { // the solution of the other ranks' subtrees, then the un-permutation of the whole vector
+        if (bcast_group)
+            bcast_group(true);
         for (size_t k = 0; k < plan.xx_lo.size(); k++)
             bcast(d_xnew.data() + 6LL * plan.xx_lo[k], (size_t)(6LL * (plan.xx_hi[k] - plan.xx_lo[k])), plan.xx_owner[k]);
+        if (bcast_group)
+            bcast_group(false);
         cugo_k::launch_chol_unpermute(s, dev, d_xnew.data(), d_x);
     }
     CUGO_HIP(hipGetLastError());

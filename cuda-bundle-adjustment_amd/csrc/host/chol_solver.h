@@ -37,6 +37,7 @@ struct cugo_chol
     // subtrees arrive by `bcast(device pointer, doubles, root rank)` on the solver's stream
     int rank = 0, world = 1;
     std::function<void(double*, size_t, int)> bcast;
+    std::function<void(bool)> bcast_group; // brackets the broadcasts that may be fused into one operation
     bool own_subtrees() const { return world > 1 && bcast && !plan.owner.empty(); }
 
     void analyze(int n, const int32_t* rowptr, const int32_t* colind);

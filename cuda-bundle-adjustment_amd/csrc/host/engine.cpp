@@ -249,9 +249,15 @@ struct Engine::Impl : cugo_k::LaunchHook
     {
         chol.rank = rank, chol.world = world;
         if (world > 1)
+        {
             chol.bcast = [this](double* d, size_t n, int root) { broadcast(d, n, root); };
+            chol.bcast_group = [this](bool start) {
+                if (comm)
+                    comm->group(start);
+            };
+        }
         else
-            chol.bcast = nullptr;
+            chol.bcast = nullptr, chol.bcast_group = nullptr;
         pattern_dirty = true; // the plan depends on (rank, world)
     }
     // broadcast of n doubles at d from rank `root` (update blocks / solution ranges of rank-owned elimination
@@ -1347,6 +1353,8 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
     const bool speculate = !sharded && !m.profile && !(spec_env && spec_env[0] == '0');
     const char* tev_env = std::getenv("CUGO_TRIAL_EVENT"); // 0: wait for the whole stream (A/B)
     const bool trial_event = !(tev_env && tev_env[0] == '0');
+    const char* poll_env = std::getenv("CUGO_TRIAL_POLL"); // 0: wait by event / stream synchronisation
+    const bool trial_poll = !m.profile && !(poll_env && poll_env[0] == '0');
     bool have_build = false;      // the build pass of this iteration is already queued
     double built_lambda = -1.0;   // ... with invHll / T for this damping (< 0: none)
 
@@ -1468,9 +1476,12 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
             const double lambda_pred = lambda * (1.0 / 3.0);
             if (speculate && q == 0 && iteration + 1 < niterations)
             {
-                if (!m.trial_ev)
-                    CUGO_HIP(hipEventCreateWithFlags(&m.trial_ev, hipEventDisableTiming));
-                CUGO_HIP(hipEventRecord(m.trial_ev, s));
+                if (!trial_poll && trial_event)
+                {
+                    if (!m.trial_ev)
+                        CUGO_HIP(hipEventCreateWithFlags(&m.trial_ev, hipEventDisableTiming));
+                    CUGO_HIP(hipEventRecord(m.trial_ev, s));
+                }
                 m.timed("build", [&] {
                     cugo_k::launch_build(s, m.ev, m.d_poses[nxt].data(), m.d_lms[nxt].data(), m.rk, m.d_Hpp.data(),
                                          m.bp(), m.d_Hll.data(), m.bl(), m.d_Hpl.data(), m.rs(), nullptr,
@@ -1492,21 +1503,46 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
             }
             // behind a speculative build the host waits for the trial's own last launch only: it then
             // decides and queues the next Schur complement while the build pass still runs
-            if (spec_queued && trial_event)
-                CUGO_HIP(hipEventSynchronize(m.trial_ev));
-            else
-                CUGO_HIP(hipStreamSynchronize(s));
-            if (!sharded)
-            { // the three words in the pinned block are this trial's (see k_sum_partials2)
+            if (!sharded && trial_poll)
+            {
+                // the trial's last launch ends by writing the trial's sequence number behind its three words in
+                // the pinned block (k_sum_partials2, system-scope release): the host polls that word — no event,
+                // no stream synchronisation, and whatever is queued behind the trial keeps running
                 const volatile double* seq = m.h_scal.data() + 5;
-                for (long spin = 0; *seq != (double)m.trial_seq; spin++)
+                for (unsigned long spin = 1; *seq != (double)m.trial_seq; spin++)
                 {
-                    if (spin == 0)
-                        sstats_.trial_sync_retries += 1;
-                    if (spin > 2000000000L)
-                        throw std::runtime_error("cugo: the result of an LM trial never arrived");
+                    __builtin_ia32_pause();
+                    if ((spin & 0xFFFFF) == 0)
+                    { // every ~10 ms: a stream that is idle or failed will never deliver
+                        const hipError_t q = hipStreamQuery(s);
+                        if (q != hipErrorNotReady)
+                        {
+                            CUGO_HIP(q);
+                            if (*seq != (double)m.trial_seq)
+                                throw std::runtime_error("cugo: the result of an LM trial never arrived");
+                        }
+                    }
                 }
                 std::atomic_thread_fence(std::memory_order_acquire);
+            }
+            else
+            {
+                if (spec_queued && trial_event)
+                    CUGO_HIP(hipEventSynchronize(m.trial_ev));
+                else
+                    CUGO_HIP(hipStreamSynchronize(s));
+                if (!sharded)
+                { // the three words in the pinned block are this trial's
+                    const volatile double* seq = m.h_scal.data() + 5;
+                    for (long spin = 0; *seq != (double)m.trial_seq; spin++)
+                    {
+                        if (spin == 0)
+                            sstats_.trial_sync_retries += 1;
+                        if (spin > 2000000000L)
+                            throw std::runtime_error("cugo: the result of an LM trial never arrived");
+                    }
+                    std::atomic_thread_fence(std::memory_order_acquire);
+                }
             }
             int32_t fail_flag;
             std::memcpy(&fail_flag, m.h_scal.data() + 4, sizeof fail_flag);

@@ -24,6 +24,8 @@ struct Api
     decltype(&ncclCommDestroy) comm_destroy = nullptr;
     decltype(&ncclAllReduce) all_reduce = nullptr;
     decltype(&ncclBroadcast) broadcast = nullptr;
+    decltype(&ncclGroupStart) group_start = nullptr;
+    decltype(&ncclGroupEnd) group_end = nullptr;
     decltype(&ncclGetErrorString) error_string = nullptr;
 };
 
@@ -44,6 +46,8 @@ Api& api()
         a.comm_destroy = reinterpret_cast<decltype(a.comm_destroy)>(dlsym(a.handle, "ncclCommDestroy"));
         a.all_reduce = reinterpret_cast<decltype(a.all_reduce)>(dlsym(a.handle, "ncclAllReduce"));
         a.broadcast = reinterpret_cast<decltype(a.broadcast)>(dlsym(a.handle, "ncclBroadcast"));
+        a.group_start = reinterpret_cast<decltype(a.group_start)>(dlsym(a.handle, "ncclGroupStart"));
+        a.group_end = reinterpret_cast<decltype(a.group_end)>(dlsym(a.handle, "ncclGroupEnd"));
         a.error_string = reinterpret_cast<decltype(a.error_string)>(dlsym(a.handle, "ncclGetErrorString"));
     });
     if (!a.handle || !a.get_unique_id || !a.comm_init_rank || !a.comm_destroy || !a.all_reduce)
@@ -95,6 +99,18 @@ void RcclComm::broadcast(double* d_buf, size_t n, int root, hipStream_t s)
     if (!api().broadcast)
         throw std::runtime_error("cugo: librccl.so has no ncclBroadcast");
     check(api().broadcast(d_buf, d_buf, n, ncclDouble, root, static_cast<ncclComm_t>(comm_), s), "ncclBroadcast");
+}
+
+// the broadcasts between group(true) and group(false) are issued as ONE fused operation (ncclGroupStart / End):
+// the update blocks that cross the ownership boundary after a level have different roots and sizes
+void RcclComm::group(bool start)
+{
+    if (!api().group_start || !api().group_end)
+        return; // (each broadcast then is an operation of its own)
+    if (start)
+        check(api().group_start(), "ncclGroupStart");
+    else
+        check(api().group_end(), "ncclGroupEnd");
 }
 
 } // namespace cugo_host

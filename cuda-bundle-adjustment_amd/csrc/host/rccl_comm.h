@@ -24,6 +24,8 @@ public:
     void all_reduce(double* d_buf, size_t n, int op, hipStream_t s);
     // in-place broadcast of n doubles from rank `root` on `s`; asynchronous
     void broadcast(double* d_buf, size_t n, int root, hipStream_t s);
+    // broadcasts issued between group(true) and group(false) form one fused operation
+    void group(bool start);
     int rank() const { return rank_; }
     int world() const { return world_; }
 

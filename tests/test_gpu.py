@@ -922,6 +922,10 @@ def test_rank_owned_elimination_subtrees_match_unsharded(oracle_lib, world, monk
     as the unsharded run and as the replicated form (CUGO_OWN_SUBTREES=0); the work really is split."""
     d, prob = synth_problem(oracle_lib, 700, 12000, 50000, seed=21, lc=150)
     single = run_graph(d, 6)
+    # (a graph this small stays replicated unless the form is forced: CUGO_OWN_MIN_GFLOP, chol_solver.cpp)
+    auto = run_sharded_in_threads(d, world, 2, want_sstats=True)
+    assert auto[0]["sstats"]["chol_bcasts"] == 0
+    monkeypatch.setenv("CUGO_OWN_SUBTREES", "1")
     res = run_sharded_in_threads(d, world, 6, want_sstats=True)
     ref = prob.optimize(6)
     total = None

@@ -485,10 +485,11 @@ def test_changing_the_shard_forces_a_full_initialize(lib):
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])
-def test_plan_only_rank_owned_subtrees_partition_the_factorisation(lib, world):
+def test_plan_only_rank_owned_subtrees_partition_the_factorisation(lib, world, monkeypatch):
     """rank-owned elimination subtrees of a sharded run (chol_symbolic.cpp, CholPlan::owner), host side only:
     every rank sees the same replicated top, the ranks' own shares add up with it to the whole factorisation
     (the unsharded plan's), and no rank keeps (nearly) all of it"""
+    monkeypatch.setenv("CUGO_OWN_SUBTREES", "1")  # (forced: a graph this small stays replicated by default)
     d = cugo.synth(900, 16000, 66000, seed=4, n_loop_closures=200)
     g = cugo.graph_from_arrays(d, plan_only=True)
     g.initialize()

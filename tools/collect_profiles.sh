@@ -10,7 +10,7 @@ for W in kitti00 synth10k; do
   cp gpurun_out/prof_${R}_${W}_summary.txt profiles/${R}_kernel_stats_summary$sfx.txt
   cp "$(ls -t gpurun_out/prof_${R}_$W/*/*_kernel_stats.csv | head -1)" profiles/${R}_kernel_stats$sfx.csv
 done
-for W in kitti00 synth10k; do for V in gather strip rows; do cp gpurun_out/pmc_schur_${W}_${V}.txt profiles/${R}_pmc_schur_${W}_${V}.txt; done; done
+for W in kitti00 synth10k; do for V in mfma gather strip rows; do cp gpurun_out/pmc_schur_${W}_${V}.txt profiles/${R}_pmc_schur_${W}_${V}.txt; done; done
 python - <<'PY'
 import json
 for src, dst in (("gpurun_out/bench_kitti00.json", "profiles/r03_bench_kitti00.json"),

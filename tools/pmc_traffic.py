@@ -30,7 +30,7 @@ def main():
     shape = sys.argv[3] if len(sys.argv) > 3 else "kitti00"
     out = {
         "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on: "
-                  "python bench.py --workload %s --steps 1 --warmup 1 --no-cpu-baseline --no-extras, round 2 "
+                  "python bench.py --workload %s --steps 1 --warmup 1 --no-cpu-baseline --no-extras, round 3 "
                   "(tools/refresh_profiles.sh)" % shape,
         "note": "FETCH_SIZE on gfx950 under-counts wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM); "
                 "both the raw and the x2-corrected sums are given; gather/scatter patterns are uncalibrated",

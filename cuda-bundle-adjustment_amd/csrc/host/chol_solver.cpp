@@ -57,15 +57,20 @@ void cugo_chol::pack()
     }
     ea1.resize(ea1.size() + 8, 0);
     const size_t o_ea1 = put32(ea1);
-    std::vector<int32_t> tmeta(20 * ntask, 0);
+    std::vector<int32_t> tmeta(cugo_k::TMETA * ntask, 0);
     for (size_t t = 0; t < ntask; t++)
     {
-        int32_t* m = tmeta.data() + 20 * t;
+        int32_t* m = tmeta.data() + cugo_k::TMETA * t;
         const int f = P.task_fronts[P.task_ptr[t]];
         m[0] = P.task_ptr[t + 1] - P.task_ptr[t], m[1] = f, m[2] = P.ncb[f], m[3] = P.nb[f], m[4] = P.col0[f];
         m[5] = P.bw_np[f], m[6] = P.rows_ptr[f];
         m[7] = (P.alias_of[f] < 0 && P.child_ptr[f + 1] > P.child_ptr[f]) ? 1 : 0;
         m[16] = ea1_ptr[f], m[17] = ea1_ptr[f + 1];
+        for (int q = 0; q < 16; q++)
+        { // the first boundary block rows (clamped: a front with fewer repeats its last one)
+            const int nrows = P.rows_ptr[f + 1] - P.rows_ptr[f];
+            m[20 + q] = nrows > 0 ? P.rows[P.rows_ptr[f] + std::min(q, nrows - 1)] : 0;
+        }
         const int64_t q[4] = {P.off[f], P.ldf[f], P.woff[f], P.l21off[f]};
         std::memcpy(m + 8, q, sizeof q);
     }
@@ -81,6 +86,7 @@ void cugo_chol::pack()
         if (f < 0 || f >= P.n_super)
             continue;
         m[3] = 6 * P.ncb[f], m[4] = 6 * (P.nb[f] - P.ncb[f]);
+        m[5] = P.bw_np[f], m[6] = P.col0[f], m[7] = P.rows_ptr[f]; // (the ahead-of-time mat-vec items of the backward pass)
         const int64_t q[4] = {P.off[f], P.ldf[f], P.woff[f], P.l21off[f]};
         std::memcpy(m + 8, q, sizeof q);
         if ((int)i >= P.asm0 && (int)i < P.asm0 + P.nasm)

@@ -22,7 +22,8 @@ struct CholOptions
     int max_front_cols = 16; // hard cap on pivot block columns of a front (LDS-resident L11)
     // a level with more 64x64 tiles than this solves its L21 row tiles once (k_up_trsm) and then runs
     // syrk-only tiles (k_up_syrk) instead of the fused trsm+syrk tile kernel (0: never)
-    int two_phase_min_tiles = 128; // (swept: 128-256 equal on the kitti_00 shape, 64-128 best on the 10k-pose graph)
+    int two_phase_min_tiles = 260; // (re-swept in round 3 with the 16-column potrf: 128 / 260 / 400 / 600 / never = 11.13 / 11.00 / 11.08 /
+                                   // 11.29 / 11.27 ms per step on the kitti_00 shape; 128 / 400 / 800 / 1600 / never = 38.8 / 38.9 / 38.0 / 39.4 / 40.7 ms on the 10k graph)
     bool xcd_affinity = true; // tile items of a front share an index class mod 8, i.e. an XCD and its L2 (CUGO_XCD_AFFINITY=0: listed front by front)
     int tile32_max_tiles = 64; // a level with at most this many 64x64 tiles is cut into 32x32 tiles (0: never)
     // landmark-sharded run (one process per GPU): this rank's schedule holds the fronts of the elimination

@@ -1043,14 +1043,15 @@ __device__ __forceinline__ void dev_potrf16(int ncp, double* __restrict__ lds, d
         }
         if (s == 1)
             stamp(5, 1);
-        if (w < 2)
+        // wave 1 carries rows 64.. of the next panel (only the first panels of a 96-column block have them)
+        const bool panel1 = panel && ncp - jn > 64;
+        if ((w == 0 && panel) || (w == 1 && panel1))
         {
             // the panel wave is the critical path of the slot: it goes first wherever it competes with the
             // other waves of the CU (after the barrier every wave issues its LDS operand loads at once; at
             // equal priority the panel's 16 loads — and later its stores — queue behind ~200 others)
             __builtin_amdgcn_s_setprio(3);
-            if (panel && (w == 0 || ncp - jn > 64))
-                panel16_factor(Ls, ncp, jn, invd, w);
+            panel16_factor(Ls, ncp, jn, invd, w);
             __builtin_amdgcn_s_setprio(0);
             if (s == 1)
                 stamp(5, 2);
@@ -1060,9 +1061,18 @@ __device__ __forceinline__ void dev_potrf16(int ncp, double* __restrict__ lds, d
             // (measured, not kept: the other waves starting ~200 cycles later so that the panel's 16 loads sit at the
             // head of the CU's LDS queue — 11.55 vs 11.54 ms per step)
             // one task per wave: the s + 1 blocks of row s of U, then the remaining trailing tiles.
-            // Waves w and w + 4 share a SIMD (observed placement; speed only): the tasks go first to the
-            // waves that do not sit beside a panel wave (2, 3 mod 4), the heavy ones (U blocks) first
-            const int tw = (w & 3) >= 2 ? (w >> 2) * 2 + (w & 1) : ((w & 3) == 1 ? 8 + (w >> 2) - 1 : 11 + (w >> 2) - 1);
+            // Waves w and w + 4 share a SIMD (observed placement; speed only): the tasks go first to the SIMDs
+            // without a panel wave, the heavy ones (U blocks) first, and round the SIMDs:
+            //   two panel waves (SIMDs 0, 1):  SIMDs 2, 3 (8 waves), then SIMD 1's, then SIMD 0's other waves
+            //   one panel wave (SIMD 0):       SIMDs 1, 2, 3 (12 waves), then SIMD 0's other waves
+            //   no panel (last slot):          every wave, SIMDs 0 1 2 3 0 1 ...
+            int tw, ntw;
+            if (!panel)
+                tw = w, ntw = 16;
+            else if (panel1)
+                tw = (w & 3) >= 2 ? (w >> 2) * 2 + (w & 1) : ((w & 3) == 1 ? 8 + (w >> 2) - 1 : 11 + (w >> 2) - 1), ntw = 14;
+            else
+                tw = (w & 3) ? ((w & 3) - 1) + 3 * (w >> 2) : 11 + (w >> 2), ntw = 15;
             int t = tw;
             if (t <= s)
             {
@@ -1076,7 +1086,7 @@ __device__ __forceinline__ void dev_potrf16(int ncp, double* __restrict__ lds, d
             {
                 const int nt = nblk - (s + 2); // block columns still to update
                 const int ntiles = nt * (nt + 1) / 2;
-                for (t -= s + 1; t < ntiles; t += 13 - s)
+                for (t -= s + 1; t < ntiles; t += ntw - (s + 1))
                 {
                     int tj = 0, rem = t;
                     while (rem >= nt - tj)
@@ -1893,7 +1903,7 @@ __device__ __forceinline__ FrontView front_view(const int32_t* __restrict__ tm)
 
 __device__ __forceinline__ void dev_backward(const CholPlanDev& p, const double* __restrict__ fronts,
                              const FrontView fv, double* __restrict__ lds, double* __restrict__ xnew,
-                             double* __restrict__ xout)
+                             double* __restrict__ xout, const int32_t* __restrict__ rows16 = nullptr)
 {
     const int ncb = fv.ncb, nb = fv.nb;
     const long ld = fv.ldf;
@@ -1928,8 +1938,11 @@ __device__ __forceinline__ void dev_backward(const CholPlanDev& p, const double*
     const int jb = j / 6, comp = j - 6 * jb;
     double xg = 0.0; // this thread's entry of x_R (nr_here <= blockDim on every front of an upper stage)
     const int ig = threadIdx.x;
+    // (rows16: the first 16 boundary block rows ride in the task record — with the ancestor part done ahead
+    // these are all the rows there are, and the gather starts one round trip earlier)
+    const int32_t* rws = (rows16 && nr_here <= 96) ? rows16 : rows;
     if (ig < nr_here)
-        xg = xnew[6L * rows[ig / 6] + (ig % 6)];
+        xg = xnew[6L * rws[ig / 6] + (ig % 6)];
     double a[12], wv[12];
 #pragma unroll
     for (int u = 0; u < 12; u++)
@@ -2059,7 +2072,7 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
     }
     stamp(0, 0);
     // the front's scalars from the task's 64-byte record (one scalar load instead of task -> front -> arrays)
-    const int32_t* tm = p.tmeta + 20 * (task0 + blockIdx.x);
+    const int32_t* tm = p.tmeta + cugo_k::TMETA * (task0 + blockIdx.x);
     const long* tm64 = reinterpret_cast<const long*>(tm + 8);
     const int f = tm[1];
     const int ncs = 6 * tm[2];
@@ -2260,16 +2273,18 @@ __global__ __launch_bounds__(BIG) void k_up_syrk(CholPlanDev p, double* __restri
 // the ancestor part of a front's backward mat-vec, one launch ahead of the front itself:
 // v_j = y_j - sum_{i >= 6*npb} L21[i,j] x_R[i] for the 16 columns j0.. (one wave per column, its
 // 64 lanes stride the rows), parked in xnew at the front's own positions
-__device__ __forceinline__ void dev_backward_ahead(const CholPlanDev& p, int f, int j0, double* __restrict__ lds,
+__device__ __forceinline__ void dev_backward_ahead(const CholPlanDev& p, const int32_t* __restrict__ ft, double* __restrict__ lds,
                                                    double* __restrict__ xnew)
 {
-    const int ncb = p.ncb[f], nb = p.nb[f];
-    const int ncs = 6 * ncb, nrs = 6 * (nb - ncb);
-    const int r0 = 6 * p.bw_np[f]; // first row of the ancestor part
-    const double* L = p.l21 + p.l21off[f];
+    // the item's 64-byte record (CholPlanDev::fat): {front, first column, -, 6 ncb, 6 (nb - ncb), bw_np, col0,
+    // rows_ptr, off, ldf, woff, l21off} — one load instead of item -> front -> six per-front arrays
+    const int j0 = ft[1];
+    const int ncs = ft[3], nrs = ft[4];
+    const int r0 = 6 * ft[5]; // first row of the ancestor part
+    const double* L = p.l21 + reinterpret_cast<const long*>(ft + 8)[3];
     const long ldl = nrs + 1;
-    const int c0 = p.col0[f];
-    const int32_t* rows = p.rows + p.rows_ptr[f];
+    const int c0 = ft[6];
+    const int32_t* rows = p.rows + ft[7];
     double* xr = lds;
     for (int i = r0 + threadIdx.x; i < nrs; i += blockDim.x)
     {
@@ -2311,15 +2326,14 @@ __global__ __launch_bounds__(BIG) void k_backward_stage(CholPlanDev p,
     extern __shared__ double lds[];
     if ((int)blockIdx.x >= ntasks)
     { // ahead-of-time mat-vec of a child of this level's fronts
-        const int32_t* it = wl_gemv + 3 * (blockIdx.x - ntasks);
-        dev_backward_ahead(p, it[0], it[1], lds, xnew);
+        dev_backward_ahead(p, p.fat + 16 * ((int)((wl_gemv - p.wl_base) / 3) + ((int)blockIdx.x - ntasks)), lds, xnew);
         return;
     }
     stamp(3, 0);
     const int task = task0 + blockIdx.x;
-    const int32_t* tm = p.tmeta + 20 * task;
+    const int32_t* tm = p.tmeta + cugo_k::TMETA * task;
     if (tm[0] == 1)
-        dev_backward(p, fronts, front_view(tm), lds, xnew, xout);
+        dev_backward(p, fronts, front_view(tm), lds, xnew, xout, tm + 20);
     else
         for (int fi = p.task_ptr[task + 1] - 1; fi >= p.task_ptr[task]; fi--)
             dev_backward(p, fronts, front_view(p, p.task_fronts[fi]), lds, xnew, xout);

@@ -115,6 +115,7 @@ void launch_edge_chi(hipStream_t s, const cugo_edges& e, const double* d_poses, 
 
 // --- multifrontal LL^T (chol_kernels.hip) -------------------------------------------------
 // Device-side plan; all index arrays in units of 6x6 blocks unless noted.
+constexpr int TMETA = 36; // ints per task record (CholPlanDev::tmeta)
 struct CholPlanDev
 {
     int n_fronts;
@@ -148,8 +149,10 @@ struct CholPlanDev
     const int32_t* ea1;        // per child link: {child, its boundary block rows, its leading rows inside the
                                // parent's pivots, offset of its rel list, update-block offset (int64), its leading
                                // dimension (int64)} — the potrf workgroup's extend-add into F11 (tmeta[16..17])
-    const int32_t* tmeta;      // [n_tasks_total][20] (16..17: range in ea1, 18..19 unused): {fronts in the task, first front, its ncb, nb, col0, bw_np,
-                               // rows_ptr, has-children-to-add flag, off, ldf, woff, l21off (four int64)} (potrf, backward substitution)
+    const int32_t* tmeta;      // [n_tasks_total][TMETA] (16..17: range in ea1, 18..19 unused): {fronts in the task, first front, its ncb, nb, col0, bw_np,
+                               // rows_ptr, has-children-to-add flag, off, ldf, woff, l21off (four int64)} (potrf, backward substitution);
+                               // 20..35: the front's first 16 boundary block rows (those inside its parent's pivot block: the
+                               // backward substitution gathers x_R through them without a round trip to the row lists)
     // k_assemble_fronts (chol_symbolic.h: CholPlan::asm_map): per stored front its map at asm_off[front]
     const int32_t* asm_map;
     const int64_t* asm_off;

@@ -8,6 +8,7 @@
 #include "hip_util.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -94,6 +95,27 @@ void* cache_alloc(size_t bytes, bool pinned, size_t* got_bytes)
     }
     *got_bytes = cls;
     return p;
+}
+
+// CUGO_POISON_ALLOC=1: the two guard zones of a device buffer must still hold their pattern
+void guard_check(const void* raw, size_t payload_bytes, bool floating, const char* what)
+{
+    (void)hipDeviceSynchronize();
+    unsigned char g[2][kGuardBytes];
+    if (hipMemcpy(g[0], raw, kGuardBytes, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(g[1], static_cast<const char*>(raw) + kGuardBytes + payload_bytes, kGuardBytes,
+                  hipMemcpyDeviceToHost) != hipSuccess)
+        return;
+    const unsigned char want = floating ? (unsigned char)poison_byte() : 0x00;
+    for (int side = 0; side < 2; side++)
+        for (size_t i = 0; i < kGuardBytes; i++)
+            if (g[side][i] != want)
+            {
+                std::fprintf(stderr,
+                             "cugo: guard zone %s a device buffer of %zu bytes was overwritten at byte %zu (%s)\n",
+                             side ? "behind" : "before", payload_bytes, i, what);
+                std::abort();
+            }
 }
 
 void cache_free(void* p)

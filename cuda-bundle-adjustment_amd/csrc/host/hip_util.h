@@ -48,6 +48,23 @@ inline bool poison_alloc()
     static const bool on = std::getenv("CUGO_POISON_ALLOC") != nullptr;
     return on;
 }
+// the byte a poisoned floating-point buffer is filled with: 0xFF (NaN; CUGO_POISON_ALLOC=1) or 0x40 (=2: the finite
+// value 32.5 / 3.004f — garbage that max / min / comparisons do not swallow the way they swallow a NaN)
+inline int poison_byte()
+{
+    static const int b = [] {
+        const char* e = std::getenv("CUGO_POISON_ALLOC");
+        return e && e[0] == '2' ? 0x40 : 0xFF;
+    }();
+    return b;
+}
+
+// Debugging aid (CUGO_POISON_ALLOC=1): every device buffer sits between two 256-byte guard zones; a fresh
+// floating-point buffer and its guards start as NaNs (an int buffer's guards as zeros).  A result that depends
+// on memory nobody wrote, or on a read past a buffer's end, then shows up as NaN instead of as a run-to-run
+// difference, and a write past a buffer's end is reported (on stderr, then abort) when the buffer is released.
+constexpr size_t kGuardBytes = 256;
+void guard_check(const void* raw, size_t payload_bytes, bool floating, const char* what); // device_cache.cpp
 
 template <typename T>
 class DevBuf
@@ -60,25 +77,45 @@ public:
     void release()
     {
         if (p_)
-            cache_free(p_);
+        {
+            if (guarded_)
+            {
+                guard_check(raw(), payload_, std::is_floating_point<T>::value, "release");
+                cache_free(raw());
+            }
+            else
+                cache_free(p_);
+        }
         p_ = nullptr;
         cap_ = n_ = 0;
+        guarded_ = false;
     }
     // grow-only; contents are NOT preserved (and a fresh buffer is NOT zeroed)
     void resize(size_t n)
     {
         if (n > cap_)
         {
-            if (p_)
-                cache_free(p_);
-            p_ = nullptr;
+            release();
             size_t got = 0;
-            p_ = static_cast<T*>(cache_alloc((n + 16) * sizeof(T), false, &got));
-            cap_ = got / sizeof(T);
-            // debugging aid (CUGO_POISON_ALLOC=1): a fresh floating-point buffer starts as NaNs, so a result that
-            // depends on memory nobody wrote shows up as NaN instead of as a run-to-run difference
-            if (std::is_floating_point<T>::value && poison_alloc())
-                CUGO_HIP(hipMemset(p_, 0xFF, got));
+            if (poison_alloc())
+            {
+                payload_ = (n + 16) * sizeof(T);
+                payload_ = (payload_ + 255) & ~size_t(255);
+                char* r = static_cast<char*>(cache_alloc(payload_ + 2 * kGuardBytes, false, &got));
+                const bool fl = std::is_floating_point<T>::value;
+                CUGO_HIP(hipMemset(r, fl ? poison_byte() : 0x00, kGuardBytes));
+                if (fl)
+                    CUGO_HIP(hipMemset(r + kGuardBytes, poison_byte(), payload_));
+                CUGO_HIP(hipMemset(r + kGuardBytes + payload_, fl ? poison_byte() : 0x00, kGuardBytes));
+                p_ = reinterpret_cast<T*>(r + kGuardBytes);
+                cap_ = payload_ / sizeof(T) - 16;
+                guarded_ = true;
+            }
+            else
+            {
+                p_ = static_cast<T*>(cache_alloc((n + 16) * sizeof(T), false, &got));
+                cap_ = got / sizeof(T);
+            }
         }
         n_ = n;
     }
@@ -98,8 +135,10 @@ public:
     size_t size() const { return n_; }
 
 private:
+    void* raw() const { return reinterpret_cast<char*>(p_) - kGuardBytes; }
     T* p_ = nullptr;
-    size_t cap_ = 0, n_ = 0;
+    size_t cap_ = 0, n_ = 0, payload_ = 0;
+    bool guarded_ = false;
 };
 
 template <typename T>

@@ -1934,7 +1934,6 @@ __device__ __forceinline__ void dev_backward(const CholPlanDev& p, const double*
     const int j = min(g, ncs - 1);
     const double* col = L + (long)j * ldl;
     const double* wcol = Wg + (long)j * ncp;
-    const int k0 = (j & ~15) + l8;
     const int jb = j / 6, comp = j - 6 * jb;
     double xg = 0.0; // this thread's entry of x_R (nr_here <= blockDim on every front of an upper stage)
     const int ig = threadIdx.x;
@@ -1943,14 +1942,25 @@ __device__ __forceinline__ void dev_backward(const CholPlanDev& p, const double*
     const int32_t* rws = (rows16 && nr_here <= 96) ? rows16 : rows;
     if (ig < nr_here)
         xg = xnew[6L * rws[ig / 6] + (ig % 6)];
+    // 16-byte loads: the 8 lanes of a column read one full 128-byte line per instruction (rows 2 l8 + 16 u and the
+    // one after it) — half the load instructions and half the cache-line requests of 8-byte loads at stride 8.
+    // (col + i is only 8-byte aligned when the column length is odd: global loads take that; index nrs — the
+    // rhs entry — exists, so the pair (nrs - 1, nrs) is in bounds)
     double a[12], wv[12];
 #pragma unroll
-    for (int u = 0; u < 12; u++)
-        a[u] = col[min(l8 + 8 * u, nrs - 1)];
+    for (int u = 0; u < 6; u++)
+    {
+        const double2 v = *reinterpret_cast<const double2*>(col + min(2 * l8 + 16 * u, max(nrs - 1, 0)));
+        a[2 * u] = v.x, a[2 * u + 1] = v.y;
+    }
     const double y = npb >= 0 ? xnew[6L * c0 + j] : col[nrs];
+    const int k0 = (j & ~15) + 2 * l8;
 #pragma unroll
-    for (int u = 0; u < 12; u++)
-        wv[u] = wcol[min(k0 + 8 * u, ncp - 1)];
+    for (int u = 0; u < 6; u++)
+    { // (ncp is a multiple of 16 and k0 + 16 u is even: aligned, and k0 + 16 u + 1 < ncp whenever k0 + 16 u < ncp)
+        const double2 v = *reinterpret_cast<const double2*>(wcol + min(k0 + 16 * u, ncp - 2));
+        wv[2 * u] = v.x, wv[2 * u + 1] = v.y;
+    }
     const int pj = p.perm[c0 + jb];
     if (ig < nr_here)
         xr[ig] = xg;
@@ -1968,16 +1978,25 @@ __device__ __forceinline__ void dev_backward(const CholPlanDev& p, const double*
         double s = 0;
 #pragma unroll
         for (int u = 0; u < 12; u++)
-            s += (l8 + 8 * u < nr_here) ? a[u] * xr[l8 + 8 * u] : 0.0;
-        for (int i = 96 + l8; i < nr_here; i += 96)
+        {
+            const int i = 2 * l8 + 16 * (u >> 1) + (u & 1);
+            s += (i < nr_here) ? a[u] * xr[i] : 0.0;
+        }
+        for (int i0 = 96; i0 < nr_here; i0 += 96)
         { // rows beyond the first 96 (a front that does its whole mat-vec itself)
             double b[12];
 #pragma unroll
-            for (int u = 0; u < 12; u++)
-                b[u] = col[min(i + 8 * u, nrs - 1)];
+            for (int u = 0; u < 6; u++)
+            {
+                const double2 v = *reinterpret_cast<const double2*>(col + min(i0 + 2 * l8 + 16 * u, max(nrs - 1, 0)));
+                b[2 * u] = v.x, b[2 * u + 1] = v.y;
+            }
 #pragma unroll
             for (int u = 0; u < 12; u++)
-                s += (i + 8 * u < nr_here) ? b[u] * xr[i + 8 * u] : 0.0;
+            {
+                const int i = i0 + 2 * l8 + 16 * (u >> 1) + (u & 1);
+                s += (i < nr_here) ? b[u] * xr[i] : 0.0;
+            }
         }
 #pragma unroll
         for (int off = 4; off > 0; off >>= 1)
@@ -1993,7 +2012,10 @@ __device__ __forceinline__ void dev_backward(const CholPlanDev& p, const double*
         double s = 0;
 #pragma unroll
         for (int u = 0; u < 12; u++)
-            s += (k0 + 8 * u < ncp) ? wv[u] * vs[k0 + 8 * u] : 0.0;
+        {
+            const int k = k0 + 16 * (u >> 1) + (u & 1);
+            s += (k < ncp) ? wv[u] * vs[k] : 0.0;
+        }
 #pragma unroll
         for (int off = 4; off > 0; off >>= 1)
             s += __shfl_xor(s, off, 8);

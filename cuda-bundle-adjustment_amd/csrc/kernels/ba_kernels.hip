@@ -1196,7 +1196,8 @@ __global__ __launch_bounds__(HD_BS) void k_hsc_diag(EV ev, const int32_t* __rest
         const int lsafe = act ? l : 0;
         double2 tv = ld_pair(T, 9 * (size_t)e + part9);
         const double2 hv = ld_pair(Hpl, 9 * (size_t)e + part9);
-        const double bv = act ? bl[3 * (size_t)lsafe + min(part9, 2)] : 0.0; // (see k_hsc_diag_mfma)
+        const double bvl = bl[3 * (size_t)lsafe + min(part9, 2)];
+        const double bv = act ? bvl : 0.0; // (see k_hsc_diag_mfma)
         if (!act)
             tv = make_double2(0, 0); // the edge contributes nothing
         if (writer)
@@ -1312,8 +1313,11 @@ __global__ __launch_bounds__(HM_BS, 8) void k_hsc_diag_mfma(EV ev, const int32_t
         const double2 ha = ld_pair(Hpl, 9 * (size_t)ea + part9), hb = ld_pair(Hpl, 9 * (size_t)eb + part9);
         // (an inactive edge contributes a zero T block, but 0 x whatever sits at bl[0] must stay 0: with no free
         // landmark at all bl is empty and that word is memory nobody wrote)
-        const double ba = acta ? bl[3 * (size_t)la + min(part9, 2)] : 0.0;
-        const double bb = actb ? bl[3 * (size_t)lb + min(part9, 2)] : 0.0;
+        // (loaded unconditionally — a conditional load is a branch on the dependent chain: 40 -> 46 us — and
+        // selected afterwards)
+        const double bla = bl[3 * (size_t)(acta ? la : 0) + min(part9, 2)];
+        const double blb = bl[3 * (size_t)(actb ? lb : 0) + min(part9, 2)];
+        const double ba = acta ? bla : 0.0, bb = actb ? blb : 0.0;
         if (!acta)
             ta = make_double2(0, 0); // the edge contributes nothing
         if (!actb)

@@ -389,6 +389,9 @@ __device__ __forceinline__ void l11_issue(const double* __restrict__ F, long ld,
             v[u][q] = q < u ? 0.0 : ldg32(F, (unsigned)min(c, nc - 1) * uld + (unsigned)min(r, nc - 1));
         }
 }
+// MIRROR: the diagonal 16x16 tiles are stored symmetric right away (what dev_potrf16 otherwise does in a pass of
+// its own after the extend-add: a front without children to add needs no such pass)
+template <bool MIRROR = false>
 __device__ __forceinline__ void l11_store(int nc, const double (&v)[3][3], double* __restrict__ Ls)
 {
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -399,9 +402,14 @@ __device__ __forceinline__ void l11_store(int nc, const double (&v)[3][3], doubl
         {
             const int c = ty + 32 * u, r = tx + 32 * q;
             const double x = (c < nc && r < nc) ? (r >= c ? v[u][q] : 0.0) : (r == c ? 1.0 : 0.0);
-            Ls[c * LLD + r] = x;
+            const bool tile = MIRROR && (r >> 4) == (c >> 4);
+            if (!(tile && r < c)) // (the strict upper triangle of a diagonal tile is written by the mirror partner)
+                Ls[c * LLD + r] = x;
+            if (tile && r > c)
+                Ls[r * LLD + c] = x;
         }
 }
+template <bool MIRROR = false>
 __device__ __forceinline__ void dev_load_l11(const double* __restrict__ F, long ld, int nc, double* __restrict__ Ls)
 {
     // 1024 threads cover the full NC_MAX x NC_MAX LDS matrix, 9 elements each: all global loads (6 per
@@ -409,7 +417,7 @@ __device__ __forceinline__ void dev_load_l11(const double* __restrict__ F, long 
     // the nc x nc lower triangle becomes identity / zero
     double v[3][3];
     l11_issue(F, ld, nc, v);
-    l11_store(nc, v, Ls);
+    l11_store<MIRROR>(nc, v, Ls);
 }
 
 // Factor the 6-column panel starting at (j0,j0) of the LDS matrix Ls by ONE wave, in registers.
@@ -658,10 +666,11 @@ __device__ __forceinline__ void panel_update_next(double* __restrict__ Ls, int n
 // factorisation) overlaps the parallel part (trailing update).
 // On return Ls holds L11 (lower) and dinv the reciprocal diagonal.  L11 is NOT written back to
 // F: every later consumer (trsm, backward substitution) works with W = L11^-1 (dev_winv).
+template <bool MIRROR = false>
 __device__ __forceinline__ void dev_potrf_load(const double* __restrict__ F, long ld, int nc, double* __restrict__ Ls,
                                                double* __restrict__ dinv)
 {
-    dev_load_l11(F, ld, nc, Ls);
+    dev_load_l11<MIRROR>(F, ld, nc, Ls);
     if (threadIdx.x < NC_MAX)
         dinv[threadIdx.x] = 1.0; // identity padding; the panels overwrite the real columns
     __syncthreads();
@@ -1002,7 +1011,7 @@ __device__ __forceinline__ void p16_utask(const double* __restrict__ Ls, const d
 // F11 (ncp x ncp in LDS, lower triangle, identity padding) -> W = F11^-1/2-inverse in global memory.
 // lds: Ls | invd | rsv | Vs | Ub  (p16::LDS_DOUBLES doubles)
 __device__ __forceinline__ void dev_potrf16(int ncp, double* __restrict__ lds, double* __restrict__ Wg,
-                                            int32_t* __restrict__ fail)
+                                            int32_t* __restrict__ fail, bool mirrored = false)
 {
     double* Ls = lds;
     double* invd = lds + p16::OFF_INV;
@@ -1012,13 +1021,16 @@ __device__ __forceinline__ void dev_potrf16(int ncp, double* __restrict__ lds, d
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // the diagonal 16x16 tiles become symmetric: the trailing update treats them as full tiles and a
     // panel load is then the same plain column walk for every lane
-    for (int e = threadIdx.x; e < nblk * 256; e += blockDim.x)
+    if (!mirrored) // (uniform; a front without children to add had its tiles mirrored by the load)
     {
-        const int b = e >> 8, r = (e >> 4) & 15, c = e & 15;
-        if (r > c)
-            Ls[(16 * b + r) * LLD + 16 * b + c] = Ls[(16 * b + c) * LLD + 16 * b + r];
+        for (int e = threadIdx.x; e < nblk * 256; e += blockDim.x)
+        {
+            const int b = e >> 8, r = (e >> 4) & 15, c = e & 15;
+            if (r > c)
+                Ls[(16 * b + r) * LLD + 16 * b + c] = Ls[(16 * b + c) * LLD + 16 * b + r];
+        }
+        __syncthreads();
     }
-    __syncthreads();
     stamp(0, 2);
     if (w == 0 || (w == 1 && ncp > 64))
         panel16_factor(Ls, ncp, 0, invd, w);
@@ -2113,7 +2125,11 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
         __threadfence_block();
         __syncthreads();
     }
-    dev_potrf_load(fronts + foff, fld, ncs, Ls, dinv);
+    const bool mirror_now = p.panel16 && !kids; // nothing will be added to F11: the diagonal tiles go in symmetric
+    if (mirror_now)
+        dev_potrf_load<true>(fronts + foff, fld, ncs, Ls, dinv);
+    else
+        dev_potrf_load(fronts + foff, fld, ncs, Ls, dinv);
     stamp(0, 1);
     if (kids && p.ea_lds)
     { // straight into the LDS copy (Vs: unused until the W phase, serves as the masked lanes' sink).
@@ -2125,7 +2141,7 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
     }
     if (p.panel16)
     { // 16-column L D L^T panels, W built behind them (dev_potrf16)
-        dev_potrf16(ncp, lds, p.winv + fwoff, fail);
+        dev_potrf16(ncp, lds, p.winv + fwoff, fail, mirror_now);
         stamp_value(0, 6, ncs);
         stamp(0, 7);
         return;

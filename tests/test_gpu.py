@@ -1105,3 +1105,25 @@ def test_repeated_new_optimisers_no_memory_drift(oracle_lib):
         soak.main()
     finally:
         sys.argv = argv
+
+
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_no_result_depends_on_unwritten_device_memory(mode):
+    """CUGO_POISON_ALLOC (hip_util.h): every device buffer of the library sits between guard zones, and a fresh
+    floating-point buffer starts as NaNs (mode 1) or as the finite value 32.5 (mode 2: what max / min /
+    comparisons do not swallow).  A part of this suite — golden trajectories, degenerate fixed sets (no free
+    landmark / no free pose), float storage, the medium graphs with every Cholesky form, outlier rejection, the
+    soak cycles — runs in a child process in that mode: a result that read memory nobody wrote is wrong there,
+    and a store past a buffer's end aborts the child when the buffer is released.  (Found this way: the diagonal
+    Schur kernels multiplied a zero T block with bl[0], unwritten when no landmark is free.)"""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, CUGO_POISON_ALLOC=mode)
+    sel = ("golden or degenerate or float32_block_storage or medium_synthetic or outlier or repeated_new or "
+           "more_than_256 or schur_complement_and_backsubst or bitwise_reproducible")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu.py"), "-m", "gpu", "-q", "-x",
+                        "-p", "no:cacheprovider", "-k", sel], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "guard zone" not in r.stderr

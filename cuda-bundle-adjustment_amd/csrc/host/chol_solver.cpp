@@ -158,6 +158,10 @@ void cugo_chol::upload(hipStream_t s)
         D.ea_lds = !(e && e[0] == '0');
         const char* e16 = std::getenv("CUGO_PANEL16");
         D.panel16 = !(e16 && e16[0] == '0');
+        const char* ez = std::getenv("CUGO_DEBUG_ZERO_LDS");
+        D.zero_lds = ez && ez[0] == '1';
+        const char* ep = std::getenv("CUGO_EA_PIPE");
+        D.ea_pipe = ep && ep[0] == '1';
     }
     D.l21off = b64 + o_l21off, D.l21 = d_l21.data();
     D.ldf = b64 + o_ldf, D.alias_of = b32 + o_alias, D.bw_np = b32 + o_bwnp, D.la_np = b32 + o_lanp;

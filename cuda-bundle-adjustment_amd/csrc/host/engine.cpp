@@ -97,6 +97,7 @@ struct Engine::Impl : cugo_k::LaunchHook
 
     DevBuf<int32_t> d_e_pose, d_e_lm, d_lm_ptr, d_pose_ptr, d_pose_edge;
     DevBuf<int32_t> d_pose_rec; // [n][4] per entry of the pose-major list: slot, end of its landmark, landmark, flags (k_hsc_rows)
+    DevBuf<unsigned long long> d_hash; // diagnosis (CUGO_DEBUG_HASH=file): per iteration 16 stage checksums
     uint64_t trial_seq = 0;        // sequence number of the last LM trial whose result the host waited for
     hipEvent_t trial_ev = nullptr; // end of a trial whose successor build is already queued (optimize)
     bool rows_on = false;       // the Schur complement by block rows (k_hsc_rows; CUGO_HSC_ROWS=0: the gather kernels)
@@ -1351,6 +1352,19 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
     // H is rebuilt from the kept estimates before the retry.  Same arithmetic on the same data in every case.
     const char* spec_env = std::getenv("CUGO_SPECULATE");
     const bool speculate = !sharded && !m.profile && !(spec_env && spec_env[0] == '0');
+    // diagnosis: CUGO_DEBUG_HASH=<file> — position-weighted integer checksums of the arrays every stage of the
+    // first trial of an iteration leaves behind, computed by kernels queued in the same stream (no host
+    // synchronisation: the flow of the loop stays what it is), appended to the file when optimize() returns
+    const char* hash_file = std::getenv("CUGO_DEBUG_HASH");
+    if (hash_file)
+    {
+        m.d_hash.resize(16 * (size_t)std::max(niterations, 1));
+        m.d_hash.zero(s);
+    }
+    auto hash = [&](int iteration, int slot, const void* p, size_t words) {
+        if (hash_file)
+            cugo_k::launch_hash_words(s, p, words, m.d_hash.data() + 16 * (size_t)iteration + slot);
+    };
     const char* tev_env = std::getenv("CUGO_TRIAL_EVENT"); // 0: wait for the whole stream (A/B)
     const bool trial_event = !(tev_env && tev_env[0] == '0');
     const char* poll_env = std::getenv("CUGO_TRIAL_POLL"); // 0: wait by event / stream synchronisation
@@ -1430,6 +1444,14 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
                 });
                 spec_queued = false;
             }
+            const size_t blkw = (m.ev.block_f32 ? 9 : 18) * (size_t)m.E;
+            if (q == 0)
+            { // what the build pass left
+                hash(iteration, 0, m.d_Hpp.data(), 36 * (size_t)m.P);
+                hash(iteration, 1, m.d_b.data(), 6 * (size_t)m.P + 3 * (size_t)m.L);
+                hash(iteration, 2, m.d_Hll.data(), 9 * (size_t)m.L);
+                hash(iteration, 3, m.d_Hpl.data(), blkw);
+            }
             auto ts = Clock::now();
             m.timed("schur", [&] {
                 cugo_k::launch_schur(s, m.ev, m.hs, lambda, 0, m.d_Hpp.data(), m.bp(),
@@ -1441,11 +1463,20 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
             if (sharded)
                 m.exchange(m.d_sys.data(), 36 * (size_t)m.hs.n_blocks + 6 * (size_t)m.P, 0);
             sync_prof(PROF_SCHUR, ts);
+            if (q == 0)
+            {
+                hash(iteration, 4, m.d_sys.data(), 36 * (size_t)m.hs.n_blocks + 6 * (size_t)m.P);
+                if (m.d_T.size())
+                    hash(iteration, 5, m.d_T.data(), blkw);
+                hash(iteration, 6, m.d_invHll.data(), 9 * (size_t)m.L);
+            }
             auto tn = Clock::now();
             m.timed("cholesky", [&] {
                 m.chol.factor_solve(m.Hsc(), lambda, m.bsc(), m.xp(), d_fail);
             });
             sync_prof(PROF_NUMERIC, tn);
+            if (q == 0)
+                hash(iteration, 7, m.xp(), 6 * (size_t)m.P);
             auto tu = Clock::now();
             const int nxt = m.cur ^ 1;
             // single process: the two reductions that end a trial (scale of the update pass, chi2 of
@@ -1460,6 +1491,12 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
                     m.d_poses[nxt].data(), m.d_lms[nxt].data(), m.rs(), sharded ? m.d_scal.data() + 3 : nullptr);
             });
             sync_prof(PROF_UPDATE, tu);
+            if (q == 0)
+            {
+                hash(iteration, 8, m.xl(), 3 * (size_t)m.L);
+                hash(iteration, 9, m.d_poses[nxt].data(), 7 * (size_t)m.Pall);
+                hash(iteration, 10, m.d_lms[nxt].data(), 3 * (size_t)m.Lall);
+            }
             auto te = Clock::now();
             m.timed("errors", [&] {
                 if (sharded)
@@ -1581,6 +1618,23 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
                         iteration, ms_since(it0), F, lambda, rho, E_global_, q);
         if (q == maxq || rho < 1e-6 || !std::isfinite(lambda))
             break;
+    }
+    if (hash_file)
+    {
+        std::vector<unsigned long long> h(m.d_hash.size());
+        CUGO_HIP(hipMemcpyAsync(h.data(), m.d_hash.data(), h.size() * sizeof(h[0]), hipMemcpyDeviceToHost, s));
+        CUGO_HIP(hipStreamSynchronize(s));
+        if (FILE* fp = std::fopen(hash_file, "a"))
+        {
+            std::fprintf(fp, "run\n");
+            for (size_t it = 0; it < records.size(); it++)
+            {
+                for (int k = 0; k < 11; k++)
+                    std::fprintf(fp, "%016llx ", h[16 * it + k]);
+                std::fprintf(fp, "\n");
+            }
+            std::fclose(fp);
+        }
     }
     m.collect_times();
 }

@@ -363,6 +363,94 @@ __device__ __forceinline__ void dev_extend_add_lead(const CholPlanDev& p, const 
 
 __device__ __forceinline__ int pad16(int nc) { return (nc + 15) & ~15; }
 
+// dev_extend_add_lead with the NEXT child's loads in flight while the current child's entries are added: a wave's
+// (block column, 64-row chunk) units of a child — at most two: a child has <= 22 units (np <= 16 block columns of
+// <= 96 rows) for 16 waves — are fetched into registers (rel entries, then the update-block entries), and only the
+// LDS read-modify-writes run child after child behind a barrier: the sums keep their order, bit for bit.
+struct EaUnit
+{
+    double u[6];
+    int dst;     // LDS offset of (row, first column of the unit); -1: the wave has no such unit
+    unsigned ok; // bit jj: column jj holds an entry of this lane (inside the chunk, row >= column)
+};
+__device__ __forceinline__ void ea_unit_load(const CholPlanDev& p, const double* __restrict__ fronts, int k, int t,
+                                             int lane, const double* __restrict__ sink, EaUnit& r)
+{
+    const int32_t* d = p.ea1 + 8 * k;
+    const long* d64 = reinterpret_cast<const long*>(d + 4);
+    const int nbr = d[1], np = d[2];
+    const int32_t* rel = p.rel + d[3];
+    const double* U = fronts + d64[0];
+    const long ldc = d64[1];
+    int jb = 0;
+    for (; jb < np; jb++)
+    { // (wave-uniform: unit t of the child -> block column jb, chunk t)
+        const int nch = (6 * (np - jb) + 63) >> 6;
+        if (t < nch)
+            break;
+        t -= nch;
+    }
+    r.dst = -1, r.ok = 0;
+    if (jb >= np)
+    {
+#pragma unroll
+        for (int jj = 0; jj < 6; jj++)
+            r.u[jj] = 0.0;
+        return;
+    }
+    const int i = 6 * jb + 64 * t + lane;
+    const bool ok = i < 6 * np;
+    const int ic = ok ? i : 6 * jb, ib = ic / 6;
+    const int rjb = rel[jb], rr = rel[min(ib, nbr - 1)];
+    r.dst = (6 * rjb) * LLD + 6 * rr + (ic - 6 * ib);
+#pragma unroll
+    for (int jj = 0; jj < 6; jj++)
+    {
+        const int j = 6 * jb + jj;
+        const bool okj = ok && ic >= j;
+        r.ok |= okj ? 1u << jj : 0u;
+        r.u[jj] = *(okj ? U + (long)j * ldc + ic : sink);
+    }
+}
+__device__ __forceinline__ void ea_unit_apply(const EaUnit& r, double* __restrict__ Ls, double* __restrict__ sink_lds)
+{
+    if (r.dst < 0)
+        return; // wave-uniform
+    double* dst[6];
+    double v[6];
+#pragma unroll
+    for (int jj = 0; jj < 6; jj++)
+        dst[jj] = (r.ok >> jj & 1) ? Ls + r.dst + jj * LLD : sink_lds;
+#pragma unroll
+    for (int jj = 0; jj < 6; jj++)
+        v[jj] = *dst[jj];
+#pragma unroll
+    for (int jj = 0; jj < 6; jj++)
+        *dst[jj] = v[jj] + r.u[jj];
+}
+__device__ __forceinline__ void dev_extend_add_lead_piped(const CholPlanDev& p, const double* __restrict__ fronts, int e0,
+                                                          int e1, double* __restrict__ Ls, double* sink_lds)
+{
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const double* sink = p.junk + ((blockIdx.x & 63) << 10) + threadIdx.x;
+    EaUnit c0, c1, n0, n1;
+    ea_unit_load(p, fronts, e0, wv, lane, sink, c0);
+    ea_unit_load(p, fronts, e0, wv + 16, lane, sink, c1);
+    for (int k = e0; k < e1; k++)
+    {
+        const bool more = k + 1 < e1; // uniform
+        if (more)
+        {
+            ea_unit_load(p, fronts, k + 1, wv, lane, sink, n0);
+            ea_unit_load(p, fronts, k + 1, wv + 16, lane, sink, n1);
+        }
+        ea_unit_apply(c0, Ls, sink_lds), ea_unit_apply(c1, Ls, sink_lds);
+        __syncthreads(); // the next child may touch the same entries
+        if (more)
+            c0 = n0, c1 = n1;
+    }
+}
+
 // load base[idx] with a 32-bit BYTE offset: `uniform 64-bit base + zero-extended 32-bit offset` is
 // the addressing mode of global_load (saddr + voffset) — one VALU instruction per address instead
 // of a 64-bit multiply-add pair.  idx * 8 must fit 32 bits (a front / a W block always does).
@@ -2105,6 +2193,12 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
         return;
     }
     stamp(0, 0);
+    if (p.zero_lds)
+    { // (diagnosis: CUGO_DEBUG_ZERO_LDS=1 — nothing may depend on what the previous kernel left in LDS)
+        for (int i = threadIdx.x; i < p16::LDS_DOUBLES + 8; i += blockDim.x)
+            lds[i] = 0.0;
+        __syncthreads();
+    }
     // the front's scalars from the task's 64-byte record (one scalar load instead of task -> front -> arrays)
     const int32_t* tm = p.tmeta + cugo_k::TMETA * (task0 + blockIdx.x);
     const long* tm64 = reinterpret_cast<const long*>(tm + 8);
@@ -2137,7 +2231,10 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
       // before / beside the loads of F11 — every global load of the phase in flight at once, only the LDS adds
       // child after child: 11.57 vs 11.22 ms per step on the kitti_00 shape, 38.1 vs 37.5 ms on the 10k-pose
       // graph.  The phase is not bound by the latency of its loads.)
-        dev_extend_add_lead(p, fronts, tm[16], tm[17], Ls, Vs + threadIdx.x);
+        if (p.ea_pipe && tm[17] - tm[16] >= 2)
+            dev_extend_add_lead_piped(p, fronts, tm[16], tm[17], Ls, Vs + threadIdx.x);
+        else
+            dev_extend_add_lead(p, fronts, tm[16], tm[17], Ls, Vs + threadIdx.x);
     }
     if (p.panel16)
     { // 16-column L D L^T panels, W built behind them (dev_potrf16)
@@ -2531,6 +2628,21 @@ void launch_chol_lead(hipStream_t s, const CholPlanDev& p, double* d_fronts, con
                 d_fronts, d_lead, nlead, d_eap, neap, d_eab);
 }
 
+__global__ __launch_bounds__(256) void k_hash_words(const unsigned long long* __restrict__ p, size_t n,
+                                                    unsigned long long* __restrict__ out)
+{
+    unsigned long long h = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        h += p[i] * (2 * i + 1); // (position-weighted: a swap of two words changes the sum)
+    atomicAdd(out, h);
+}
+void launch_hash_words(hipStream_t s, const void* p, size_t n_words, unsigned long long* out)
+{
+    if (n_words == 0)
+        return;
+    const int nb = (int)std::min<size_t>(512, (n_words + 255) / 256);
+    hipLaunchKernelGGL(k_hash_words, dim3(nb), dim3(256), 0, s, static_cast<const unsigned long long*>(p), n_words, out);
+}
 void launch_flag_to_double(hipStream_t s, int32_t* d_flag) { CUGO_LAUNCH(k_flag_to_double, dim3(1), dim3(1), 0, s, d_flag); }
 
 void launch_chol_unpermute(hipStream_t s, const CholPlanDev& p, const double* d_xnew, double* d_x)

@@ -1,0 +1,50 @@
+"""GPU box: one medium graph (400 poses / 8 000 landmarks / 33 000 edges, 200 loop closures — the shape on which the
+suite's rare run-to-run differences were seen) optimised N times per configuration from the same estimates by NEW
+optimisers; counts the runs whose chi2 trace or final poses differ from the first run bit for bit.
+    python tools/repro_medium.py N [VAR=val,VAR=val ...]"""
+import importlib, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+cugo = importlib.import_module("cuda-bundle-adjustment_amd")
+import numpy as np
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+configs = [dict(kv.split("=") for kv in a.split(",") if kv) for a in sys.argv[2:]] or [{}]
+d = cugo.synth(400, 8000, 33000, seed=11, n_loop_closures=200)
+for cfg in configs:
+    for k, v in cfg.items():
+        os.environ[k] = v
+    f32 = cfg.get("F32") == "1"
+    ref, bad = None, []
+    hf = os.environ.get("CUGO_DEBUG_HASH")
+    SLOTS = ["Hpp", "b", "Hll", "Hpl", "Hsc|bsc", "T", "invHll", "x_p", "x_l", "poses'", "landmarks'"]
+
+    def last_hashes():
+        blocks = open(hf).read().split("run\n")
+        return [ln.split() for ln in blocks[-1].strip().splitlines()]
+    href = None
+    for c in range(N):
+        if hf and os.path.exists(hf):
+            os.remove(hf)
+        g = cugo.graph_from_arrays(d)
+        if f32:
+            g.set_float32(True)
+        g.initialize(); g.optimize(10)
+        st = g.stats()
+        cur = (tuple(s["chi2"] for s in st), g.poses().copy(), [(s["lam"], s["rho"], s["trials"]) for s in st])
+        g.close()
+        hcur = last_hashes() if hf else None
+        if ref is None:
+            ref, href = cur, hcur
+        elif cur[0] != ref[0] or not np.array_equal(cur[1], ref[1]):
+            it = next((i for i, (a, b) in enumerate(zip(cur[0], ref[0])) if a != b), -1)
+            bad.append((c, it, abs(cur[0][it] - ref[0][it]) / ref[0][it] if it >= 0 else 0.0))
+            lo = max(it - 2, 0)
+            print("  run", c, "first chi2 difference at iteration", it)
+            if hf:
+                first = next(((i, k) for i in range(min(len(href), len(hcur))) for k in range(11) if href[i][k] != hcur[i][k]), None)
+                print("    first differing array: iteration %s, %s" % ((first[0], SLOTS[first[1]]) if first else ("-", "none")),
+                      " all differing in that iteration:", [SLOTS[k] for k in range(11) if first and href[first[0]][k] != hcur[first[0]][k]])
+            for i in range(lo, min(it + 2, len(ref[0]))):
+                print("    it %d  chi2 %r / %r   (lam, rho, trials) %r / %r" % (i, cur[0][i], ref[0][i], cur[2][i], ref[2][i]), flush=True)
+    print(cfg, "runs", N, "deviating", len(bad), bad[:8], flush=True)
+    for k in cfg:
+        os.environ.pop(k, None)

@@ -158,6 +158,8 @@ void cugo_chol::upload(hipStream_t s)
         D.ea_lds = !(e && e[0] == '0');
         const char* e16 = std::getenv("CUGO_PANEL16");
         D.panel16 = !(e16 && e16[0] == '0');
+        const char* ed = std::getenv("CUGO_DEBUG_DELAY");
+        D.dbg_delay = ed ? std::atoi(ed) : 0;
         const char* ez = std::getenv("CUGO_DEBUG_ZERO_LDS");
         D.zero_lds = ez && ez[0] == '1';
         const char* ep = std::getenv("CUGO_EA_PIPE");

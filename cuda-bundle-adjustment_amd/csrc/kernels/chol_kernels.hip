@@ -868,6 +868,15 @@ __device__ __forceinline__ int opaque_lane()
     return lane;
 }
 
+// diagnosis (CUGO_DEBUG_DELAY=n): chosen waves / workgroups of k_up_potrf sleep ~25 k cycles at chosen points.  A
+// kernel without a race gives the same bits whatever runs late.
+__device__ __forceinline__ void dbg_sleep()
+{
+#pragma unroll 1
+    for (int i = 0; i < 3; i++)
+        __builtin_amdgcn_s_sleep(127);
+}
+
 __device__ __forceinline__ void stamp_wave(int kernel, int slot)
 {
 #ifdef CUGO_STAMPS
@@ -1099,7 +1108,7 @@ __device__ __forceinline__ void p16_utask(const double* __restrict__ Ls, const d
 // F11 (ncp x ncp in LDS, lower triangle, identity padding) -> W = F11^-1/2-inverse in global memory.
 // lds: Ls | invd | rsv | Vs | Ub  (p16::LDS_DOUBLES doubles)
 __device__ __forceinline__ void dev_potrf16(int ncp, double* __restrict__ lds, double* __restrict__ Wg,
-                                            int32_t* __restrict__ fail, bool mirrored = false)
+                                            int32_t* __restrict__ fail, bool mirrored = false, int dbg_delay = 0)
 {
     double* Ls = lds;
     double* invd = lds + p16::OFF_INV;
@@ -1137,6 +1146,8 @@ __device__ __forceinline__ void dev_potrf16(int ncp, double* __restrict__ lds, d
             // phase A: the block column of the next panel, <= 5 tiles, one per wave, on waves 0 1 2 3 6 (four
             // different SIMDs first)
             const int ta = w < 4 ? w : (w == 6 ? 4 : 99);
+            if (dbg_delay == 3 && (w & 1))
+                dbg_sleep();
             if (s + 1 + ta < nblk)
                 panel16_update_tile(Ls, invd, j0, 16 * (s + 1 + ta), jn);
             __syncthreads();
@@ -1145,6 +1156,8 @@ __device__ __forceinline__ void dev_potrf16(int ncp, double* __restrict__ lds, d
             stamp(5, 1);
         // wave 1 carries rows 64.. of the next panel (only the first panels of a 96-column block have them)
         const bool panel1 = panel && ncp - jn > 64;
+        if ((dbg_delay == 1 && w >= 2) || (dbg_delay == 2 && w < 2) || (dbg_delay == 4 && (w & 2)))
+            dbg_sleep();
         if ((w == 0 && panel) || (w == 1 && panel1))
         {
             // the panel wave is the critical path of the slot: it goes first wherever it competes with the
@@ -2188,11 +2201,15 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
     if ((int)blockIdx.x >= npotrf)
     { // items of the pivot columns first, then of the boundary columns
         const int b = blockIdx.x - npotrf;
+        if (p.dbg_delay == 6)
+            dbg_sleep();
         const int32_t* it = b < neap ? wl_eap + 3 * b : wl_eab + 3 * (b - neap);
         dev_extend_add(p, fronts, it[0], it[1], it[2], 2); // everything below the parents' F11
         return;
     }
     stamp(0, 0);
+    if (p.dbg_delay == 5)
+        dbg_sleep();
     if (p.zero_lds)
     { // (diagnosis: CUGO_DEBUG_ZERO_LDS=1 — nothing may depend on what the previous kernel left in LDS)
         for (int i = threadIdx.x; i < p16::LDS_DOUBLES + 8; i += blockDim.x)
@@ -2238,7 +2255,7 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
     }
     if (p.panel16)
     { // 16-column L D L^T panels, W built behind them (dev_potrf16)
-        dev_potrf16(ncp, lds, p.winv + fwoff, fail, mirror_now);
+        dev_potrf16(ncp, lds, p.winv + fwoff, fail, mirror_now, p.dbg_delay);
         stamp_value(0, 6, ncs);
         stamp(0, 7);
         return;

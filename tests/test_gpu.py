@@ -1127,3 +1127,20 @@ def test_no_result_depends_on_unwritten_device_memory(mode):
                         "-p", "no:cacheprovider", "-k", sel], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "guard zone" not in r.stderr
+
+
+def test_potrf_gives_the_same_bits_whichever_waves_run_late(monkeypatch):
+    """CUGO_DEBUG_DELAY (chol_kernels.hip: dbg_sleep): chosen waves / workgroups of k_up_potrf — the task waves, the
+    panel waves, every other wave of phase A or B, the potrf workgroups, the extend-add workgroups of the same
+    launch — sleep ~25 k cycles at the start of their phase.  Every hand-over inside the kernel goes through a
+    barrier, so the optimisation must end on the same bits whatever runs late (tools/delay_check.py does the same
+    on the kitti_00 shape as well)."""
+    d = cugo.synth(400, 8000, 33000, seed=11, n_loop_closures=200)
+    ref = None
+    for delay in (0, 1, 2, 3, 4, 5, 6):
+        monkeypatch.setenv("CUGO_DEBUG_DELAY", str(delay))
+        out = run_graph(d, 5)
+        cur = ([s["chi2"] for s in out["stats"]], out["pose"])
+        if ref is None:
+            ref = cur
+        assert cur[0] == ref[0] and np.array_equal(cur[1], ref[1]), delay

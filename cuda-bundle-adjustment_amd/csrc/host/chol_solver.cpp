@@ -162,8 +162,6 @@ void cugo_chol::upload(hipStream_t s)
         D.dbg_delay = ed ? std::atoi(ed) : 0;
         const char* ez = std::getenv("CUGO_DEBUG_ZERO_LDS");
         D.zero_lds = ez && ez[0] == '1';
-        const char* ep = std::getenv("CUGO_EA_PIPE");
-        D.ea_pipe = ep && ep[0] == '1';
     }
     D.l21off = b64 + o_l21off, D.l21 = d_l21.data();
     D.ldf = b64 + o_ldf, D.alias_of = b32 + o_alias, D.bw_np = b32 + o_bwnp, D.la_np = b32 + o_lanp;

@@ -363,94 +363,6 @@ __device__ __forceinline__ void dev_extend_add_lead(const CholPlanDev& p, const 
 
 __device__ __forceinline__ int pad16(int nc) { return (nc + 15) & ~15; }
 
-// dev_extend_add_lead with the NEXT child's loads in flight while the current child's entries are added: a wave's
-// (block column, 64-row chunk) units of a child — at most two: a child has <= 22 units (np <= 16 block columns of
-// <= 96 rows) for 16 waves — are fetched into registers (rel entries, then the update-block entries), and only the
-// LDS read-modify-writes run child after child behind a barrier: the sums keep their order, bit for bit.
-struct EaUnit
-{
-    double u[6];
-    int dst;     // LDS offset of (row, first column of the unit); -1: the wave has no such unit
-    unsigned ok; // bit jj: column jj holds an entry of this lane (inside the chunk, row >= column)
-};
-__device__ __forceinline__ void ea_unit_load(const CholPlanDev& p, const double* __restrict__ fronts, int k, int t,
-                                             int lane, const double* __restrict__ sink, EaUnit& r)
-{
-    const int32_t* d = p.ea1 + 8 * k;
-    const long* d64 = reinterpret_cast<const long*>(d + 4);
-    const int nbr = d[1], np = d[2];
-    const int32_t* rel = p.rel + d[3];
-    const double* U = fronts + d64[0];
-    const long ldc = d64[1];
-    int jb = 0;
-    for (; jb < np; jb++)
-    { // (wave-uniform: unit t of the child -> block column jb, chunk t)
-        const int nch = (6 * (np - jb) + 63) >> 6;
-        if (t < nch)
-            break;
-        t -= nch;
-    }
-    r.dst = -1, r.ok = 0;
-    if (jb >= np)
-    {
-#pragma unroll
-        for (int jj = 0; jj < 6; jj++)
-            r.u[jj] = 0.0;
-        return;
-    }
-    const int i = 6 * jb + 64 * t + lane;
-    const bool ok = i < 6 * np;
-    const int ic = ok ? i : 6 * jb, ib = ic / 6;
-    const int rjb = rel[jb], rr = rel[min(ib, nbr - 1)];
-    r.dst = (6 * rjb) * LLD + 6 * rr + (ic - 6 * ib);
-#pragma unroll
-    for (int jj = 0; jj < 6; jj++)
-    {
-        const int j = 6 * jb + jj;
-        const bool okj = ok && ic >= j;
-        r.ok |= okj ? 1u << jj : 0u;
-        r.u[jj] = *(okj ? U + (long)j * ldc + ic : sink);
-    }
-}
-__device__ __forceinline__ void ea_unit_apply(const EaUnit& r, double* __restrict__ Ls, double* __restrict__ sink_lds)
-{
-    if (r.dst < 0)
-        return; // wave-uniform
-    double* dst[6];
-    double v[6];
-#pragma unroll
-    for (int jj = 0; jj < 6; jj++)
-        dst[jj] = (r.ok >> jj & 1) ? Ls + r.dst + jj * LLD : sink_lds;
-#pragma unroll
-    for (int jj = 0; jj < 6; jj++)
-        v[jj] = *dst[jj];
-#pragma unroll
-    for (int jj = 0; jj < 6; jj++)
-        *dst[jj] = v[jj] + r.u[jj];
-}
-__device__ __forceinline__ void dev_extend_add_lead_piped(const CholPlanDev& p, const double* __restrict__ fronts, int e0,
-                                                          int e1, double* __restrict__ Ls, double* sink_lds)
-{
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const double* sink = p.junk + ((blockIdx.x & 63) << 10) + threadIdx.x;
-    EaUnit c0, c1, n0, n1;
-    ea_unit_load(p, fronts, e0, wv, lane, sink, c0);
-    ea_unit_load(p, fronts, e0, wv + 16, lane, sink, c1);
-    for (int k = e0; k < e1; k++)
-    {
-        const bool more = k + 1 < e1; // uniform
-        if (more)
-        {
-            ea_unit_load(p, fronts, k + 1, wv, lane, sink, n0);
-            ea_unit_load(p, fronts, k + 1, wv + 16, lane, sink, n1);
-        }
-        ea_unit_apply(c0, Ls, sink_lds), ea_unit_apply(c1, Ls, sink_lds);
-        __syncthreads(); // the next child may touch the same entries
-        if (more)
-            c0 = n0, c1 = n1;
-    }
-}
-
 // load base[idx] with a 32-bit BYTE offset: `uniform 64-bit base + zero-extended 32-bit offset` is
 // the addressing mode of global_load (saddr + voffset) — one VALU instruction per address instead
 // of a 64-bit multiply-add pair.  idx * 8 must fit 32 bits (a front / a W block always does).
@@ -2248,10 +2160,9 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
       // before / beside the loads of F11 — every global load of the phase in flight at once, only the LDS adds
       // child after child: 11.57 vs 11.22 ms per step on the kitti_00 shape, 38.1 vs 37.5 ms on the 10k-pose
       // graph.  The phase is not bound by the latency of its loads.)
-        if (p.ea_pipe && tm[17] - tm[16] >= 2)
-            dev_extend_add_lead_piped(p, fronts, tm[16], tm[17], Ls, Vs + threadIdx.x);
-        else
-            dev_extend_add_lead(p, fronts, tm[16], tm[17], Ls, Vs + threadIdx.x);
+        // (a second attempt — the NEXT child's rel and update-block entries fetched into registers while the current
+        // child's are added, nothing else changed — was slower as well: 11.14 vs 10.97 ms, 38.6 vs 37.9 ms)
+        dev_extend_add_lead(p, fronts, tm[16], tm[17], Ls, Vs + threadIdx.x);
     }
     if (p.panel16)
     { // 16-column L D L^T panels, W built behind them (dev_potrf16)

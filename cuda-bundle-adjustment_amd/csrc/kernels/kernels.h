@@ -139,7 +139,6 @@ struct CholPlanDev
     int panel16;               // potrf: 16-column register panels (CUGO_PANEL16=0: the 6-column LDS panels)
     int dbg_delay;             // diagnosis (CUGO_DEBUG_DELAY): which waves / workgroups of k_up_potrf sleep (chol_kernels.hip: dbg_sleep)
     int zero_lds;              // diagnosis (CUGO_DEBUG_ZERO_LDS): k_up_potrf clears its LDS first
-    int ea_pipe;               // potrf: the next child's contributions fetched while the current child's are added (CUGO_EA_PIPE)
     const int32_t* col0;       // first pivot column (new ordering, block units)
     const int32_t* rows_ptr;   // [n_fronts+1] into rows: boundary block rows (new ordering)
     const int32_t* rows;

@@ -944,6 +944,8 @@ void Engine::fill_structure_stats(int B, double products, double offdiag_product
         auto copy = [](auto& dst, const auto& src) {
             dst.resize(src.size());
             const size_t bytes = src.size() * sizeof(src[0]);
+            if (bytes == 0)
+                return; // (an empty vector's data() may be null: not a valid memcpy argument)
             const char* from = reinterpret_cast<const char*>(src.data());
             char* to = reinterpret_cast<char*>(dst.data());
             parallel_chunks(bytes, 1u << 18, [&](size_t a, size_t b, unsigned) { std::memcpy(to + a, from + a, b - a); });

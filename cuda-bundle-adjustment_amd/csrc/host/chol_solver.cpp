@@ -158,6 +158,8 @@ void cugo_chol::upload(hipStream_t s)
         D.ea_lds = !(e && e[0] == '0');
         const char* e16 = std::getenv("CUGO_PANEL16");
         D.panel16 = !(e16 && e16[0] == '0');
+        const char* ka = std::getenv("CUGO_KERNEL_ACQUIRE");
+        D.kernel_acquire = ka && ka[0] == '1';
         const char* ed = std::getenv("CUGO_DEBUG_DELAY");
         D.dbg_delay = ed ? std::atoi(ed) : 0;
         const char* ez = std::getenv("CUGO_DEBUG_ZERO_LDS");
@@ -235,6 +237,12 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
     cugo_k::launch_chol_assemble(s, dev, d_fronts.data(), (size_t)plan.front_doubles, d_Hsc, lambda, d_bsc, d_fail,
                                  d_wl_ptr + 3L * plan.clr0, plan.nclr, asm_fronts ? d_wl_ptr + 3L * plan.asm0 : nullptr,
                                  plan.nasm);
+    static const bool dbg_gap = std::getenv("CUGO_DEBUG_GAP") != nullptr; // diagnosis: an empty kernel after every level
+    auto hash = [&](int slot, const double* ptr, size_t n) {
+        if (dbg_hash && slot < 64)
+            cugo_k::launch_hash_words(s, ptr, n, dbg_hash + slot);
+    };
+    hash(11, d_fronts.data(), (size_t)plan.front_doubles);
     int pend0 = 0, npend = 0, pend_tile = 64; // update tiles of the previous level, not launched yet
     for (int st = 0; st < plan.n_stages; st++)
     {
@@ -265,6 +273,10 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
                                               d_wl_ptr + 3L * plan.syrk_ptr[st],
                                               plan.syrk_ptr[st + 1] - plan.syrk_ptr[st]);
         }
+        hash(16 + st, d_winv.data(), (size_t)plan.winv_doubles);
+        hash(40 + st, d_fronts.data(), (size_t)plan.front_doubles);
+        if (dbg_gap)
+            cugo_k::launch_nop(s);
         // update blocks that cross the ownership boundary: the subtree roots of this level whose parent is
         // replicated go from their owner to every rank (columns 6 ncb .. of the front: one contiguous range)
         bool grouped = false;
@@ -286,6 +298,9 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
     }
     if (npend > 0) // the last level's tiles (the rhs rows of the roots)
         cugo_k::launch_chol_potrf_la(s, dev, d_fronts.data(), 0, 0, d_wl_ptr + 3L * pend0, npend, pend_tile, d_fail);
+    hash(12, d_winv.data(), (size_t)plan.winv_doubles);
+    hash(13, d_l21.data(), (size_t)plan.l21_doubles);
+    hash(14, d_fronts.data(), (size_t)plan.front_doubles);
     for (int st = plan.n_stages - 1; st >= 0; st--)
     {
         const int t0 = plan.stage_task_ptr[st], t1 = plan.stage_task_ptr[st + 1];
@@ -300,6 +315,7 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
             CUGO_HIP(hipMemcpy(d_stamps + 48, d_stamps + 24, 8 * sizeof(long long), hipMemcpyDeviceToDevice));
         }
     }
+    hash(15, d_xnew.data(), (size_t)6 * plan.n);
     if (!plan.xx_lo.empty())
     { // the solution of the other ranks' subtrees, then the un-permutation of the whole vector
         if (bcast_group)

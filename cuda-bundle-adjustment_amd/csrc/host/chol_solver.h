@@ -38,6 +38,10 @@ struct cugo_chol
     int rank = 0, world = 1;
     std::function<void(double*, size_t, int)> bcast;
     std::function<void(bool)> bcast_group; // brackets the broadcasts that may be fused into one operation
+    // diagnosis (CUGO_DEBUG_HASH): 64 checksum slots of the factorisation being queued, or null —
+    // 11 fronts after the assembly, 12 / 13 / 14 W, L21, fronts after the forward pass, 15 x after the backward pass,
+    // 16 + st: W after the potrf launch of stage st, 40 + st: the fronts after the tile launches of stage st
+    unsigned long long* dbg_hash = nullptr;
     bool own_subtrees() const { return world > 1 && bcast && !plan.owner.empty(); }
 
     void analyze(int n, const int32_t* rowptr, const int32_t* colind);

@@ -1360,12 +1360,12 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
     const char* hash_file = std::getenv("CUGO_DEBUG_HASH");
     if (hash_file)
     {
-        m.d_hash.resize(16 * (size_t)std::max(niterations, 1));
+        m.d_hash.resize(64 * (size_t)std::max(niterations, 1));
         m.d_hash.zero(s);
     }
     auto hash = [&](int iteration, int slot, const void* p, size_t words) {
         if (hash_file)
-            cugo_k::launch_hash_words(s, p, words, m.d_hash.data() + 16 * (size_t)iteration + slot);
+            cugo_k::launch_hash_words(s, p, words, m.d_hash.data() + 64 * (size_t)iteration + slot);
     };
     const char* tev_env = std::getenv("CUGO_TRIAL_EVENT"); // 0: wait for the whole stream (A/B)
     const bool trial_event = !(tev_env && tev_env[0] == '0');
@@ -1473,9 +1473,11 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
                 hash(iteration, 6, m.d_invHll.data(), 9 * (size_t)m.L);
             }
             auto tn = Clock::now();
+            m.chol.dbg_hash = hash_file && q == 0 ? m.d_hash.data() + 64 * (size_t)iteration : nullptr;
             m.timed("cholesky", [&] {
                 m.chol.factor_solve(m.Hsc(), lambda, m.bsc(), m.xp(), d_fail);
             });
+            m.chol.dbg_hash = nullptr;
             sync_prof(PROF_NUMERIC, tn);
             if (q == 0)
                 hash(iteration, 7, m.xp(), 6 * (size_t)m.P);
@@ -1631,8 +1633,8 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
             std::fprintf(fp, "run\n");
             for (size_t it = 0; it < records.size(); it++)
             {
-                for (int k = 0; k < 11; k++)
-                    std::fprintf(fp, "%016llx ", h[16 * it + k]);
+                for (int k = 0; k < 64; k++)
+                    std::fprintf(fp, "%016llx ", h[64 * it + k]);
                 std::fprintf(fp, "\n");
             }
             std::fclose(fp);

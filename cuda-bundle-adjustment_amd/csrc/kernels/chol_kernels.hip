@@ -11,17 +11,20 @@
 //                         (off by default, CUGO_MIN_SUBTREE_TASKS=0 enables it; k_subtree_factor)
 //   upper stages        : one etree level per stage, two batched kernels per level so that a
 //                         big front is spread over many workgroups (256 CUs / 8 XCDs):
-//        k_up_potrf       1 workgroup / front: extend-add of the children into F11, L11 = chol(F11)
-//                         in LDS, then W = L11^-1 on the matrix cores; extra workgroups of the
-//                         same launch do the extend-add of everything below F11
+//        k_up_potrf       1 workgroup / front: extend-add of the children into F11, F11 = L D L^T in LDS
+//                         by 16-column register panels, W = L11^-1 = D^-1/2 L^-1 built behind the panels
+//                         (dev_potrf16; CUGO_PANEL16=0: 6-column L L^T panels, then W in a phase of its
+//                         own); extra workgroups of the same launch do the extend-add of everything below F11
 //        k_up_trsyrk      per 64x64 tile of the update matrix: X = B W^T for its two L21 row
 //                         tiles, U -= X_i X_j^T, all v_mfma_f64_16x16x4_f64 (k_up_trsyrk32: 32x32
 //                         tiles on the levels with few fronts); the items of a front share an XCD
 //        (k_up_potrf_la / k_up_lead: the opt-in look-ahead schedule, CUGO_LOOKAHEAD=1)
 //   backward            : k_backward_stage per level, x_J = W^T (y_J - L21^T x_R): two mat-vecs;
 //                         the ancestor part of L21^T x_R is done one launch ahead (extra workgroups)
-//   before every factorisation: k_clear_fronts (lower triangles only) and k_assemble_blocks
-//                         (Hsc blocks + lambda, right-hand side, reset of the zero-pivot flag)
+//   before every factorisation: k_assemble_fronts — ONE launch that zeroes every lower-triangle entry no Hsc block
+//                         or right-hand side entry lands on and scatters Hsc (+ lambda), the right-hand side and
+//                         the reset of the zero-pivot flag (CUGO_ASM_FRONTS=0: k_clear_fronts + k_assemble_blocks)
+//   (levels with more than 260 tiles of 64x64: k_up_trsm + k_up_syrk, every L21 row tile solved once)
 //
 // The right-hand side rides along as the last row of every front, so L y = b is a by-product
 // of the factorisation (y ends in the rhs row of the pivot columns); only the backward
@@ -2057,6 +2060,16 @@ __device__ __forceinline__ void dev_backward(const CholPlanDev& p, const double*
 
 constexpr int BIG = 1024; // workgroup size of the latency-critical single-front kernels
 
+// CUGO_KERNEL_ACQUIRE=1: every kernel of the factorisation starts with an agent-scope acquire fence of its own
+// (buffer_inv sc1: the CU's vector cache and the non-coherent lines of its L2 are dropped) on top of what the
+// dispatch does between two kernels of a stream — see DESIGN.md section 2 (the rare run-to-run deviation reads
+// like a consumer kernel seeing the PREVIOUS factorisation's value of something its producer just rewrote)
+__device__ __forceinline__ void kernel_acquire(const CholPlanDev& p)
+{
+    if (p.kernel_acquire)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
 // ---------------------------------------------------------------- stage 0: subtrees ----
 __global__ __launch_bounds__(BIG) void k_subtree_factor(CholPlanDev p, double* __restrict__ fronts,
                                                         int task0, int32_t* __restrict__ fail)
@@ -2109,6 +2122,7 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
                                                   const int32_t* __restrict__ wl_eab,
                                                   int32_t* __restrict__ fail)
 {
+    kernel_acquire(p);
     extern __shared__ double lds[];
     if ((int)blockIdx.x >= npotrf)
     { // items of the pivot columns first, then of the boundary columns
@@ -2206,6 +2220,7 @@ __device__ __forceinline__ TileItem tile_item(const CholPlanDev& p, const int32_
 __global__ __launch_bounds__(BIG) void k_up_trsyrk(CholPlanDev p, double* __restrict__ fronts,
                                                    const int32_t* __restrict__ wl)
 {
+    kernel_acquire(p);
     extern __shared__ double lds[];
     stamp(4, 0);
     const TileItem t = tile_item(p, wl);
@@ -2218,6 +2233,7 @@ __global__ __launch_bounds__(BIG) void k_up_trsyrk(CholPlanDev p, double* __rest
 __global__ __launch_bounds__(BIG) void k_up_trsyrk32(CholPlanDev p, double* __restrict__ fronts,
                                                      const int32_t* __restrict__ wl)
 {
+    kernel_acquire(p);
     extern __shared__ double lds[];
     const TileItem t = tile_item(p, wl);
     dev_trsyrk_tile32(fronts + t.off, t.ld, t.ncs, t.nrs + 1, t.nrs, t.a, t.b, p.winv + t.woff, p.l21 + t.l21off,
@@ -2319,6 +2335,7 @@ constexpr int KC_SYRK2 = 48;
 __global__ __launch_bounds__(BIG) void k_up_trsm(CholPlanDev p, double* __restrict__ fronts,
                                                  const int32_t* __restrict__ wl)
 {
+    kernel_acquire(p);
     extern __shared__ double lds[];
     const TileItem t = tile_item(p, wl);
     dev_trsm_w(fronts + t.off, t.ld, t.ncs, (long)t.ncs + t.a, t.b, p.winv + t.woff, lds, p.junk, p.l21 + t.l21off,
@@ -2328,6 +2345,7 @@ __global__ __launch_bounds__(BIG) void k_up_trsm(CholPlanDev p, double* __restri
 __global__ __launch_bounds__(BIG) void k_up_syrk(CholPlanDev p, double* __restrict__ fronts,
                                                  const int32_t* __restrict__ wl)
 {
+    kernel_acquire(p);
     extern __shared__ double lds[];
     const TileItem t = tile_item(p, wl);
     dev_syrk_tiles<KC_SYRK2>(fronts + t.off, t.ld, t.ncs, t.nrs + 1, t.nrs, t.a, t.a + 1, t.b, lds, p.junk);
@@ -2386,6 +2404,7 @@ __global__ __launch_bounds__(BIG) void k_backward_stage(CholPlanDev p,
                                                         double* __restrict__ xnew,
                                                         double* __restrict__ xout)
 {
+    kernel_acquire(p);
     extern __shared__ double lds[];
     if ((int)blockIdx.x >= ntasks)
     { // ahead-of-time mat-vec of a child of this level's fronts
@@ -2564,6 +2583,8 @@ __global__ __launch_bounds__(256) void k_hash_words(const unsigned long long* __
         h += p[i] * (2 * i + 1); // (position-weighted: a swap of two words changes the sum)
     atomicAdd(out, h);
 }
+__global__ void k_nop() {}
+void launch_nop(hipStream_t s) { hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, s); }
 void launch_hash_words(hipStream_t s, const void* p, size_t n_words, unsigned long long* out)
 {
     if (n_words == 0)

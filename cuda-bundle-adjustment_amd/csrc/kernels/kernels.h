@@ -137,6 +137,7 @@ struct CholPlanDev
     int nc_max;                // widest pivot block (scalars)
     int ea_lds;                // potrf: children's contributions to F11 go straight into its LDS copy
     int panel16;               // potrf: 16-column register panels (CUGO_PANEL16=0: the 6-column LDS panels)
+    int kernel_acquire;        // every kernel of the factorisation starts with an agent-scope acquire fence (CUGO_KERNEL_ACQUIRE)
     int dbg_delay;             // diagnosis (CUGO_DEBUG_DELAY): which waves / workgroups of k_up_potrf sleep (chol_kernels.hip: dbg_sleep)
     int zero_lds;              // diagnosis (CUGO_DEBUG_ZERO_LDS): k_up_potrf clears its LDS first
     const int32_t* col0;       // first pivot column (new ordering, block units)
@@ -211,6 +212,7 @@ void launch_chol_backward_stage(hipStream_t s, const CholPlanDev& p, double* d_f
                                 const int32_t* d_wl_gemv, int ngemv);
 // LDS bytes of the factor kernels (L11 + one 64-row tile) and of the backward kernel
 // diagnosis (CUGO_DEBUG_HASH): *out += the sum of the n 64-bit words at p (integer sum: order-independent)
+void launch_nop(hipStream_t s); // diagnosis (CUGO_DEBUG_GAP): an empty kernel
 void launch_hash_words(hipStream_t s, const void* p, size_t n_words, unsigned long long* out);
 void launch_flag_to_double(hipStream_t s, int32_t* d_flag); // int32 0 / 1 -> double 0.0 / 1.0 in the same 8-byte slot
 void launch_chol_unpermute(hipStream_t s, const CholPlanDev& p, const double* d_xnew, double* d_x);

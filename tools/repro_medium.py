@@ -15,7 +15,11 @@ for cfg in configs:
     f32 = cfg.get("F32") == "1"
     ref, bad = None, []
     hf = os.environ.get("CUGO_DEBUG_HASH")
-    SLOTS = ["Hpp", "b", "Hll", "Hpl", "Hsc|bsc", "T", "invHll", "x_p", "x_l", "poses'", "landmarks'"]
+    SLOTS = (["Hpp", "b", "Hll", "Hpl", "Hsc|bsc", "T", "invHll", "x_p", "x_l", "poses'", "landmarks'", "fronts after assembly",
+              "W after forward", "L21 after forward", "fronts after forward", "x after backward"] +
+             ["W after potrf of stage %d" % i for i in range(24)] + ["fronts after tiles of stage %d" % i for i in range(24)])
+    # order in which the arrays come into being within an iteration
+    ORDER = [0, 1, 2, 3, 4, 5, 6, 11] + [k for i in range(24) for k in (16 + i, 40 + i)] + [12, 13, 14, 15, 7, 8, 9, 10]
 
     def last_hashes():
         blocks = open(hf).read().split("run\n")
@@ -40,9 +44,9 @@ for cfg in configs:
             lo = max(it - 2, 0)
             print("  run", c, "first chi2 difference at iteration", it)
             if hf:
-                first = next(((i, k) for i in range(min(len(href), len(hcur))) for k in range(11) if href[i][k] != hcur[i][k]), None)
+                first = next(((i, k) for i in range(min(len(href), len(hcur))) for k in ORDER if href[i][k] != hcur[i][k]), None)
                 print("    first differing array: iteration %s, %s" % ((first[0], SLOTS[first[1]]) if first else ("-", "none")),
-                      " all differing in that iteration:", [SLOTS[k] for k in range(11) if first and href[first[0]][k] != hcur[first[0]][k]])
+                      " all differing in that iteration:", [SLOTS[k] for k in ORDER if first and href[first[0]][k] != hcur[first[0]][k]][:12])
             for i in range(lo, min(it + 2, len(ref[0]))):
                 print("    it %d  chi2 %r / %r   (lam, rho, trials) %r / %r" % (i, cur[0][i], ref[0][i], cur[2][i], ref[2][i]), flush=True)
     print(cfg, "runs", N, "deviating", len(bad), bad[:8], flush=True)

@@ -1,25 +1,40 @@
 # GPU box: is this a box (and a time) at which the rare run-to-run deviation shows?  If so:
-# which kind of separation between the kernels of the factorisation makes it go away?
+# which configuration makes it go away?  The deviation comes in bursts, so the configurations take turns in short
+# blocks (one process each: some of the switches are read by the HIP runtime when it starts) and the counts are summed.
 #   gpurun --timeout 1150 -- bash tools/hunt_deviation.sh
 set -e
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-run() { # name, runs, env...
+rm -f gpurun_out/hunt_*.txt
+block() { # name, runs, env...
   name=$1; n=$2; shift 2
-  env "$@" timeout -k 10 400 python tools/repro_medium.py $n "" > gpurun_out/hunt_$name.txt 2>&1 || true
-  echo "$name: $(grep -v '^    it \|^  run\|^    first' gpurun_out/hunt_$name.txt | cut -c1-160)"
+  env "$@" timeout -k 10 300 python tools/repro_medium.py $n "" >> gpurun_out/hunt_$name.txt 2>&1 || true
 }
-run control1 800 CUGO_X=0
-if grep -q "deviating 0 " gpurun_out/hunt_control1.txt; then echo "clean box"; exit 0; fi
-run gap 2500 CUGO_DEBUG_GAP=1
-run control2 800 CUGO_X=0
-run serialize3 2500 AMD_SERIALIZE_KERNEL=3
-run control3 800 CUGO_X=0
-run serialize1 2500 AMD_SERIALIZE_KERNEL=1
-run serialize2 2500 AMD_SERIALIZE_KERNEL=2
-run control4 800 CUGO_X=0
-run panel16_0 2500 CUGO_PANEL16=0
-run hsc_mfma_0 2500 CUGO_HSC_MFMA=0
-run control5 800 CUGO_X=0
+hipcc --offload-arch=gfx950 -O2 tools/mfma_selftest.hip -o /tmp/mfma_selftest 2> /dev/null
+selftest() { timeout -k 10 200 /tmp/mfma_selftest 240 20000 > gpurun_out/hunt_selftest_$1.txt 2>&1 || true; tail -12 gpurun_out/hunt_selftest_$1.txt | cut -c1-200; }
+selftest before
+block control 800 CUGO_X=0
+grep "deviating" gpurun_out/hunt_control.txt | cut -c1-160
+if grep -q "deviating 0 " gpurun_out/hunt_control.txt; then echo "clean box"; exit 0; fi
+for round in 1 2 3 4 5 6; do
+  block default 400 CUGO_X=0
+  block panel16_0 400 CUGO_PANEL16=0
+  block hsc_mfma_0 400 CUGO_HSC_MFMA=0
+  block kernel_acquire 400 CUGO_KERNEL_ACQUIRE=1
+  block serialize3 400 AMD_SERIALIZE_KERNEL=3
+  block hash 400 CUGO_DEBUG_HASH=/tmp/hunt_hash.txt
+  block xcd_affinity_0 400 CUGO_XCD_AFFINITY=0
+  echo "round $round done"
+done
+for n in default panel16_0 hsc_mfma_0 kernel_acquire serialize3 hash xcd_affinity_0; do
+  echo "$n: $(grep -c 'first chi2 difference' gpurun_out/hunt_$n.txt || true) deviating of $(grep -c ' runs ' gpurun_out/hunt_$n.txt)x400"
+done
+grep -h "first differing" gpurun_out/hunt_hash.txt | cut -c1-300 || true
+selftest after
+# the factorisation alone, back to back with changing inputs (a value left over from the previous call shows)
+timeout -k 10 300 python tools/repro_chain.py 1500 "" CUGO_PANEL16=0 > gpurun_out/hunt_chain.txt 2>&1 || true
+cut -c1-200 gpurun_out/hunt_chain.txt
+timeout -k 10 300 python tools/repro_chain.py 1500 --schur "" CUGO_PANEL16=0 > gpurun_out/hunt_chain_schur.txt 2>&1 || true
+cut -c1-200 gpurun_out/hunt_chain_schur.txt
 if grep -q "Memory access fault" gpurun_out/hunt_*.txt; then exit 1; fi
 echo done

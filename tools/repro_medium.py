@@ -1,14 +1,37 @@
 """GPU box: one medium graph (400 poses / 8 000 landmarks / 33 000 edges, 200 loop closures — the shape on which the
 suite's rare run-to-run differences were seen) optimised N times per configuration from the same estimates by NEW
 optimisers; counts the runs whose chi2 trace or final poses differ from the first run bit for bit.
-    python tools/repro_medium.py N [VAR=val,VAR=val ...]"""
+    python tools/repro_medium.py N [VAR=val,VAR=val ...]
+    python tools/repro_medium.py N --interleave CFG CFG ...   (one run of every configuration in turn, N rounds: the
+                                                              deviation comes in bursts, so blocks of runs cannot be compared)"""
 import importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 cugo = importlib.import_module("cuda-bundle-adjustment_amd")
 import numpy as np
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-configs = [dict(kv.split("=") for kv in a.split(",") if kv) for a in sys.argv[2:]] or [{}]
+interleave = "--interleave" in sys.argv
+args = [a for a in sys.argv[2:] if a != "--interleave"]
+configs = [dict(kv.split("=") for kv in a.split(",") if kv) for a in args] or [{}]
 d = cugo.synth(400, 8000, 33000, seed=11, n_loop_closures=200)
+if interleave:
+    refs, bads = [None] * len(configs), [0] * len(configs)
+    for c in range(N):
+        for q, cfg in enumerate(configs):
+            for k, v in cfg.items():
+                os.environ[k] = v
+            g = cugo.graph_from_arrays(d)
+            g.initialize(); g.optimize(10)
+            cur = (tuple(s["chi2"] for s in g.stats()), g.poses().copy())
+            g.close()
+            for k in cfg:
+                os.environ.pop(k, None)
+            if refs[q] is None:
+                refs[q] = cur
+            elif cur[0] != refs[q][0] or not np.array_equal(cur[1], refs[q][1]):
+                bads[q] += 1
+    for q, cfg in enumerate(configs):
+        print("interleaved", cfg, "rounds", N, "deviating", bads[q], flush=True)
+    sys.exit(0)
 for cfg in configs:
     for k, v in cfg.items():
         os.environ[k] = v

@@ -2066,8 +2066,15 @@ constexpr int BIG = 1024; // workgroup size of the latency-critical single-front
 // like a consumer kernel seeing the PREVIOUS factorisation's value of something its producer just rewrote)
 __device__ __forceinline__ void kernel_acquire(const CholPlanDev& p)
 {
-    if (p.kernel_acquire)
+    if (p.kernel_acquire & 1)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+// CUGO_KERNEL_ACQUIRE=2 (3: both): every wave ends with an agent-scope release fence of its own (buffer_wbl2 sc1 and a
+// wait for all its stores) — the writer's side of the same question
+__device__ __forceinline__ void kernel_release(const CholPlanDev& p)
+{
+    if (p.kernel_acquire & 2)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 }
 
 // ---------------------------------------------------------------- stage 0: subtrees ----
@@ -2131,6 +2138,7 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
             dbg_sleep();
         const int32_t* it = b < neap ? wl_eap + 3 * b : wl_eab + 3 * (b - neap);
         dev_extend_add(p, fronts, it[0], it[1], it[2], 2); // everything below the parents' F11
+        kernel_release(p);
         return;
     }
     stamp(0, 0);
@@ -2183,6 +2191,7 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
         dev_potrf16(ncp, lds, p.winv + fwoff, fail, mirror_now, p.dbg_delay);
         stamp_value(0, 6, ncs);
         stamp(0, 7);
+        kernel_release(p);
         return;
     }
     dev_potrf_panels(ncs, Ls, dinv, fail);
@@ -2198,6 +2207,7 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
     dev_winv(Ls, ncp, Vs, p.winv + fwoff);
     stamp_value(0, 6, ncs);
     stamp(0, 7);
+    kernel_release(p);
 }
 
 // fused trsm + syrk: one workgroup per item (front, ti, tj), see dev_trsyrk_tile
@@ -2228,6 +2238,7 @@ __global__ __launch_bounds__(BIG) void k_up_trsyrk(CholPlanDev p, double* __rest
                            p.l21 + t.l21off, t.nrs + 1, lds, p.junk, 0);
     stamp(4, 7);
     stamp_value(4, 6, 1000000L * (t.a * 10 + t.b + 1) + 1000L * t.ncs + t.nrs);
+    kernel_release(p);
 }
 
 __global__ __launch_bounds__(BIG) void k_up_trsyrk32(CholPlanDev p, double* __restrict__ fronts,
@@ -2238,6 +2249,7 @@ __global__ __launch_bounds__(BIG) void k_up_trsyrk32(CholPlanDev p, double* __re
     const TileItem t = tile_item(p, wl);
     dev_trsyrk_tile32(fronts + t.off, t.ld, t.ncs, t.nrs + 1, t.nrs, t.a, t.b, p.winv + t.woff, p.l21 + t.l21off,
                       t.nrs + 1, lds, p.junk, 0);
+    kernel_release(p);
 }
 
 // ---- look-ahead schedule (CUGO_LOOKAHEAD=1; off by default, see chol_solver.h): two launches per level, the bulk of the update matrix of level
@@ -2340,6 +2352,7 @@ __global__ __launch_bounds__(BIG) void k_up_trsm(CholPlanDev p, double* __restri
     const TileItem t = tile_item(p, wl);
     dev_trsm_w(fronts + t.off, t.ld, t.ncs, (long)t.ncs + t.a, t.b, p.winv + t.woff, lds, p.junk, p.l21 + t.l21off,
                t.nrs + 1);
+    kernel_release(p);
 }
 
 __global__ __launch_bounds__(BIG) void k_up_syrk(CholPlanDev p, double* __restrict__ fronts,
@@ -2349,6 +2362,7 @@ __global__ __launch_bounds__(BIG) void k_up_syrk(CholPlanDev p, double* __restri
     extern __shared__ double lds[];
     const TileItem t = tile_item(p, wl);
     dev_syrk_tiles<KC_SYRK2>(fronts + t.off, t.ld, t.ncs, t.nrs + 1, t.nrs, t.a, t.a + 1, t.b, lds, p.junk);
+    kernel_release(p);
 }
 
 // the ancestor part of a front's backward mat-vec, one launch ahead of the front itself:
@@ -2409,6 +2423,7 @@ __global__ __launch_bounds__(BIG) void k_backward_stage(CholPlanDev p,
     if ((int)blockIdx.x >= ntasks)
     { // ahead-of-time mat-vec of a child of this level's fronts
         dev_backward_ahead(p, p.fat + 16 * ((int)((wl_gemv - p.wl_base) / 3) + ((int)blockIdx.x - ntasks)), lds, xnew);
+        kernel_release(p);
         return;
     }
     stamp(3, 0);
@@ -2420,6 +2435,7 @@ __global__ __launch_bounds__(BIG) void k_backward_stage(CholPlanDev p,
         for (int fi = p.task_ptr[task + 1] - 1; fi >= p.task_ptr[task]; fi--)
             dev_backward(p, fronts, front_view(p, p.task_fronts[fi]), lds, xnew, xout);
     stamp(3, 7);
+    kernel_release(p);
 }
 
 // x[perm[j]] = xnew[j] for all block rows (after the solution ranges of other ranks' subtrees have arrived)

@@ -137,7 +137,7 @@ struct CholPlanDev
     int nc_max;                // widest pivot block (scalars)
     int ea_lds;                // potrf: children's contributions to F11 go straight into its LDS copy
     int panel16;               // potrf: 16-column register panels (CUGO_PANEL16=0: the 6-column LDS panels)
-    int kernel_acquire;        // every kernel of the factorisation starts with an agent-scope acquire fence (CUGO_KERNEL_ACQUIRE)
+    int kernel_acquire;        // CUGO_KERNEL_ACQUIRE: bit 0 = every kernel of the factorisation starts with an agent-scope acquire fence, bit 1 = ends with a release fence
     int dbg_delay;             // diagnosis (CUGO_DEBUG_DELAY): which waves / workgroups of k_up_potrf sleep (chol_kernels.hip: dbg_sleep)
     int zero_lds;              // diagnosis (CUGO_DEBUG_ZERO_LDS): k_up_potrf clears its LDS first
     const int32_t* col0;       // first pivot column (new ordering, block units)

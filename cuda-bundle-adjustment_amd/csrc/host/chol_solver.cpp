@@ -237,6 +237,7 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
     cugo_k::launch_chol_assemble(s, dev, d_fronts.data(), (size_t)plan.front_doubles, d_Hsc, lambda, d_bsc, d_fail,
                                  d_wl_ptr + 3L * plan.clr0, plan.nclr, asm_fronts ? d_wl_ptr + 3L * plan.asm0 : nullptr,
                                  plan.nasm);
+    static const bool hash_levels = !(std::getenv("CUGO_DEBUG_HASH_LEVELS") && std::getenv("CUGO_DEBUG_HASH_LEVELS")[0] == '0');
     static const bool dbg_gap = std::getenv("CUGO_DEBUG_GAP") != nullptr; // diagnosis: an empty kernel after every level
     auto hash = [&](int slot, const double* ptr, size_t n) {
         if (dbg_hash && slot < 64)
@@ -273,8 +274,12 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
                                               d_wl_ptr + 3L * plan.syrk_ptr[st],
                                               plan.syrk_ptr[st + 1] - plan.syrk_ptr[st]);
         }
-        hash(16 + st, d_winv.data(), (size_t)plan.winv_doubles);
-        hash(40 + st, d_fronts.data(), (size_t)plan.front_doubles);
+        if (hash_levels)
+        { // (CUGO_DEBUG_HASH_LEVELS=0: only the checksums before and behind the loops — those between the levels
+          // separate the launches, and the deviation they are to localise stays away)
+            hash(16 + st, d_winv.data(), (size_t)plan.winv_doubles);
+            hash(40 + st, d_fronts.data(), (size_t)plan.front_doubles);
+        }
         if (dbg_gap)
             cugo_k::launch_nop(s);
         // update blocks that cross the ownership boundary: the subtree roots of this level whose parent is

@@ -24,13 +24,14 @@ for round in 1 2 3 4 5 6; do
   block kernel_release 400 CUGO_KERNEL_ACQUIRE=2
   block serialize3 400 AMD_SERIALIZE_KERNEL=3
   block hash 400 CUGO_DEBUG_HASH=/tmp/hunt_hash.txt
+  block hash_ends 400 CUGO_DEBUG_HASH=/tmp/hunt_hash2.txt CUGO_DEBUG_HASH_LEVELS=0
   block xcd_affinity_0 400 CUGO_XCD_AFFINITY=0
   echo "round $round done"
 done
-for n in default panel16_0 hsc_mfma_0 kernel_acquire kernel_release serialize3 hash xcd_affinity_0; do
+for n in default panel16_0 hsc_mfma_0 kernel_acquire kernel_release serialize3 hash hash_ends xcd_affinity_0; do
   echo "$n: $(grep -c 'first chi2 difference' gpurun_out/hunt_$n.txt || true) deviating of $(grep -c ' runs ' gpurun_out/hunt_$n.txt)x400"
 done
-grep -h "first differing" gpurun_out/hunt_hash.txt | cut -c1-300 || true
+grep -h "first differing" gpurun_out/hunt_hash.txt gpurun_out/hunt_hash_ends.txt | cut -c1-300 || true
 selftest after
 # the factorisation alone, back to back with changing inputs (a value left over from the previous call shows)
 timeout -k 10 300 python tools/repro_chain.py 1500 "" CUGO_PANEL16=0 > gpurun_out/hunt_chain.txt 2>&1 || true

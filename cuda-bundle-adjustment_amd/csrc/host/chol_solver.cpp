@@ -163,7 +163,7 @@ void cugo_chol::upload(hipStream_t s)
         const char* ed = std::getenv("CUGO_DEBUG_DELAY");
         D.dbg_delay = ed ? std::atoi(ed) : 0;
         const char* ez = std::getenv("CUGO_DEBUG_ZERO_LDS");
-        D.zero_lds = ez && ez[0] == '1';
+        D.zero_lds = ez ? std::atoi(ez) : 0, D.lds_doubles = 0;
     }
     D.l21off = b64 + o_l21off, D.l21 = d_l21.data();
     D.ldf = b64 + o_ldf, D.alias_of = b32 + o_alias, D.bw_np = b32 + o_bwnp, D.la_np = b32 + o_lanp;

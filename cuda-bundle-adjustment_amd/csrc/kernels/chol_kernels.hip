@@ -2077,6 +2077,20 @@ __device__ __forceinline__ void kernel_release(const CholPlanDev& p)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 }
 
+// CUGO_DEBUG_ZERO_LDS=1 / 2: every kernel of the factorisation first fills its dynamic LDS with zeros / NaNs (the
+// launch functions put the size into their copy of the plan) — nothing may depend on what the kernel that ran on
+// the CU before has left there
+__device__ __forceinline__ void dbg_fill_lds(const CholPlanDev& p, double* lds)
+{
+    if (p.zero_lds)
+    {
+        const double v = p.zero_lds == 2 ? __longlong_as_double(0x7FF8000000000000LL) : 0.0;
+        for (int i = threadIdx.x; i < p.lds_doubles; i += blockDim.x)
+            lds[i] = v;
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------- stage 0: subtrees ----
 __global__ __launch_bounds__(BIG) void k_subtree_factor(CholPlanDev p, double* __restrict__ fronts,
                                                         int task0, int32_t* __restrict__ fail)
@@ -2144,12 +2158,7 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
     stamp(0, 0);
     if (p.dbg_delay == 5)
         dbg_sleep();
-    if (p.zero_lds)
-    { // (diagnosis: CUGO_DEBUG_ZERO_LDS=1 — nothing may depend on what the previous kernel left in LDS)
-        for (int i = threadIdx.x; i < p16::LDS_DOUBLES + 8; i += blockDim.x)
-            lds[i] = 0.0;
-        __syncthreads();
-    }
+    dbg_fill_lds(p, lds);
     // the front's scalars from the task's 64-byte record (one scalar load instead of task -> front -> arrays)
     const int32_t* tm = p.tmeta + cugo_k::TMETA * (task0 + blockIdx.x);
     const long* tm64 = reinterpret_cast<const long*>(tm + 8);
@@ -2232,6 +2241,7 @@ __global__ __launch_bounds__(BIG) void k_up_trsyrk(CholPlanDev p, double* __rest
 {
     kernel_acquire(p);
     extern __shared__ double lds[];
+    dbg_fill_lds(p, lds);
     stamp(4, 0);
     const TileItem t = tile_item(p, wl);
     dev_trsyrk_tile<false>(fronts + t.off, t.ld, t.ncs, t.nrs + 1, t.nrs, t.a, t.b, p.winv + t.woff,
@@ -2246,6 +2256,7 @@ __global__ __launch_bounds__(BIG) void k_up_trsyrk32(CholPlanDev p, double* __re
 {
     kernel_acquire(p);
     extern __shared__ double lds[];
+    dbg_fill_lds(p, lds);
     const TileItem t = tile_item(p, wl);
     dev_trsyrk_tile32(fronts + t.off, t.ld, t.ncs, t.nrs + 1, t.nrs, t.a, t.b, p.winv + t.woff, p.l21 + t.l21off,
                       t.nrs + 1, lds, p.junk, 0);
@@ -2349,6 +2360,7 @@ __global__ __launch_bounds__(BIG) void k_up_trsm(CholPlanDev p, double* __restri
 {
     kernel_acquire(p);
     extern __shared__ double lds[];
+    dbg_fill_lds(p, lds);
     const TileItem t = tile_item(p, wl);
     dev_trsm_w(fronts + t.off, t.ld, t.ncs, (long)t.ncs + t.a, t.b, p.winv + t.woff, lds, p.junk, p.l21 + t.l21off,
                t.nrs + 1);
@@ -2360,6 +2372,7 @@ __global__ __launch_bounds__(BIG) void k_up_syrk(CholPlanDev p, double* __restri
 {
     kernel_acquire(p);
     extern __shared__ double lds[];
+    dbg_fill_lds(p, lds);
     const TileItem t = tile_item(p, wl);
     dev_syrk_tiles<KC_SYRK2>(fronts + t.off, t.ld, t.ncs, t.nrs + 1, t.nrs, t.a, t.a + 1, t.b, lds, p.junk);
     kernel_release(p);
@@ -2420,6 +2433,7 @@ __global__ __launch_bounds__(BIG) void k_backward_stage(CholPlanDev p,
 {
     kernel_acquire(p);
     extern __shared__ double lds[];
+    dbg_fill_lds(p, lds);
     if ((int)blockIdx.x >= ntasks)
     { // ahead-of-time mat-vec of a child of this level's fronts
         dev_backward_ahead(p, p.fat + 16 * ((int)((wl_gemv - p.wl_base) / 3) + ((int)blockIdx.x - ntasks)), lds, xnew);
@@ -2454,6 +2468,12 @@ __global__ void k_flag_to_double(int32_t* __restrict__ flag)
     *reinterpret_cast<double*>(flag) = v ? 1.0 : 0.0;
 }
 
+static inline CholPlanDev with_lds(const CholPlanDev& p, size_t lds_bytes)
+{ // (the plan is a kernel argument passed by value: the copy carries this launch's LDS size for dbg_fill_lds)
+    CholPlanDev q = p;
+    q.lds_doubles = (int)(lds_bytes / sizeof(double));
+    return q;
+}
 void ensure_lds(const void* fn, size_t bytes)
 {
     if (bytes > 48 * 1024)
@@ -2533,12 +2553,12 @@ void launch_chol_two_phase(hipStream_t s, const CholPlanDev& p, double* d_fronts
     if (ntrsm > 0)
     {
         ensure_lds(reinterpret_cast<const void*>(k_up_trsm), lds_t);
-        CUGO_LAUNCH(k_up_trsm, dim3(ntrsm), dim3(BIG), lds_t, s, p, d_fronts, d_trsm);
+        CUGO_LAUNCH(k_up_trsm, dim3(ntrsm), dim3(BIG), lds_t, s, with_lds(p, lds_t), d_fronts, d_trsm);
     }
     if (nsyrk > 0)
     {
         ensure_lds(reinterpret_cast<const void*>(k_up_syrk), lds_s);
-        CUGO_LAUNCH(k_up_syrk, dim3(nsyrk), dim3(BIG), lds_s, s, p, d_fronts, d_syrk);
+        CUGO_LAUNCH(k_up_syrk, dim3(nsyrk), dim3(BIG), lds_s, s, with_lds(p, lds_s), d_fronts, d_syrk);
     }
 }
 
@@ -2550,7 +2570,7 @@ void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fron
     if (ntasks <= 0)
         return;
     ensure_lds(reinterpret_cast<const void*>(k_up_potrf), chol_lds_potrf_bytes());
-    CUGO_LAUNCH(k_up_potrf, dim3(ntasks + neap + nea), dim3(BIG), chol_lds_potrf_bytes(), s, p, d_fronts,
+    CUGO_LAUNCH(k_up_potrf, dim3(ntasks + neap + nea), dim3(BIG), chol_lds_potrf_bytes(), s, with_lds(p, chol_lds_potrf_bytes()), d_fronts,
                 task0, ntasks, d_wl + 3L * eap0, neap, d_wl + 3L * ea0, d_fail);
     if (tile == 0)
         return; // two-phase level: the caller queues launch_chol_two_phase
@@ -2558,13 +2578,13 @@ void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fron
     {
         const size_t lds32 = (2 * KC_SYRK * TPST32 + 21 * 256) * sizeof(double);
         ensure_lds(reinterpret_cast<const void*>(k_up_trsyrk32), lds32);
-        CUGO_LAUNCH(k_up_trsyrk32, dim3(nsy), dim3(BIG), lds32, s, p, d_fronts, d_wl + 3L * sy0);
+        CUGO_LAUNCH(k_up_trsyrk32, dim3(nsy), dim3(BIG), lds32, s, with_lds(p, lds32), d_fronts, d_wl + 3L * sy0);
     }
     else if (nsy > 0)
     {
         ensure_lds(reinterpret_cast<const void*>(k_up_trsyrk), trsyrk_lds() * sizeof(double));
-        CUGO_LAUNCH(k_up_trsyrk, dim3(nsy), dim3(BIG), trsyrk_lds() * sizeof(double), s, p, d_fronts,
-                           d_wl + 3L * sy0);
+        CUGO_LAUNCH(k_up_trsyrk, dim3(nsy), dim3(BIG), trsyrk_lds() * sizeof(double), s,
+                    with_lds(p, trsyrk_lds() * sizeof(double)), d_fronts, d_wl + 3L * sy0);
     }
 }
 
@@ -2623,7 +2643,7 @@ void launch_chol_backward_stage(hipStream_t s, const CholPlanDev& p, double* d_f
     if (ntasks <= 0)
         return;
     ensure_lds(reinterpret_cast<const void*>(k_backward_stage), lds_bytes);
-    CUGO_LAUNCH(k_backward_stage, dim3(ntasks + ngemv), dim3(BIG), lds_bytes, s, p, d_fronts, task0,
+    CUGO_LAUNCH(k_backward_stage, dim3(ntasks + ngemv), dim3(BIG), lds_bytes, s, with_lds(p, lds_bytes), d_fronts, task0,
                        ntasks, d_wl_gemv, d_xnew, d_x);
 }
 

@@ -139,7 +139,8 @@ struct CholPlanDev
     int panel16;               // potrf: 16-column register panels (CUGO_PANEL16=0: the 6-column LDS panels)
     int kernel_acquire;        // CUGO_KERNEL_ACQUIRE: bit 0 = every kernel of the factorisation starts with an agent-scope acquire fence, bit 1 = ends with a release fence
     int dbg_delay;             // diagnosis (CUGO_DEBUG_DELAY): which waves / workgroups of k_up_potrf sleep (chol_kernels.hip: dbg_sleep)
-    int zero_lds;              // diagnosis (CUGO_DEBUG_ZERO_LDS): k_up_potrf clears its LDS first
+    int zero_lds;              // diagnosis (CUGO_DEBUG_ZERO_LDS=1 / 2): every kernel fills its LDS with zeros / NaNs first
+    int lds_doubles;           // (set per launch: the dynamic LDS of this launch, for that fill)
     const int32_t* col0;       // first pivot column (new ordering, block units)
     const int32_t* rows_ptr;   // [n_fronts+1] into rows: boundary block rows (new ordering)
     const int32_t* rows;

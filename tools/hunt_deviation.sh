@@ -11,8 +11,12 @@ block() { # name, runs, env...
   env "$@" timeout -k 10 300 python tools/repro_medium.py $n "" >> gpurun_out/hunt_$name.txt 2>&1 || true
 }
 hipcc --offload-arch=gfx950 -O2 tools/mfma_selftest.hip -o /tmp/mfma_selftest 2> /dev/null
-selftest() { timeout -k 10 200 /tmp/mfma_selftest 240 20000 > gpurun_out/hunt_selftest_$1.txt 2>&1 || true; tail -12 gpurun_out/hunt_selftest_$1.txt | cut -c1-200; }
-selftest before
+hipcc --offload-arch=gfx950 -O2 tools/coherence_selftest.hip -o /tmp/coherence_selftest 2> /dev/null
+selftest() {
+  timeout -k 10 200 /tmp/mfma_selftest 240 20000 > gpurun_out/hunt_selftest_$1.txt 2>&1 || true; tail -12 gpurun_out/hunt_selftest_$1.txt | cut -c1-200
+  timeout -k 10 200 /tmp/coherence_selftest $2 > gpurun_out/hunt_coherence_$1.txt 2>&1 || true; tail -30 gpurun_out/hunt_coherence_$1.txt | cut -c1-200
+}
+selftest before 10000
 block control 800 CUGO_X=0
 grep "deviating" gpurun_out/hunt_control.txt | cut -c1-160
 if grep -q "deviating 0 " gpurun_out/hunt_control.txt; then echo "clean box"; exit 0; fi
@@ -32,7 +36,7 @@ for n in default panel16_0 hsc_mfma_0 kernel_acquire kernel_release serialize3 h
   echo "$n: $(grep -c 'first chi2 difference' gpurun_out/hunt_$n.txt || true) deviating of $(grep -c ' runs ' gpurun_out/hunt_$n.txt)x400"
 done
 grep -h "first differing" gpurun_out/hunt_hash.txt gpurun_out/hunt_hash_ends.txt | cut -c1-300 || true
-selftest after
+selftest after 60000
 # the factorisation alone, back to back with changing inputs (a value left over from the previous call shows)
 timeout -k 10 300 python tools/repro_chain.py 1500 "" CUGO_PANEL16=0 > gpurun_out/hunt_chain.txt 2>&1 || true
 cut -c1-200 gpurun_out/hunt_chain.txt

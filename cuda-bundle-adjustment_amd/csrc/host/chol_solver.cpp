@@ -164,6 +164,7 @@ void cugo_chol::upload(hipStream_t s)
         D.dbg_delay = ed ? std::atoi(ed) : 0;
         const char* ez = std::getenv("CUGO_DEBUG_ZERO_LDS");
         D.zero_lds = ez ? std::atoi(ez) : 0, D.lds_doubles = 0;
+        D.dbg_skip_wg = -1;
     }
     D.l21off = b64 + o_l21off, D.l21 = d_l21.data();
     D.ldf = b64 + o_ldf, D.alias_of = b32 + o_alias, D.bw_np = b32 + o_bwnp, D.la_np = b32 + o_lanp;
@@ -226,6 +227,27 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
                              int32_t* d_fail)
 {
     hipStream_t s = ctx->stream;
+    // fault injection (diagnosis): CUGO_DEBUG_SKIP=call:launch:workgroup — in this solver's call number `call` the
+    // given workgroup of the given launch returns at once; CUGO_DEBUG_SKIP_DUMP=file: call 0 writes its launch table
+    struct SkipScope
+    {
+        bool on = false;
+        ~SkipScope()
+        {
+            if (on)
+                cugo_k::chol_dbg_skip_end();
+        }
+    } skip_scope;
+    {
+        const char* sk = std::getenv("CUGO_DEBUG_SKIP");
+        const char* dump = dbg_calls == 0 ? std::getenv("CUGO_DEBUG_SKIP_DUMP") : nullptr;
+        int c = -1, l = -1, w = -1;
+        if (sk && std::sscanf(sk, "%d:%d:%d", &c, &l, &w) == 3 && c == dbg_calls)
+            cugo_k::chol_dbg_skip_begin(l, w, dump), skip_scope.on = true;
+        else if (dump)
+            cugo_k::chol_dbg_skip_begin(-1, -1, dump), skip_scope.on = true;
+        dbg_calls++;
+    }
     static const bool dbg = std::getenv("CUGO_DEBUG_STAMPS") != nullptr;
     static long long* d_stamps = nullptr;
     if (dbg && !d_stamps)

@@ -42,6 +42,7 @@ struct cugo_chol
     // 11 fronts after the assembly, 12 / 13 / 14 W, L21, fronts after the forward pass, 15 x after the backward pass,
     // 16 + st: W after the potrf launch of stage st, 40 + st: the fronts after the tile launches of stage st
     unsigned long long* dbg_hash = nullptr;
+    int dbg_calls = 0; // factor_solve calls so far (CUGO_DEBUG_SKIP counts them)
     bool own_subtrees() const { return world > 1 && bcast && !plan.owner.empty(); }
 
     void analyze(int n, const int32_t* rowptr, const int32_t* colind);

@@ -31,6 +31,7 @@
 // substitution needs its own top-down pass.  All sums have a fixed order: bit-reproducible.
 // A pivot <= 1e-14 (or NaN) raises *fail (ref: csrcholZeroPivot tol, src/cholesky.hpp:85).
 #include <algorithm>
+#include <cstdio>
 
 #include "kernels.h"
 
@@ -2143,6 +2144,8 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
                                                   const int32_t* __restrict__ wl_eab,
                                                   int32_t* __restrict__ fail)
 {
+    if (p.dbg_skip_wg == (int)blockIdx.x)
+        return; // (fault injection, see DbgSkip)
     kernel_acquire(p);
     extern __shared__ double lds[];
     if ((int)blockIdx.x >= npotrf)
@@ -2239,6 +2242,8 @@ __device__ __forceinline__ TileItem tile_item(const CholPlanDev& p, const int32_
 __global__ __launch_bounds__(BIG) void k_up_trsyrk(CholPlanDev p, double* __restrict__ fronts,
                                                    const int32_t* __restrict__ wl)
 {
+    if (p.dbg_skip_wg == (int)blockIdx.x)
+        return; // (fault injection, see DbgSkip)
     kernel_acquire(p);
     extern __shared__ double lds[];
     dbg_fill_lds(p, lds);
@@ -2254,6 +2259,8 @@ __global__ __launch_bounds__(BIG) void k_up_trsyrk(CholPlanDev p, double* __rest
 __global__ __launch_bounds__(BIG) void k_up_trsyrk32(CholPlanDev p, double* __restrict__ fronts,
                                                      const int32_t* __restrict__ wl)
 {
+    if (p.dbg_skip_wg == (int)blockIdx.x)
+        return; // (fault injection, see DbgSkip)
     kernel_acquire(p);
     extern __shared__ double lds[];
     dbg_fill_lds(p, lds);
@@ -2358,6 +2365,8 @@ constexpr int KC_SYRK2 = 48;
 __global__ __launch_bounds__(BIG) void k_up_trsm(CholPlanDev p, double* __restrict__ fronts,
                                                  const int32_t* __restrict__ wl)
 {
+    if (p.dbg_skip_wg == (int)blockIdx.x)
+        return; // (fault injection, see DbgSkip)
     kernel_acquire(p);
     extern __shared__ double lds[];
     dbg_fill_lds(p, lds);
@@ -2370,6 +2379,8 @@ __global__ __launch_bounds__(BIG) void k_up_trsm(CholPlanDev p, double* __restri
 __global__ __launch_bounds__(BIG) void k_up_syrk(CholPlanDev p, double* __restrict__ fronts,
                                                  const int32_t* __restrict__ wl)
 {
+    if (p.dbg_skip_wg == (int)blockIdx.x)
+        return; // (fault injection, see DbgSkip)
     kernel_acquire(p);
     extern __shared__ double lds[];
     dbg_fill_lds(p, lds);
@@ -2431,6 +2442,8 @@ __global__ __launch_bounds__(BIG) void k_backward_stage(CholPlanDev p,
                                                         double* __restrict__ xnew,
                                                         double* __restrict__ xout)
 {
+    if (p.dbg_skip_wg == (int)blockIdx.x)
+        return; // (fault injection, see DbgSkip)
     kernel_acquire(p);
     extern __shared__ double lds[];
     dbg_fill_lds(p, lds);
@@ -2468,10 +2481,43 @@ __global__ void k_flag_to_double(int32_t* __restrict__ flag)
     *reinterpret_cast<double*>(flag) = v ? 1.0 : 0.0;
 }
 
-static inline CholPlanDev with_lds(const CholPlanDev& p, size_t lds_bytes)
+// Fault injection (diagnosis; CUGO_DEBUG_SKIP=call:launch:workgroup, read by the solver): ONE
+// workgroup of ONE launch of one factorisation returns at once, so everything it would have written keeps the value
+// the previous factorisation left there — the supposed failure, made on purpose, to compare its results with the
+// alternates the rare deviation produces.  The launches of a factorisation are counted in queueing order.
+struct DbgSkip
+{
+    int launch = 0, target_launch = -1, target_wg = -1;
+    std::FILE* dump = nullptr;
+};
+static DbgSkip g_skip;
+void chol_dbg_skip_begin(int target_launch, int target_wg, const char* dump_path)
+{
+    if (g_skip.dump)
+        std::fclose(g_skip.dump), g_skip.dump = nullptr;
+    g_skip.launch = 0, g_skip.target_launch = target_launch, g_skip.target_wg = target_wg;
+    if (dump_path)
+        g_skip.dump = std::fopen(dump_path, "w");
+}
+void chol_dbg_skip_end()
+{
+    if (g_skip.dump)
+        std::fclose(g_skip.dump), g_skip.dump = nullptr;
+    g_skip.target_launch = -1;
+}
+static inline CholPlanDev with_lds(const CholPlanDev& p, size_t lds_bytes, const char* name, int grid, int first = 0)
 { // (the plan is a kernel argument passed by value: the copy carries this launch's LDS size for dbg_fill_lds)
     CholPlanDev q = p;
     q.lds_doubles = (int)(lds_bytes / sizeof(double));
+    q.dbg_skip_wg = -1;
+    if (g_skip.dump || g_skip.target_launch >= 0)
+    {
+        if (g_skip.dump)
+            std::fprintf(g_skip.dump, "%d %s %d %d\n", g_skip.launch, name, grid, first);
+        if (g_skip.launch == g_skip.target_launch)
+            q.dbg_skip_wg = g_skip.target_wg;
+        g_skip.launch++;
+    }
     return q;
 }
 void ensure_lds(const void* fn, size_t bytes)
@@ -2553,12 +2599,12 @@ void launch_chol_two_phase(hipStream_t s, const CholPlanDev& p, double* d_fronts
     if (ntrsm > 0)
     {
         ensure_lds(reinterpret_cast<const void*>(k_up_trsm), lds_t);
-        CUGO_LAUNCH(k_up_trsm, dim3(ntrsm), dim3(BIG), lds_t, s, with_lds(p, lds_t), d_fronts, d_trsm);
+        CUGO_LAUNCH(k_up_trsm, dim3(ntrsm), dim3(BIG), lds_t, s, with_lds(p, lds_t, "k_up_trsm", ntrsm), d_fronts, d_trsm);
     }
     if (nsyrk > 0)
     {
         ensure_lds(reinterpret_cast<const void*>(k_up_syrk), lds_s);
-        CUGO_LAUNCH(k_up_syrk, dim3(nsyrk), dim3(BIG), lds_s, s, with_lds(p, lds_s), d_fronts, d_syrk);
+        CUGO_LAUNCH(k_up_syrk, dim3(nsyrk), dim3(BIG), lds_s, s, with_lds(p, lds_s, "k_up_syrk", nsyrk), d_fronts, d_syrk);
     }
 }
 
@@ -2570,7 +2616,7 @@ void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fron
     if (ntasks <= 0)
         return;
     ensure_lds(reinterpret_cast<const void*>(k_up_potrf), chol_lds_potrf_bytes());
-    CUGO_LAUNCH(k_up_potrf, dim3(ntasks + neap + nea), dim3(BIG), chol_lds_potrf_bytes(), s, with_lds(p, chol_lds_potrf_bytes()), d_fronts,
+    CUGO_LAUNCH(k_up_potrf, dim3(ntasks + neap + nea), dim3(BIG), chol_lds_potrf_bytes(), s, with_lds(p, chol_lds_potrf_bytes(), "k_up_potrf", ntasks + neap + nea, ntasks), d_fronts,
                 task0, ntasks, d_wl + 3L * eap0, neap, d_wl + 3L * ea0, d_fail);
     if (tile == 0)
         return; // two-phase level: the caller queues launch_chol_two_phase
@@ -2578,13 +2624,13 @@ void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fron
     {
         const size_t lds32 = (2 * KC_SYRK * TPST32 + 21 * 256) * sizeof(double);
         ensure_lds(reinterpret_cast<const void*>(k_up_trsyrk32), lds32);
-        CUGO_LAUNCH(k_up_trsyrk32, dim3(nsy), dim3(BIG), lds32, s, with_lds(p, lds32), d_fronts, d_wl + 3L * sy0);
+        CUGO_LAUNCH(k_up_trsyrk32, dim3(nsy), dim3(BIG), lds32, s, with_lds(p, lds32, "k_up_trsyrk32", nsy), d_fronts, d_wl + 3L * sy0);
     }
     else if (nsy > 0)
     {
         ensure_lds(reinterpret_cast<const void*>(k_up_trsyrk), trsyrk_lds() * sizeof(double));
         CUGO_LAUNCH(k_up_trsyrk, dim3(nsy), dim3(BIG), trsyrk_lds() * sizeof(double), s,
-                    with_lds(p, trsyrk_lds() * sizeof(double)), d_fronts, d_wl + 3L * sy0);
+                    with_lds(p, trsyrk_lds() * sizeof(double), "k_up_trsyrk", nsy), d_fronts, d_wl + 3L * sy0);
     }
 }
 
@@ -2643,7 +2689,7 @@ void launch_chol_backward_stage(hipStream_t s, const CholPlanDev& p, double* d_f
     if (ntasks <= 0)
         return;
     ensure_lds(reinterpret_cast<const void*>(k_backward_stage), lds_bytes);
-    CUGO_LAUNCH(k_backward_stage, dim3(ntasks + ngemv), dim3(BIG), lds_bytes, s, with_lds(p, lds_bytes), d_fronts, task0,
+    CUGO_LAUNCH(k_backward_stage, dim3(ntasks + ngemv), dim3(BIG), lds_bytes, s, with_lds(p, lds_bytes, "k_backward_stage", ntasks + ngemv, ntasks), d_fronts, task0,
                        ntasks, d_wl_gemv, d_xnew, d_x);
 }
 

@@ -141,6 +141,7 @@ struct CholPlanDev
     int dbg_delay;             // diagnosis (CUGO_DEBUG_DELAY): which waves / workgroups of k_up_potrf sleep (chol_kernels.hip: dbg_sleep)
     int zero_lds;              // diagnosis (CUGO_DEBUG_ZERO_LDS=1 / 2): every kernel fills its LDS with zeros / NaNs first
     int lds_doubles;           // (set per launch: the dynamic LDS of this launch, for that fill)
+    int dbg_skip_wg;           // (set per launch, -1: none) fault injection: this workgroup returns at once (CUGO_DEBUG_SKIP)
     const int32_t* col0;       // first pivot column (new ordering, block units)
     const int32_t* rows_ptr;   // [n_fronts+1] into rows: boundary block rows (new ordering)
     const int32_t* rows;
@@ -213,7 +214,11 @@ void launch_chol_backward_stage(hipStream_t s, const CholPlanDev& p, double* d_f
                                 const int32_t* d_wl_gemv, int ngemv);
 // LDS bytes of the factor kernels (L11 + one 64-row tile) and of the backward kernel
 // diagnosis (CUGO_DEBUG_HASH): *out += the sum of the n 64-bit words at p (integer sum: order-independent)
-void launch_nop(hipStream_t s); // diagnosis (CUGO_DEBUG_GAP): an empty kernel
+void launch_nop(hipStream_t s);
+// fault injection (CUGO_DEBUG_SKIP): the launches of the factorisation that follows are counted from 0; workgroup
+// target_wg of launch target_launch returns at once; dump_path: the launch table (index, kernel, grid, first items) goes there
+void chol_dbg_skip_begin(int target_launch, int target_wg, const char* dump_path);
+void chol_dbg_skip_end(); // diagnosis (CUGO_DEBUG_GAP): an empty kernel
 void launch_hash_words(hipStream_t s, const void* p, size_t n_words, unsigned long long* out);
 void launch_flag_to_double(hipStream_t s, int32_t* d_flag); // int32 0 / 1 -> double 0.0 / 1.0 in the same 8-byte slot
 void launch_chol_unpermute(hipStream_t s, const CholPlanDev& p, const double* d_xnew, double* d_x);

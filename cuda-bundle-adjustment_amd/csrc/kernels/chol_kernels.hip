@@ -2491,20 +2491,6 @@ struct DbgSkip
     std::FILE* dump = nullptr;
 };
 static DbgSkip g_skip;
-void chol_dbg_skip_begin(int target_launch, int target_wg, const char* dump_path)
-{
-    if (g_skip.dump)
-        std::fclose(g_skip.dump), g_skip.dump = nullptr;
-    g_skip.launch = 0, g_skip.target_launch = target_launch, g_skip.target_wg = target_wg;
-    if (dump_path)
-        g_skip.dump = std::fopen(dump_path, "w");
-}
-void chol_dbg_skip_end()
-{
-    if (g_skip.dump)
-        std::fclose(g_skip.dump), g_skip.dump = nullptr;
-    g_skip.target_launch = -1;
-}
 static inline CholPlanDev with_lds(const CholPlanDev& p, size_t lds_bytes, const char* name, int grid, int first = 0)
 { // (the plan is a kernel argument passed by value: the copy carries this launch's LDS size for dbg_fill_lds)
     CholPlanDev q = p;
@@ -2530,6 +2516,20 @@ void ensure_lds(const void* fn, size_t bytes)
 
 namespace cugo_k
 {
+void chol_dbg_skip_begin(int target_launch, int target_wg, const char* dump_path)
+{
+    if (g_skip.dump)
+        std::fclose(g_skip.dump), g_skip.dump = nullptr;
+    g_skip.launch = 0, g_skip.target_launch = target_launch, g_skip.target_wg = target_wg;
+    if (dump_path)
+        g_skip.dump = std::fopen(dump_path, "w");
+}
+void chol_dbg_skip_end()
+{
+    if (g_skip.dump)
+        std::fclose(g_skip.dump), g_skip.dump = nullptr;
+    g_skip.target_launch = -1;
+}
 
 size_t chol_lds_factor_bytes(int nc_max)
 { // subtree / potrf kernels: L11 + dinv + inverted diagonal blocks + one trsm B tile, or the syrk panels

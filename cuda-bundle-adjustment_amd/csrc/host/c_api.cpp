@@ -208,6 +208,14 @@ int cugo_chol_factor_solve(cugo_chol* s, const double* d_Hsc, double lambda, con
         s->factor_solve(d_Hsc, lambda, d_bsc, d_x, d_fail);
     });
 }
+int cugo_debug_dump(const char* dir, int* n_calls)
+{
+    return guarded([&] {
+        const int n = cugo_debug_dump_last_solver(dir);
+        if (n_calls)
+            *n_calls = n;
+    });
+}
 int cugo_chol_stats(const cugo_chol* s, double* nnzL, double* flops, int* n_super, int* n_stages,
                     double* front_bytes)
 {

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 
 using namespace cugo_host;
 
@@ -223,6 +224,36 @@ void cugo_chol::analyze_host(int n, const int32_t* rowptr, const int32_t* colind
     analyzed = true;
 }
 
+static cugo_chol* g_last_kept = nullptr; // (diagnosis only: the solver that ran last with CUGO_DEBUG_KEEP; valid while its graph is open)
+void cugo_chol::dump_kept(const char* dir)
+{
+    CUGO_HIP(hipStreamSynchronize(ctx->stream));
+    const size_t nf = (size_t)plan.front_doubles, nw = (size_t)plan.winv_doubles, nl = (size_t)plan.l21_doubles,
+                 nx = (size_t)6 * plan.n;
+    for (size_t c = 0; c < keep.size(); c++)
+    {
+        std::vector<double> h(nf + nw + nl + 2 * nx);
+        if (keep[c]->size() < h.size())
+            continue;
+        CUGO_HIP(hipMemcpy(h.data(), keep[c]->data(), h.size() * sizeof(double), hipMemcpyDeviceToHost));
+        const std::string path = std::string(dir) + "/call" + std::to_string(c) + ".bin";
+        std::FILE* f = std::fopen(path.c_str(), "wb");
+        if (!f)
+            throw std::runtime_error("cugo_debug_dump: cannot write " + path);
+        const int64_t hdr[8] = {(int64_t)nf, (int64_t)nw, (int64_t)nl, (int64_t)nx, (int64_t)nx, 0, 0, 0};
+        std::fwrite(hdr, sizeof hdr, 1, f);
+        std::fwrite(h.data(), sizeof(double), h.size(), f);
+        std::fclose(f);
+    }
+}
+int cugo_debug_dump_last_solver(const char* dir)
+{
+    if (!g_last_kept)
+        return 0;
+    g_last_kept->dump_kept(dir);
+    return (int)g_last_kept->keep.size();
+}
+
 void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d_bsc, double* d_x,
                              int32_t* d_fail)
 {
@@ -354,6 +385,26 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
         cugo_k::launch_chol_unpermute(s, dev, d_xnew.data(), d_x);
     }
     CUGO_HIP(hipGetLastError());
+    static const bool keep_on = std::getenv("CUGO_DEBUG_KEEP") != nullptr;
+    if (keep_on && dbg_calls <= 16)
+    { // (dbg_calls counts this call already)
+        const size_t nf = (size_t)plan.front_doubles, nw = (size_t)plan.winv_doubles, nl = (size_t)plan.l21_doubles,
+                     nx = (size_t)6 * plan.n;
+        while (keep.size() < (size_t)dbg_calls)
+            keep.emplace_back(new cugo_host::DevBuf<double>());
+        auto& k = *keep[dbg_calls - 1];
+        k.resize(nf + nw + nl + 2 * nx + 8);
+        double* dst = k.data();
+        const std::pair<const double*, size_t> parts[] = {{d_fronts.data(), nf}, {d_winv.data(), nw}, {d_l21.data(), nl},
+                                                          {d_xnew.data(), nx}, {d_x, nx}};
+        for (const auto& pr : parts)
+        {
+            if (pr.second)
+                CUGO_HIP(hipMemcpyAsync(dst, pr.first, pr.second * sizeof(double), hipMemcpyDeviceToDevice, s));
+            dst += pr.second;
+        }
+        g_last_kept = this;
+    }
     if (dbg)
     {
         long long h[64];

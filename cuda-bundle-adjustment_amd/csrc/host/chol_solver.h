@@ -5,6 +5,7 @@
 
 #include <array>
 #include <functional>
+#include <memory>
 
 // definition of the opaque cugo_chol of include/cugo_hip.h
 struct cugo_chol
@@ -43,6 +44,11 @@ struct cugo_chol
     // 16 + st: W after the potrf launch of stage st, 40 + st: the fronts after the tile launches of stage st
     unsigned long long* dbg_hash = nullptr;
     int dbg_calls = 0; // factor_solve calls so far (CUGO_DEBUG_SKIP counts them)
+    // diagnosis (CUGO_DEBUG_KEEP=1): after every one of the first 16 factor_solve calls the fronts, W, L21, x (permuted)
+    // and x are copied (same stream) into a slot of their own; cugo_debug_dump() writes the slots of the solver that
+    // ran last to files — the autopsy of a run that deviated from its twin (tools/autopsy.py)
+    std::vector<std::unique_ptr<cugo_host::DevBuf<double>>> keep;
+    void dump_kept(const char* dir);
     bool own_subtrees() const { return world > 1 && bcast && !plan.owner.empty(); }
 
     void analyze(int n, const int32_t* rowptr, const int32_t* colind);
@@ -52,3 +58,6 @@ struct cugo_chol
     void factor_solve(const double* d_Hsc, double lambda, const double* d_bsc, double* d_x,
                       int32_t* d_fail);
 };
+
+// diagnosis: writes the CUGO_DEBUG_KEEP slots of the solver that ran last to dir/call<k>.bin; returns their number
+int cugo_debug_dump_last_solver(const char* dir);

@@ -204,6 +204,10 @@ int cugo_chol_analyze(cugo_chol* s, int n_block_rows, const int32_t* h_rowptr,
  * d_fail[0] (int32 device, 0 = ok) — ref: solve()->bool, zero pivot tol 1e-14. */
 int cugo_chol_factor_solve(cugo_chol* s, const double* d_Hsc, double lambda, const double* d_bsc,
                            double* d_x, int32_t* d_fail);
+/* diagnosis only (no counterpart in the reference): with CUGO_DEBUG_KEEP=1 a solver keeps device copies of the fronts,
+ * W, L21 and the solution after each of its first 16 factor_solve calls; this writes those of the solver that ran last
+ * (its graph still open) to dir/call<k>.bin: int64[8] header {fronts, W, L21, x permuted, x: doubles}, then the arrays. */
+int cugo_debug_dump(const char* dir, int* n_calls);
 /* statistics of the analysis: nnz(L) in scalars, factorisation flops, #supernodes, #stages */
 int cugo_chol_stats(const cugo_chol* s, double* nnzL, double* flops, int* n_supernodes,
                     int* n_stages, double* front_bytes);

@@ -20,6 +20,9 @@ selftest before 10000
 block control 800 CUGO_X=0
 grep "deviating" gpurun_out/hunt_control.txt | cut -c1-160
 if grep -q "deviating 0 " gpurun_out/hunt_control.txt; then echo "clean box"; exit 0; fi
+# where a deviating run differs from its twin (fronts, W, L21, x after every factorisation)
+timeout -k 10 400 python tools/autopsy.py 6000 > gpurun_out/hunt_autopsy.txt 2>&1 || true
+cut -c1-220 gpurun_out/hunt_autopsy.txt | head -150
 for round in 1 2 3 4 5 6; do
   block default 400 CUGO_X=0
   block panel16_0 400 CUGO_PANEL16=0

@@ -160,7 +160,7 @@ void cugo_chol::upload(hipStream_t s)
         const char* e16 = std::getenv("CUGO_PANEL16");
         D.panel16 = !(e16 && e16[0] == '0');
         const char* ka = std::getenv("CUGO_KERNEL_ACQUIRE");
-        D.kernel_acquire = ka ? std::atoi(ka) & 3 : 0; // 1: acquire at the start, 2: release at the end, 3: both
+        D.kernel_acquire = ka ? std::atoi(ka) & 7 : 0; // 1: acquire at the start, 2: release at the end, 3: both, 4: waves wait for their stores
         const char* ed = std::getenv("CUGO_DEBUG_DELAY");
         D.dbg_delay = ed ? std::atoi(ed) : 0;
         const char* ez = std::getenv("CUGO_DEBUG_ZERO_LDS");

@@ -2076,6 +2076,8 @@ __device__ __forceinline__ void kernel_release(const CholPlanDev& p)
 {
     if (p.kernel_acquire & 2)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    else if (p.kernel_acquire & 4) // 4: every wave only waits until its own stores are acknowledged before it ends
+        __builtin_amdgcn_s_waitcnt(0); // (vmcnt counts stores too on gfx9; a workgroup-scope fence emits nothing here)
 }
 
 // CUGO_DEBUG_ZERO_LDS=1 / 2: every kernel of the factorisation first fills its dynamic LDS with zeros / NaNs (the

@@ -29,6 +29,7 @@ for round in 1 2 3 4 5 6; do
   block hsc_mfma_0 400 CUGO_HSC_MFMA=0
   block kernel_acquire 400 CUGO_KERNEL_ACQUIRE=1
   block kernel_release 400 CUGO_KERNEL_ACQUIRE=2
+  block wave_waits 400 CUGO_KERNEL_ACQUIRE=4
   block serialize3 400 AMD_SERIALIZE_KERNEL=3
   block hash 400 CUGO_DEBUG_HASH=/tmp/hunt_hash.txt
   block hash_ends 400 CUGO_DEBUG_HASH=/tmp/hunt_hash2.txt CUGO_DEBUG_HASH_LEVELS=0
@@ -36,7 +37,7 @@ for round in 1 2 3 4 5 6; do
   block round2_paths 400 CUGO_PANEL16=0 CUGO_HSC_MFMA=0 CUGO_ASM_FRONTS=0 CUGO_TRIAL_POLL=0 CUGO_SPECULATE=0 CUGO_EA_LDS=0
   echo "round $round done"
 done
-for n in default panel16_0 hsc_mfma_0 kernel_acquire kernel_release serialize3 hash hash_ends xcd_affinity_0 round2_paths; do
+for n in default panel16_0 hsc_mfma_0 kernel_acquire kernel_release wave_waits serialize3 hash hash_ends xcd_affinity_0 round2_paths; do
   echo "$n: $(grep -c 'first chi2 difference' gpurun_out/hunt_$n.txt || true) deviating of $(grep -c ' runs ' gpurun_out/hunt_$n.txt)x400"
 done
 grep -h "first differing" gpurun_out/hunt_hash.txt gpurun_out/hunt_hash_ends.txt | cut -c1-300 || true

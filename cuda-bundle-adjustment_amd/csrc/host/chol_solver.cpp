@@ -279,6 +279,41 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
             cugo_k::chol_dbg_skip_begin(-1, -1, dump), skip_scope.on = true;
         dbg_calls++;
     }
+    // stale-line injection (diagnosis): CUGO_DEBUG_STALE=call:kind:line — in call number `call` the 128-byte line
+    // `line` of W (kind 0) or of x in elimination order (kind 1) shows the PREVIOUS factorisation's content to the one
+    // launch that follows the launch that writes it (the tile launch of the level; the backward launch of the next level
+    // down) and the right content to everything later: a write that becomes visible one launch late
+    double* stale_line = nullptr;
+    int stale_stage = -1, stale_kind = -1;
+    {
+        const char* sl = std::getenv("CUGO_DEBUG_STALE");
+        int c = -1, kind = -1;
+        long line = -1;
+        if (sl && std::sscanf(sl, "%d:%d:%ld", &c, &kind, &line) == 3 && c == dbg_calls - 1 && line >= 0)
+        {
+            std::vector<int> stage_of(plan.n_super, 0);
+            for (int st = 0; st < plan.n_stages; st++)
+                for (int t = plan.stage_task_ptr[st]; t < plan.stage_task_ptr[st + 1]; t++)
+                    for (int fi = plan.task_ptr[t]; fi < plan.task_ptr[t + 1]; fi++)
+                        stage_of[plan.task_fronts[fi]] = st;
+            const int64_t e = 16 * (int64_t)line;
+            if (kind == 0 && e + 16 <= plan.winv_doubles)
+            {
+                int f = 0;
+                for (int k = 0; k < plan.n_super; k++)
+                    if (plan.woff[k] <= e && plan.woff[k] >= plan.woff[f])
+                        f = k;
+                stale_line = d_winv.data() + e, stale_stage = stage_of[f], stale_kind = 0;
+            }
+            else if (kind == 1 && e + 16 <= 6LL * plan.n)
+                stale_line = d_xnew.data() + e, stale_stage = stage_of[plan.col_front[e / 6]], stale_kind = 1;
+            if (stale_line)
+            {
+                dbg_scratch.resize(16);
+                CUGO_HIP(hipMemcpyAsync(dbg_scratch.data(), stale_line, 16 * sizeof(double), hipMemcpyDeviceToDevice, s));
+            }
+        }
+    }
     static const bool dbg = std::getenv("CUGO_DEBUG_STAMPS") != nullptr;
     static long long* d_stamps = nullptr;
     if (dbg && !d_stamps)
@@ -320,12 +355,17 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
                 s, dev, d_fronts.data(), t0, t1 - t0, d_wl_ptr, plan.ea_ptr[st],
                 plan.ea_ptr[st + 1] - plan.ea_ptr[st], plan.eab_ptr[st],
                 plan.eab_ptr[st + 1] - plan.eab_ptr[st], plan.syrk_ptr[st],
-                plan.syrk_ptr[st + 1] - plan.syrk_ptr[st], plan.stage_tile[st], lds_factor, d_fail);
+                plan.syrk_ptr[st + 1] - plan.syrk_ptr[st], plan.stage_tile[st], lds_factor, d_fail,
+                stale_kind == 0 && stale_stage == st ? stale_line : nullptr, dbg_scratch.data());
             if (plan.stage_tile[st] == 0)
+            {
                 cugo_k::launch_chol_two_phase(s, dev, d_fronts.data(), d_wl_ptr + 3L * plan.trsm_ptr[st],
                                               plan.trsm_ptr[st + 1] - plan.trsm_ptr[st],
                                               d_wl_ptr + 3L * plan.syrk_ptr[st],
                                               plan.syrk_ptr[st + 1] - plan.syrk_ptr[st]);
+                if (stale_kind == 0 && stale_stage == st)
+                    cugo_k::launch_swap16(s, stale_line, dbg_scratch.data());
+            }
         }
         if (hash_levels)
         { // (CUGO_DEBUG_HASH_LEVELS=0: only the checksums before and behind the loops — those between the levels
@@ -366,6 +406,8 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
         cugo_k::launch_chol_backward_stage(s, dev, d_fronts.data(), t0, t1 - t0, lds_backward, d_xnew.data(),
                                            d_x, d_wl_ptr + 3L * plan.bwg_ptr[st],
                                            plan.bwg_ptr[st + 1] - plan.bwg_ptr[st]);
+        if (stale_kind == 1 && (st == stale_stage || st == stale_stage - 1))
+            cugo_k::launch_swap16(s, stale_line, dbg_scratch.data()); // (old content for the next level down only)
         const int st_top = st;
         if (dbg && st_top == plan.n_stages - 1)
         { // keep the top stage's backward stamps (kernel 3) in slots 48.. before stage 0 overwrites them

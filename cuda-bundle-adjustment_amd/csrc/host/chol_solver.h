@@ -48,6 +48,7 @@ struct cugo_chol
     // and x are copied (same stream) into a slot of their own; cugo_debug_dump() writes the slots of the solver that
     // ran last to files — the autopsy of a run that deviated from its twin (tools/autopsy.py)
     std::vector<std::unique_ptr<cugo_host::DevBuf<double>>> keep;
+    cugo_host::DevBuf<double> dbg_scratch; // (CUGO_DEBUG_STALE: the other version of the line under test)
     void dump_kept(const char* dir);
     bool own_subtrees() const { return world > 1 && bcast && !plan.owner.empty(); }
 

@@ -2612,7 +2612,8 @@ void launch_chol_two_phase(hipStream_t s, const CholPlanDev& p, double* d_fronts
 
 void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,
                              int ntasks, const int32_t* d_wl, int eap0, int neap, int ea0, int nea,
-                             int sy0, int nsy, int tile, size_t lds_bytes, int32_t* d_fail)
+                             int sy0, int nsy, int tile, size_t lds_bytes, int32_t* d_fail, double* dbg_line,
+                             double* dbg_scratch)
 {
     (void)lds_bytes;
     if (ntasks <= 0)
@@ -2620,6 +2621,8 @@ void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fron
     ensure_lds(reinterpret_cast<const void*>(k_up_potrf), chol_lds_potrf_bytes());
     CUGO_LAUNCH(k_up_potrf, dim3(ntasks + neap + nea), dim3(BIG), chol_lds_potrf_bytes(), s, with_lds(p, chol_lds_potrf_bytes(), "k_up_potrf", ntasks + neap + nea, ntasks), d_fronts,
                 task0, ntasks, d_wl + 3L * eap0, neap, d_wl + 3L * ea0, d_fail);
+    if (dbg_line) // (CUGO_DEBUG_STALE: the tile launch sees the line as it was before this potrf launch ...
+        launch_swap16(s, dbg_line, dbg_scratch);
     if (tile == 0)
         return; // two-phase level: the caller queues launch_chol_two_phase
     if (nsy > 0 && tile == 32)
@@ -2634,6 +2637,8 @@ void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fron
         CUGO_LAUNCH(k_up_trsyrk, dim3(nsy), dim3(BIG), trsyrk_lds() * sizeof(double), s,
                     with_lds(p, trsyrk_lds() * sizeof(double), "k_up_trsyrk", nsy), d_fronts, d_wl + 3L * sy0);
     }
+    if (dbg_line) // ... and everything later sees what the potrf launch wrote)
+        launch_swap16(s, dbg_line, dbg_scratch);
 }
 
 void launch_chol_potrf_la(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0, int ntasks,
@@ -2667,6 +2672,12 @@ __global__ __launch_bounds__(256) void k_hash_words(const unsigned long long* __
         h += p[i] * (2 * i + 1); // (position-weighted: a swap of two words changes the sum)
     atomicAdd(out, h);
 }
+__global__ void k_swap16(double* __restrict__ a, double* __restrict__ b)
+{
+    const double x = a[threadIdx.x], y = b[threadIdx.x];
+    a[threadIdx.x] = y, b[threadIdx.x] = x;
+}
+void launch_swap16(hipStream_t s, double* line, double* scratch) { hipLaunchKernelGGL(k_swap16, dim3(1), dim3(16), 0, s, line, scratch); }
 __global__ void k_nop() {}
 void launch_nop(hipStream_t s) { hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, s); }
 void launch_hash_words(hipStream_t s, const void* p, size_t n_words, unsigned long long* out)

@@ -193,7 +193,10 @@ void launch_chol_subtree_stage(hipStream_t s, const CholPlanDev& p, double* d_fr
 // tile: edge of the update-matrix tiles of this level's items (64, or 32 on levels with few fronts)
 void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,
                              int ntasks, const int32_t* d_wl, int eap0, int neap, int ea0, int nea,
-                             int sy0, int nsy, int tile, size_t lds_bytes, int32_t* d_fail);
+                             int sy0, int nsy, int tile, size_t lds_bytes, int32_t* d_fail,
+                             double* dbg_line = nullptr, double* dbg_scratch = nullptr);
+// diagnosis (CUGO_DEBUG_STALE): exchanges the 16 doubles at `line` with those at `scratch`
+void launch_swap16(hipStream_t s, double* line, double* scratch);
 // two-phase form of a level's tile work (stage_tile == 0): trsm items (front, first row below the pivots,
 // rows) then syrk items (front, linear tile index, tile columns)
 void launch_chol_two_phase(hipStream_t s, const CholPlanDev& p, double* d_fronts, const int32_t* d_trsm, int ntrsm,

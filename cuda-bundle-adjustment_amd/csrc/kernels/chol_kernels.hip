@@ -2067,17 +2067,25 @@ constexpr int BIG = 1024; // workgroup size of the latency-critical single-front
 // like a consumer kernel seeing the PREVIOUS factorisation's value of something its producer just rewrote)
 __device__ __forceinline__ void kernel_acquire(const CholPlanDev& p)
 {
+#ifdef CUGO_DEBUG_HOOKS
     if (p.kernel_acquire & 1)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#else
+    (void)p;
+#endif
 }
 // CUGO_KERNEL_ACQUIRE=2 (3: both): every wave ends with an agent-scope release fence of its own (buffer_wbl2 sc1 and a
 // wait for all its stores) — the writer's side of the same question
 __device__ __forceinline__ void kernel_release(const CholPlanDev& p)
 {
+#ifdef CUGO_DEBUG_HOOKS
     if (p.kernel_acquire & 2)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     else if (p.kernel_acquire & 4) // 4: every wave only waits until its own stores are acknowledged before it ends
         __builtin_amdgcn_s_waitcnt(0); // (vmcnt counts stores too on gfx9; a workgroup-scope fence emits nothing here)
+#else
+    (void)p;
+#endif
 }
 
 // CUGO_DEBUG_ZERO_LDS=1 / 2: every kernel of the factorisation first fills its dynamic LDS with zeros / NaNs (the
@@ -2085,6 +2093,7 @@ __device__ __forceinline__ void kernel_release(const CholPlanDev& p)
 // the CU before has left there
 __device__ __forceinline__ void dbg_fill_lds(const CholPlanDev& p, double* lds)
 {
+#ifdef CUGO_DEBUG_HOOKS
     if (p.zero_lds)
     {
         const double v = p.zero_lds == 2 ? __longlong_as_double(0x7FF8000000000000LL) : 0.0;
@@ -2092,6 +2101,9 @@ __device__ __forceinline__ void dbg_fill_lds(const CholPlanDev& p, double* lds)
             lds[i] = v;
         __syncthreads();
     }
+#else
+    (void)p, (void)lds;
+#endif
 }
 
 // ---------------------------------------------------------------- stage 0: subtrees ----
@@ -2146,8 +2158,10 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
                                                   const int32_t* __restrict__ wl_eab,
                                                   int32_t* __restrict__ fail)
 {
+#ifdef CUGO_DEBUG_HOOKS
     if (p.dbg_skip_wg == (int)blockIdx.x)
         return; // (fault injection, see DbgSkip)
+#endif
     kernel_acquire(p);
     extern __shared__ double lds[];
     if ((int)blockIdx.x >= npotrf)
@@ -2244,8 +2258,10 @@ __device__ __forceinline__ TileItem tile_item(const CholPlanDev& p, const int32_
 __global__ __launch_bounds__(BIG) void k_up_trsyrk(CholPlanDev p, double* __restrict__ fronts,
                                                    const int32_t* __restrict__ wl)
 {
+#ifdef CUGO_DEBUG_HOOKS
     if (p.dbg_skip_wg == (int)blockIdx.x)
         return; // (fault injection, see DbgSkip)
+#endif
     kernel_acquire(p);
     extern __shared__ double lds[];
     dbg_fill_lds(p, lds);
@@ -2261,8 +2277,10 @@ __global__ __launch_bounds__(BIG) void k_up_trsyrk(CholPlanDev p, double* __rest
 __global__ __launch_bounds__(BIG) void k_up_trsyrk32(CholPlanDev p, double* __restrict__ fronts,
                                                      const int32_t* __restrict__ wl)
 {
+#ifdef CUGO_DEBUG_HOOKS
     if (p.dbg_skip_wg == (int)blockIdx.x)
         return; // (fault injection, see DbgSkip)
+#endif
     kernel_acquire(p);
     extern __shared__ double lds[];
     dbg_fill_lds(p, lds);
@@ -2367,8 +2385,10 @@ constexpr int KC_SYRK2 = 48;
 __global__ __launch_bounds__(BIG) void k_up_trsm(CholPlanDev p, double* __restrict__ fronts,
                                                  const int32_t* __restrict__ wl)
 {
+#ifdef CUGO_DEBUG_HOOKS
     if (p.dbg_skip_wg == (int)blockIdx.x)
         return; // (fault injection, see DbgSkip)
+#endif
     kernel_acquire(p);
     extern __shared__ double lds[];
     dbg_fill_lds(p, lds);
@@ -2381,8 +2401,10 @@ __global__ __launch_bounds__(BIG) void k_up_trsm(CholPlanDev p, double* __restri
 __global__ __launch_bounds__(BIG) void k_up_syrk(CholPlanDev p, double* __restrict__ fronts,
                                                  const int32_t* __restrict__ wl)
 {
+#ifdef CUGO_DEBUG_HOOKS
     if (p.dbg_skip_wg == (int)blockIdx.x)
         return; // (fault injection, see DbgSkip)
+#endif
     kernel_acquire(p);
     extern __shared__ double lds[];
     dbg_fill_lds(p, lds);
@@ -2444,8 +2466,10 @@ __global__ __launch_bounds__(BIG) void k_backward_stage(CholPlanDev p,
                                                         double* __restrict__ xnew,
                                                         double* __restrict__ xout)
 {
+#ifdef CUGO_DEBUG_HOOKS
     if (p.dbg_skip_wg == (int)blockIdx.x)
         return; // (fault injection, see DbgSkip)
+#endif
     kernel_acquire(p);
     extern __shared__ double lds[];
     dbg_fill_lds(p, lds);

@@ -4,7 +4,7 @@ the solution after every factorisation.  The first run's copies are the referenc
 its copies of the first deviating iteration are written out and compared: which arrays differ, in which fronts, in how
 many entries, and whether a differing entry holds the value the PREVIOUS factorisation left there (a stale read or a
 lost write) or something new (a wrong computation downstream of one).
-    python tools/autopsy.py N [outdir] [call:launch:workgroup of a deviation made on purpose in run 2]"""
+    python tools/autopsy.py N [outdir] [call:launch:workgroup of a deviation made on purpose in run 2: needs the HOOKS=1 build, CUGO_LIB=...]"""
 import ctypes as C, importlib, os, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -2,7 +2,7 @@
 plan is uploaded): the factorisation of a fixed system and the whole optimisation of the medium graph must give the
 same bits whatever runs late.
     python tools/delay_check.py
-    python tools/delay_check.py CUGO_DEBUG_ZERO_LDS 0 1 2     (any other diagnosis switch read when a plan is uploaded and
+    CUGO_LIB=.../libcugo_hip_hooks.so python tools/delay_check.py CUGO_DEBUG_ZERO_LDS 0 1 2     (make HOOKS=1; any other diagnosis switch read when a plan is uploaded and
                                                              its values: here the kernels' LDS pre-filled with zeros / NaNs)"""
 import ctypes as C, importlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -10,6 +10,8 @@ block() { # name, runs, env...
   name=$1; n=$2; shift 2
   env "$@" timeout -k 10 300 python tools/repro_medium.py $n "" >> gpurun_out/hunt_$name.txt 2>&1 || true
 }
+HOOKS=$GRAFT_REPO_ROOT/cuda-bundle-adjustment_amd/libcugo_hip_hooks.so  # the build that carries the kernels' diagnosis hooks
+[ -f $HOOKS ] || make -C cuda-bundle-adjustment_amd HOOKS=1 -j16 -s
 hipcc --offload-arch=gfx950 -O2 tools/mfma_selftest.hip -o /tmp/mfma_selftest 2> /dev/null
 hipcc --offload-arch=gfx950 -O2 tools/coherence_selftest.hip -o /tmp/coherence_selftest 2> /dev/null
 selftest() {
@@ -27,9 +29,10 @@ for round in 1 2 3 4 5 6; do
   block default 400 CUGO_X=0
   block panel16_0 400 CUGO_PANEL16=0
   block hsc_mfma_0 400 CUGO_HSC_MFMA=0
-  block kernel_acquire 400 CUGO_KERNEL_ACQUIRE=1
-  block kernel_release 400 CUGO_KERNEL_ACQUIRE=2
-  block wave_waits 400 CUGO_KERNEL_ACQUIRE=4
+  block hooks_build 400 CUGO_LIB=$HOOKS
+  block kernel_acquire 400 CUGO_KERNEL_ACQUIRE=1 CUGO_LIB=$HOOKS
+  block kernel_release 400 CUGO_KERNEL_ACQUIRE=2 CUGO_LIB=$HOOKS
+  block wave_waits 400 CUGO_KERNEL_ACQUIRE=4 CUGO_LIB=$HOOKS
   block serialize3 400 AMD_SERIALIZE_KERNEL=3
   block hash 400 CUGO_DEBUG_HASH=/tmp/hunt_hash.txt
   block hash_ends 400 CUGO_DEBUG_HASH=/tmp/hunt_hash2.txt CUGO_DEBUG_HASH_LEVELS=0
@@ -37,7 +40,7 @@ for round in 1 2 3 4 5 6; do
   block round2_paths 400 CUGO_PANEL16=0 CUGO_HSC_MFMA=0 CUGO_ASM_FRONTS=0 CUGO_TRIAL_POLL=0 CUGO_SPECULATE=0 CUGO_EA_LDS=0
   echo "round $round done"
 done
-for n in default panel16_0 hsc_mfma_0 kernel_acquire kernel_release wave_waits serialize3 hash hash_ends xcd_affinity_0 round2_paths; do
+for n in default panel16_0 hsc_mfma_0 hooks_build kernel_acquire kernel_release wave_waits serialize3 hash hash_ends xcd_affinity_0 round2_paths; do
   echo "$n: $(grep -c 'first chi2 difference' gpurun_out/hunt_$n.txt || true) deviating of $(grep -c ' runs ' gpurun_out/hunt_$n.txt)x400"
 done
 grep -h "first differing" gpurun_out/hunt_hash.txt gpurun_out/hunt_hash_ends.txt | cut -c1-300 || true

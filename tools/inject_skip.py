@@ -5,7 +5,7 @@ failure is made on purpose: with CUGO_DEBUG_SKIP=call:launch:workgroup one workg
 factorisation returns at once, so whatever it would have written keeps the value of the factorisation before —
 for EVERY workgroup of every launch of every factorisation of optimize(10), one run each — and the chi2 of that
 iteration is looked up among the alternates.  A match names the kernel, the level and the workgroup.
-    CUGO_LIB=.../libcugo_hip.so python tools/inject_skip.py [seconds] [call call ...]"""
+    CUGO_LIB=.../libcugo_hip_hooks.so python tools/inject_skip.py [seconds] [call call ...]   (make HOOKS=1: the hook is not in the product build)"""
 import importlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -208,6 +208,26 @@ int cugo_chol_factor_solve(cugo_chol* s, const double* d_Hsc, double lambda, con
         s->factor_solve(d_Hsc, lambda, d_bsc, d_x, d_fail);
     });
 }
+int cugo_debug_pin_reference(void)
+{
+    return guarded([&] { cugo_debug_pin_reference_solver(); });
+}
+int cugo_debug_dump_call(int which, int call, const char* path)
+{
+    return guarded([&] {
+        cugo_chol* s = cugo_debug_solver(which);
+        if (!s)
+            throw std::runtime_error("cugo_debug_dump_call: no solver has run with CUGO_DEBUG_KEEP");
+        s->dump_slot(call, path);
+    });
+}
+int cugo_debug_plan_array(int which, const char* name, const int32_t** out)
+{
+    cugo_chol* s = cugo_debug_solver(which);
+    if (!s)
+        return -1;
+    return cugo_chol_plan_array(s, name, out);
+}
 int cugo_debug_dump(const char* dir, int* n_calls)
 {
     return guarded([&] {

@@ -253,6 +253,26 @@ int cugo_debug_dump_last_solver(const char* dir)
     g_last_kept->dump_kept(dir);
     return (int)g_last_kept->keep.size();
 }
+static cugo_chol* g_ref_kept = nullptr; // (the reference run's solver, pinned by the autopsy tool while its graph stays open)
+cugo_chol* cugo_debug_solver(int which) { return which ? g_ref_kept : g_last_kept; }
+void cugo_debug_pin_reference_solver() { g_ref_kept = g_last_kept; }
+void cugo_chol::dump_slot(int call, const char* path)
+{
+    CUGO_HIP(hipStreamSynchronize(ctx->stream));
+    const size_t nf = (size_t)plan.front_doubles, nw = (size_t)plan.winv_doubles, nl = (size_t)plan.l21_doubles,
+                 nx = (size_t)6 * plan.n, total = nf + nw + nl + 2 * nx;
+    if (call < 0 || call >= (int)keep.size() || keep[call]->size() < total)
+        throw std::runtime_error("cugo_debug_dump_call: no such slot");
+    std::vector<double> h(total);
+    CUGO_HIP(hipMemcpy(h.data(), keep[call]->data(), total * sizeof(double), hipMemcpyDeviceToHost));
+    std::FILE* f = std::fopen(path, "wb");
+    if (!f)
+        throw std::runtime_error(std::string("cugo_debug_dump_call: cannot write ") + path);
+    const int64_t hdr[8] = {(int64_t)nf, (int64_t)nw, (int64_t)nl, (int64_t)nx, (int64_t)nx, 0, 0, 0};
+    std::fwrite(hdr, sizeof hdr, 1, f);
+    std::fwrite(h.data(), sizeof(double), h.size(), f);
+    std::fclose(f);
+}
 
 void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d_bsc, double* d_x,
                              int32_t* d_fail)

@@ -50,6 +50,7 @@ struct cugo_chol
     std::vector<std::unique_ptr<cugo_host::DevBuf<double>>> keep;
     cugo_host::DevBuf<double> dbg_scratch; // (CUGO_DEBUG_STALE: the other version of the line under test)
     void dump_kept(const char* dir);
+    void dump_slot(int call, const char* path);
     bool own_subtrees() const { return world > 1 && bcast && !plan.owner.empty(); }
 
     void analyze(int n, const int32_t* rowptr, const int32_t* colind);
@@ -62,3 +63,5 @@ struct cugo_chol
 
 // diagnosis: writes the CUGO_DEBUG_KEEP slots of the solver that ran last to dir/call<k>.bin; returns their number
 int cugo_debug_dump_last_solver(const char* dir);
+cugo_chol* cugo_debug_solver(int which); // 0: the solver that ran last with CUGO_DEBUG_KEEP, 1: the pinned one
+void cugo_debug_pin_reference_solver();

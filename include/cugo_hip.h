@@ -208,6 +208,11 @@ int cugo_chol_factor_solve(cugo_chol* s, const double* d_Hsc, double lambda, con
  * W, L21 and the solution after each of its first 16 factor_solve calls; this writes those of the solver that ran last
  * (its graph still open) to dir/call<k>.bin: int64[8] header {fronts, W, L21, x permuted, x: doubles}, then the arrays. */
 int cugo_debug_dump(const char* dir, int* n_calls);
+/* the solver that ran last becomes "the reference" (which = 1 below; its graph has to stay open); one slot of either
+ * solver (which = 0: the one that ran last) to a file of the same layout; a named plan array of either solver */
+int cugo_debug_pin_reference(void);
+int cugo_debug_dump_call(int which, int call, const char* path);
+int cugo_debug_plan_array(int which, const char* name, const int32_t** out);
 /* statistics of the analysis: nnz(L) in scalars, factorisation flops, #supernodes, #stages */
 int cugo_chol_stats(const cugo_chol* s, double* nnzL, double* flops, int* n_supernodes,
                     int* n_stages, double* front_bytes);

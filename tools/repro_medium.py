@@ -10,9 +10,11 @@ cugo = importlib.import_module("cuda-bundle-adjustment_amd")
 import numpy as np
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 interleave = "--interleave" in sys.argv
-args = [a for a in sys.argv[2:] if a != "--interleave"]
+big = "--10k" in sys.argv   # the 10 000-pose / 1 M-landmark / 5 M-edge graph of test_synth10k_full_size instead
+args = [a for a in sys.argv[2:] if a not in ("--interleave", "--10k")]
 configs = [dict(kv.split("=") for kv in a.split(",") if kv) for a in args] or [{}]
-d = cugo.synth(400, 8000, 33000, seed=11, n_loop_closures=200)
+d = (cugo.synth(10000, 1000000, 5000000, seed=10000, n_loop_closures=0, stereo_fraction=0.0) if big else
+     cugo.synth(400, 8000, 33000, seed=11, n_loop_closures=200))
 if interleave:
     refs, bads = [None] * len(configs), [0] * len(configs)
     for c in range(N):

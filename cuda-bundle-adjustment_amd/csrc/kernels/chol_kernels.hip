@@ -805,8 +805,15 @@ __device__ __forceinline__ void stamp_wave(int kernel, int slot)
 
 // half 0: rows j0 .. j0+63; half 1: the diagonal block's rows again (lanes 0..15, not stored) and rows
 // j0+64 .. j0+95 (lanes 16..47).  ncp = padded size of the LDS matrix (identity beyond nc).
+// When a panel has a second half (ncp - j0 > 64) the two waves run side by side with no synchronisation between
+// them, and half 1 LOADS the diagonal tile that half 0 factors in place.  Half 0 therefore parks the 16 rows of the
+// diagonal tile in `stage` (column stride LLD) instead of storing them over the tile, and the tile is filled in from
+// there behind the next barrier (p16_unstage).  (Stored in place, a second wave that issued its loads late — behind
+// the ~200 operand loads the other 14 waves queue after the barrier — read a tile whose first columns were already
+// eliminated: a slightly wrong L for ITS rows, i.e. block row 5 of a 96-column front, about once in 10^5 such
+// fronts: the run-to-run deviation of DESIGN.md section 2.)
 __device__ __forceinline__ void panel16_factor(double* __restrict__ Ls, int ncp, int j0, double* __restrict__ invd,
-                                               int half)
+                                               int half, double* __restrict__ stage, bool park = true)
 {
     const int lane = opaque_lane();
     const int rr = half == 0 ? lane : (lane < 16 ? lane : lane + 48); // row inside the panel
@@ -826,7 +833,8 @@ __device__ __forceinline__ void panel16_factor(double* __restrict__ Ls, int ncp,
         stamp(2, 1);
     }
     const bool st = (half == 0 || lane >= 16) && j0 + rr < ncp;
-    double* W0 = Ls + j0 * LLD + (st ? j0 + rr : NC_MAX + (lane & 15));
+    const bool parked = park && half == 0 && lane < 16 && ncp - j0 > 64; // (the diagonal tile's rows while half 1 may read it)
+    double* W0 = parked ? stage + lane : Ls + j0 * LLD + (st ? j0 + rr : NC_MAX + (lane & 15));
     double iv[16];
 #pragma unroll
     for (int k = 0; k < 16; k++)
@@ -872,6 +880,15 @@ __device__ __forceinline__ void panel16_factor(double* __restrict__ Ls, int ncp,
     }
     if (j0 == 32 && half == 0)
         stamp(2, 3);
+}
+
+// the parked rows of the diagonal tile at j0 (panel16_factor) into their place: one wave, behind a barrier
+__device__ __forceinline__ void p16_unstage(double* __restrict__ Ls, const double* __restrict__ stage, int j0)
+{
+    const int lane = opaque_lane(), r = lane & 15, k4 = lane >> 4;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        Ls[(j0 + k4 + 4 * q) * LLD + j0 + r] = stage[(k4 + 4 * q) * LLD + r];
 }
 
 // trailing tile (rows R.., columns C..) -= L_R D L_C^T, from the factored 16-column panel at j0 (stored
@@ -1045,8 +1062,18 @@ __device__ __forceinline__ void dev_potrf16(int ncp, double* __restrict__ lds, d
         __syncthreads();
     }
     stamp(0, 2);
+    // parking place of a two-wave panel's diagonal tile: the slots of U from block (1,0) on — nothing is written
+    // there before phase B of slot 1, and the last two-wave panel (j0 = 16) is put back in phase A of slot 1
+    double* stage = Ub + 256;
+    // (diagnosis: CUGO_DEBUG_DELAY=7 — the second panel wave alone runs late, the case the parking place is for;
+    // =8 — the same WITHOUT the parking place, i.e. the kernel as it was: deviates at once)
+    const bool park = dbg_delay != 8;
     if (w == 0 || (w == 1 && ncp > 64))
-        panel16_factor(Ls, ncp, 0, invd, w);
+    {
+        if ((dbg_delay == 7 || dbg_delay == 8) && w == 1)
+            dbg_sleep();
+        panel16_factor(Ls, ncp, 0, invd, w, stage, park);
+    }
     __syncthreads();
     stamp(0, 3);
     // slot s: [phase A: block column s+1 updated by panel s] [phase B: panel s+1 factored || the other
@@ -1062,6 +1089,8 @@ __device__ __forceinline__ void dev_potrf16(int ncp, double* __restrict__ lds, d
             // phase A: the block column of the next panel, <= 5 tiles, one per wave, on waves 0 1 2 3 6 (four
             // different SIMDs first)
             const int ta = w < 4 ? w : (w == 6 ? 4 : 99);
+            if (w == 7 && park && ncp - j0 > 64) // panel s had two waves: its diagonal tile comes out of the parking place
+                p16_unstage(Ls, stage, j0);
             if (dbg_delay == 3 && (w & 1))
                 dbg_sleep();
             if (s + 1 + ta < nblk)
@@ -1080,7 +1109,9 @@ __device__ __forceinline__ void dev_potrf16(int ncp, double* __restrict__ lds, d
             // other waves of the CU (after the barrier every wave issues its LDS operand loads at once; at
             // equal priority the panel's 16 loads — and later its stores — queue behind ~200 others)
             __builtin_amdgcn_s_setprio(3);
-            panel16_factor(Ls, ncp, jn, invd, w);
+            if ((dbg_delay == 7 || dbg_delay == 8) && w == 1)
+                dbg_sleep();
+            panel16_factor(Ls, ncp, jn, invd, w, stage, park);
             __builtin_amdgcn_s_setprio(0);
             if (s == 1)
                 stamp(5, 2);

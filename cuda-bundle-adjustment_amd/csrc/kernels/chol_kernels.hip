@@ -1067,7 +1067,7 @@ __device__ __forceinline__ void dev_potrf16(int ncp, double* __restrict__ lds, d
     double* stage = Ub + 256;
     // (diagnosis: CUGO_DEBUG_DELAY=7 — the second panel wave alone runs late, the case the parking place is for;
     // =8 — the same WITHOUT the parking place, i.e. the kernel as it was: deviates at once)
-    const bool park = dbg_delay != 8;
+    const bool park = dbg_delay != 8 && dbg_delay != 9; // (9: no parking place and no delay — the old kernel, to time the difference)
     if (w == 0 || (w == 1 && ncp > 64))
     {
         if ((dbg_delay == 7 || dbg_delay == 8) && w == 1)

@@ -1132,15 +1132,21 @@ def test_no_result_depends_on_unwritten_device_memory(mode):
 def test_potrf_gives_the_same_bits_whichever_waves_run_late(monkeypatch):
     """CUGO_DEBUG_DELAY (chol_kernels.hip: dbg_sleep): chosen waves / workgroups of k_up_potrf — the task waves, the
     panel waves, every other wave of phase A or B, the potrf workgroups, the extend-add workgroups of the same
-    launch — sleep ~25 k cycles at the start of their phase.  Every hand-over inside the kernel goes through a
-    barrier, so the optimisation must end on the same bits whatever runs late (tools/delay_check.py does the same
-    on the kitti_00 shape as well)."""
+    launch, the SECOND wave of a two-wave panel alone (7) — sleep ~25 k cycles at the start of their phase.  Every
+    hand-over inside the kernel goes through a barrier, so the optimisation must end on the same bits whatever runs
+    late (tools/delay_check.py does the same on the kitti_00 shape as well).  Pattern 7 is the one that found a
+    hand-over WITHOUT a barrier (round 3): the first panel wave factored the diagonal tile in place while the second
+    was still loading it — the rare run-to-run deviation of DESIGN.md section 2; pattern 8 is pattern 7 on the kernel
+    as it was (the tile stored in place), and must NOT give the same bits: the test of the test."""
     d = cugo.synth(400, 8000, 33000, seed=11, n_loop_closures=200)
     ref = None
-    for delay in (0, 1, 2, 3, 4, 5, 6):
+    for delay in (0, 1, 2, 3, 4, 5, 6, 7):
         monkeypatch.setenv("CUGO_DEBUG_DELAY", str(delay))
         out = run_graph(d, 5)
         cur = ([s["chi2"] for s in out["stats"]], out["pose"])
         if ref is None:
             ref = cur
         assert cur[0] == ref[0] and np.array_equal(cur[1], ref[1]), delay
+    monkeypatch.setenv("CUGO_DEBUG_DELAY", "8")
+    out = run_graph(d, 5)
+    assert [s["chi2"] for s in out["stats"]] != ref[0], "the old in-place store no longer shows the race: pattern 7 proves nothing"

@@ -117,6 +117,8 @@ for c in range(1, N):
                       ("   (iteration %d: %r)" % (it - 1, float(P[k][i]))) if P is not None else ""))
         del A, B, P
     g.close()
+    if c % 50 == 49:
+        print("  ... %d runs, %d deviating" % (c + 1, found), flush=True)
     if found >= 4:
         break
 print("runs", c + 1, "deviating", found)

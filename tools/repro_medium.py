@@ -61,6 +61,8 @@ for cfg in configs:
         cur = (tuple(s["chi2"] for s in st), g.poses().copy(), [(s["lam"], s["rho"], s["trials"]) for s in st])
         g.close()
         hcur = last_hashes() if hf else None
+        if c % 50 == 49:
+            print("  ... %d runs, %d deviating" % (c + 1, len(bad)), flush=True)  # (a silent GPU job is taken to be hung)
         if ref is None:
             ref, href = cur, hcur
         elif cur[0] != ref[0] or not np.array_equal(cur[1], ref[1]):

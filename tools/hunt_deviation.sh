@@ -1,6 +1,8 @@
-# GPU box: is this a box (and a time) at which the rare run-to-run deviation shows?  If so:
-# which configuration makes it go away?  The deviation comes in bursts, so the configurations take turns in short
-# blocks (one process each: some of the switches are read by the HIP runtime when it starts) and the counts are summed.
+# GPU box: the harness of the round-3 hunt for a rare run-to-run deviation (cause found: a race
+# between the two waves of a wide panel in k_up_potrf, fixed).  Kept as a regression harness: self-tests of the card
+# (per-CU bit equality, cross-XCD visibility), a control (800 fresh optimisers on the 400-pose graph, bitwise), and — if
+# the control deviates — the autopsy of a deviating run, interleaved blocks of switches, fault injection.
+# The sharper detector is the 10k-pose graph:  python tools/repro_medium.py 300 --10k ""  /  python tools/autopsy.py 600 --10k
 #   gpurun --timeout 1150 -- bash tools/hunt_deviation.sh
 set -e
 cd $GRAFT_REPO_ROOT

@@ -302,8 +302,8 @@ def main():
         barrier()
         el_init = max_over_ranks(time.perf_counter() - t0)
         # ---- full re-flattening (as after any change to an edge or a fixed flag), structure kept -
-        os.environ["CUGO_NO_FLATTEN_REUSE"] = "1"
         for g in timed:
+            g.set_option("flatten_reuse", 0)
             reset(g)
         barrier()
         t0 = time.perf_counter()
@@ -313,12 +313,13 @@ def main():
         barrier()
         el_flat = max_over_ranks(time.perf_counter() - t0)
         it_flat = sum(len(g.stats()) for g in timed)
-        del os.environ["CUGO_NO_FLATTEN_REUSE"]
         for g in timed:
+            g.set_option("flatten_reuse", 1)
             reset(g)
         # ---- structure dirty: pattern + ordering + symbolic analysis inside the step ---------
-        os.environ["CUGO_NO_STRUCTURE_REUSE"] = "1"
         nd = min(len(timed), 3)
+        for g in timed[:nd]:
+            g.set_option("structure_reuse", 0)
         barrier()
         t0 = time.perf_counter()
         for g in timed[:nd]:
@@ -328,7 +329,8 @@ def main():
         el_dirty = max_over_ranks(time.perf_counter() - t0)
         it_dirty = sum(len(g.stats()) for g in timed[:nd])
         dirty_profile = timed[0].time_profile()
-        del os.environ["CUGO_NO_STRUCTURE_REUSE"]
+        for g in timed[:nd]:
+            g.set_option("structure_reuse", 1)
         extras = {
             "optimize_only": {"ms_per_step": el_opt / len(timed) * 1e3, "value": nedges * it_opt / el_opt,
                               "note": "optimize(%d) alone, flattened graph resident in HBM" % args.iters},

@@ -12,8 +12,10 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# CUGO_LIB selects another build of the same library (tools/run_san.sh: the sanitizer build)
+# CUGO_LIB selects another build of the same library (tools/run_san.sh: the sanitizer build; the diagnosis tools:
+# the hooks build)
 LIB_PATH = os.environ.get("CUGO_LIB") or os.path.join(_HERE, "libcugo_hip.so")
+HOOKS_LIB_PATH = os.path.join(_HERE, "libcugo_hip_hooks.so")  # make HOOKS=1: delay patterns, checksums, fault injection
 _lib = None
 
 OK = 0
@@ -246,6 +248,11 @@ class Graph:
 
     def initialize(self):
         check(lib().cugo_graph_initialize(self._g))
+
+    def set_option(self, name, value):
+        """one run-time switch of this optimiser: "flatten_reuse", "structure_reuse", "init_timing" (the CUGO_*
+        environment variables are read once, when the optimiser is created)"""
+        check(lib().cugo_graph_set_option(self._g, name.encode(), int(value)))
 
     def flatten_reuses(self):
         """initialize() calls that found the graph unchanged and only refreshed the estimates"""

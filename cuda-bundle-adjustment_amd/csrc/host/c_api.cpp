@@ -160,8 +160,10 @@ int cugo_compute_schur(cugo_ctx* ctx, const cugo_edges* ev, const cugo_hsc_struc
         if (!d_T && !hs->d_grp_ptr)
             throw std::runtime_error("cugo_compute_schur: d_T may only be NULL with a landmark-major plan "
                                      "(cugo_hsc_plan_create); the gather kernels read T from memory");
+        cugo_k::SchurRows form;
+        form.mfma = ctx->opt.hsc_mfma, form.xcd = ctx->opt.hsc_xcd;
         cugo_k::launch_schur(ctx->stream, *ev, *hs, lambda, damp_hsc_diag, d_Hpp, d_bp, d_Hll, d_bl,
-                             d_Hpl, d_invHll, d_T, d_bsc, d_Hsc);
+                             d_Hpl, d_invHll, d_T, d_bsc, d_Hsc, false, form);
         CUGO_HIP(hipGetLastError());
     });
 }
@@ -208,6 +210,7 @@ int cugo_chol_factor_solve(cugo_chol* s, const double* d_Hsc, double lambda, con
         s->factor_solve(d_Hsc, lambda, d_bsc, d_x, d_fail);
     });
 }
+#ifdef CUGO_DEBUG_HOOKS // diagnosis entry points: only libcugo_hip_hooks.so exports them (csrc/host/cugo_debug.h)
 int cugo_debug_pin_reference(void)
 {
     return guarded([&] { cugo_debug_pin_reference_solver(); });
@@ -236,6 +239,7 @@ int cugo_debug_dump(const char* dir, int* n_calls)
             *n_calls = n;
     });
 }
+#endif
 int cugo_chol_stats(const cugo_chol* s, double* nnzL, double* flops, int* n_super, int* n_stages,
                     double* front_bytes)
 {
@@ -597,6 +601,13 @@ int cugo_graph_flatten_reuses(cugo_graph* g)
         }) != 0)
         return -1;
     return n;
+}
+int cugo_graph_set_option(cugo_graph* g, const char* name, int value)
+{
+    return guarded([&] {
+        if (!g || !g->opt->setOption(name, value))
+            throw std::invalid_argument(std::string("cugo_graph_set_option: unknown option ") + (name ? name : "(null)"));
+    });
 }
 int cugo_graph_optimize(cugo_graph* g, int n_iters)
 {

@@ -154,11 +154,9 @@ void cugo_chol::upload(hipStream_t s)
     D.n = P.n, D.perm = b32 + o_perm, D.col_front = b32 + o_col_front;
     D.junk = d_junk.data();
     D.woff = b64 + o_woff, D.winv = d_winv.data(), D.nc_max = P.nc_max;
+    D.ea_lds = opt.ea_lds, D.panel16 = opt.panel16;
+#ifdef CUGO_DEBUG_HOOKS
     {
-        const char* e = std::getenv("CUGO_EA_LDS");
-        D.ea_lds = !(e && e[0] == '0');
-        const char* e16 = std::getenv("CUGO_PANEL16");
-        D.panel16 = !(e16 && e16[0] == '0');
         const char* ka = std::getenv("CUGO_KERNEL_ACQUIRE");
         D.kernel_acquire = ka ? std::atoi(ka) & 7 : 0; // 1: acquire at the start, 2: release at the end, 3: both, 4: waves wait for their stores
         const char* ed = std::getenv("CUGO_DEBUG_DELAY");
@@ -167,24 +165,15 @@ void cugo_chol::upload(hipStream_t s)
         D.zero_lds = ez ? std::atoi(ez) : 0, D.lds_doubles = 0;
         D.dbg_skip_wg = -1;
     }
+#endif
     D.l21off = b64 + o_l21off, D.l21 = d_l21.data();
     D.ldf = b64 + o_ldf, D.alias_of = b32 + o_alias, D.bw_np = b32 + o_bwnp, D.la_np = b32 + o_lanp;
     d_wl_ptr = b32 + o_wl;
     D.wl_base = d_wl_ptr, D.fat = b32 + o_fat, D.ea1 = b32 + o_ea1;
     D.asm_map = b32 + o_asm_map, D.asm_off = b64 + o_asm_off;
-    {
-        const char* e = std::getenv("CUGO_ASM_FRONTS"); // 0: clear + scatter (two launches)
-        asm_fronts = !(e && e[0] == '0');
-    }
+    asm_fronts = opt.asm_fronts; // (CUGO_ASM_FRONTS=0: clear + scatter, two launches)
     lds_factor = cugo_k::chol_lds_factor_bytes(P.nc_max);
     lds_backward = cugo_k::chol_lds_backward_bytes(P.nc_max, P.ld_max);
-}
-
-// CUGO_OWN_MIN_GFLOP (default 3): below this much work per factorisation every rank factors everything
-static double own_min_flops()
-{
-    const char* e = std::getenv("CUGO_OWN_MIN_GFLOP");
-    return 1e9 * (e ? std::atof(e) : 3.0);
 }
 
 void cugo_chol::analyze(int n, const int32_t* rowptr, const int32_t* colind)
@@ -197,23 +186,25 @@ void cugo_chol::analyze(int n, const int32_t* rowptr, const int32_t* colind)
 // ordering + symbolic factorisation only (host); upload() brings the plan to the device
 void cugo_chol::analyze_host(int n, const int32_t* rowptr, const int32_t* colind)
 {
-    CholOptions opt = CholOptions::from_env();
+    CholOptions copt = CholOptions::from_env();
     // CUGO_OWN_SUBTREES=0: every rank factors everything (the replicated form of rounds 1-2)
-    const char* own = std::getenv("CUGO_OWN_SUBTREES");
     // unset: rank-owned subtrees only where the factorisation has work to divide.  On a graph whose levels all
     // run at the latency floor of their launches (kitti_00 shape: 1.6 GFLOP over 17 levels, every level 18-45 us
     // whatever its number of fronts) a rank that factors an eighth of a level's fronts finishes the level no
-    // sooner, and the broadcasts at the ownership boundary come on top; CUGO_OWN_SUBTREES=1 forces the form
-    const bool own_forced = own && own[0] == '1';
-    if (world > 1 && bcast && !(own && own[0] == '0'))
-        opt.rank = rank, opt.world = world;
-    chol_analyze(n, rowptr, colind, opt, plan);
-    if (opt.world > 1 && !own_forced && plan.flops < own_min_flops())
+    // sooner, and the broadcasts at the ownership boundary come on top; CUGO_OWN_SUBTREES=1 forces the form —
+    // also under a ONE-rank communicator (every subtree then belongs to rank 0, the top of the tree is
+    // "replicated" on one rank, and every broadcast / reduce-scatter of the form is really issued: the
+    // rehearsal of the multi-GPU path that a single GPU allows)
+    const bool own_forced = opt.own_subtrees == 1;
+    if ((world > 1 || own_forced) && bcast && opt.own_subtrees != 0)
+        copt.rank = rank, copt.world = world, copt.owned = true;
+    chol_analyze(n, rowptr, colind, copt, plan);
+    if (copt.owned && !own_forced && plan.flops < 1e9 * opt.own_min_gflop)
     {
-        opt.rank = 0, opt.world = 1;
-        chol_analyze(n, rowptr, colind, opt, plan);
+        copt.rank = 0, copt.world = 1, copt.owned = false;
+        chol_analyze(n, rowptr, colind, copt, plan);
     }
-    lookahead = std::getenv("CUGO_LOOKAHEAD") && std::atoi(std::getenv("CUGO_LOOKAHEAD")) != 0;
+    lookahead = opt.lookahead;
     trans32.assign(plan.blk_trans.begin(), plan.blk_trans.end());
     pack();
     if (plan.nc_max > cugo_k::chol_max_pivot_cols() ||
@@ -224,7 +215,17 @@ void cugo_chol::analyze_host(int n, const int32_t* rowptr, const int32_t* colind
     analyzed = true;
 }
 
-static cugo_chol* g_last_kept = nullptr; // (diagnosis only: the solver that ran last with CUGO_DEBUG_KEEP; valid while its graph is open)
+#ifdef CUGO_DEBUG_HOOKS
+// ---- diagnosis (libcugo_hip_hooks.so only) -------------------------------------------------
+static cugo_chol* g_last_kept = nullptr; // the solver that ran last with CUGO_DEBUG_KEEP (cleared when it is destroyed)
+static cugo_chol* g_ref_kept = nullptr;  // the reference run's solver, pinned by the autopsy tool
+cugo_chol::~cugo_chol()
+{
+    if (g_last_kept == this)
+        g_last_kept = nullptr;
+    if (g_ref_kept == this)
+        g_ref_kept = nullptr;
+}
 void cugo_chol::dump_kept(const char* dir)
 {
     CUGO_HIP(hipStreamSynchronize(ctx->stream));
@@ -253,7 +254,6 @@ int cugo_debug_dump_last_solver(const char* dir)
     g_last_kept->dump_kept(dir);
     return (int)g_last_kept->keep.size();
 }
-static cugo_chol* g_ref_kept = nullptr; // (the reference run's solver, pinned by the autopsy tool while its graph stays open)
 cugo_chol* cugo_debug_solver(int which) { return which ? g_ref_kept : g_last_kept; }
 void cugo_debug_pin_reference_solver() { g_ref_kept = g_last_kept; }
 void cugo_chol::dump_slot(int call, const char* path)
@@ -274,42 +274,42 @@ void cugo_chol::dump_slot(int call, const char* path)
     std::fclose(f);
 }
 
-void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d_bsc, double* d_x,
-                             int32_t* d_fail)
+// what factor_solve() consults between its launches in the hooks build: fault injection (CUGO_DEBUG_SKIP), stale-line
+// injection (CUGO_DEBUG_STALE), in-stream checksums (CUGO_DEBUG_HASH, set by the engine), an empty kernel after every
+// level (CUGO_DEBUG_GAP), copies of every factorisation's arrays (CUGO_DEBUG_KEEP)
+struct cugo_chol_hooks
 {
-    hipStream_t s = ctx->stream;
-    // fault injection (diagnosis): CUGO_DEBUG_SKIP=call:launch:workgroup — in this solver's call number `call` the
-    // given workgroup of the given launch returns at once; CUGO_DEBUG_SKIP_DUMP=file: call 0 writes its launch table
-    struct SkipScope
-    {
-        bool on = false;
-        ~SkipScope()
-        {
-            if (on)
-                cugo_k::chol_dbg_skip_end();
-        }
-    } skip_scope;
-    {
-        const char* sk = std::getenv("CUGO_DEBUG_SKIP");
-        const char* dump = dbg_calls == 0 ? std::getenv("CUGO_DEBUG_SKIP_DUMP") : nullptr;
-        int c = -1, l = -1, w = -1;
-        if (sk && std::sscanf(sk, "%d:%d:%d", &c, &l, &w) == 3 && c == dbg_calls)
-            cugo_k::chol_dbg_skip_begin(l, w, dump), skip_scope.on = true;
-        else if (dump)
-            cugo_k::chol_dbg_skip_begin(-1, -1, dump), skip_scope.on = true;
-        dbg_calls++;
-    }
-    // stale-line injection (diagnosis): CUGO_DEBUG_STALE=call:kind:line — in call number `call` the 128-byte line
-    // `line` of W (kind 0) or of x in elimination order (kind 1) shows the PREVIOUS factorisation's content to the one
-    // launch that follows the launch that writes it (the tile launch of the level; the backward launch of the next level
-    // down) and the right content to everything later: a write that becomes visible one launch late
+    cugo_chol& c;
+    hipStream_t s;
+    bool skip_on = false;
     double* stale_line = nullptr;
     int stale_stage = -1, stale_kind = -1;
+    bool hash_levels, gap, keep_on;
+    explicit cugo_chol_hooks(cugo_chol& solver) : c(solver), s(solver.ctx->stream)
     {
+        const char* hl = std::getenv("CUGO_DEBUG_HASH_LEVELS");
+        hash_levels = !(hl && hl[0] == '0'); // (0: only the checksums before and behind the loops — those between the
+                                             // levels separate the launches, and the deviation they localise stays away)
+        gap = std::getenv("CUGO_DEBUG_GAP") != nullptr;
+        keep_on = std::getenv("CUGO_DEBUG_KEEP") != nullptr;
+        const cugo_host::CholPlan& plan = c.plan;
+        // CUGO_DEBUG_SKIP=call:launch:workgroup — in this solver's call number `call` the given workgroup of the given
+        // launch returns at once; CUGO_DEBUG_SKIP_DUMP=file: call 0 writes its launch table
+        const char* sk = std::getenv("CUGO_DEBUG_SKIP");
+        const char* dump = c.dbg_calls == 0 ? std::getenv("CUGO_DEBUG_SKIP_DUMP") : nullptr;
+        int cc = -1, l = -1, w = -1;
+        if (sk && std::sscanf(sk, "%d:%d:%d", &cc, &l, &w) == 3 && cc == c.dbg_calls)
+            cugo_k::chol_dbg_skip_begin(l, w, dump), skip_on = true;
+        else if (dump)
+            cugo_k::chol_dbg_skip_begin(-1, -1, dump), skip_on = true;
+        c.dbg_calls++;
+        // CUGO_DEBUG_STALE=call:kind:line — in call number `call` the 128-byte line `line` of W (kind 0) or of x in
+        // elimination order (kind 1) shows the PREVIOUS factorisation's content to the one launch that follows the
+        // launch that writes it and the right content to everything later: a write that becomes visible one launch late
         const char* sl = std::getenv("CUGO_DEBUG_STALE");
-        int c = -1, kind = -1;
+        int kind = -1;
         long line = -1;
-        if (sl && std::sscanf(sl, "%d:%d:%ld", &c, &kind, &line) == 3 && c == dbg_calls - 1 && line >= 0)
+        if (sl && std::sscanf(sl, "%d:%d:%ld", &cc, &kind, &line) == 3 && cc == c.dbg_calls - 1 && line >= 0)
         {
             std::vector<int> stage_of(plan.n_super, 0);
             for (int st = 0; st < plan.n_stages; st++)
@@ -323,17 +323,88 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
                 for (int k = 0; k < plan.n_super; k++)
                     if (plan.woff[k] <= e && plan.woff[k] >= plan.woff[f])
                         f = k;
-                stale_line = d_winv.data() + e, stale_stage = stage_of[f], stale_kind = 0;
+                stale_line = c.d_winv.data() + e, stale_stage = stage_of[f], stale_kind = 0;
             }
             else if (kind == 1 && e + 16 <= 6LL * plan.n)
-                stale_line = d_xnew.data() + e, stale_stage = stage_of[plan.col_front[e / 6]], stale_kind = 1;
+                stale_line = c.d_xnew.data() + e, stale_stage = stage_of[plan.col_front[e / 6]], stale_kind = 1;
             if (stale_line)
             {
-                dbg_scratch.resize(16);
-                CUGO_HIP(hipMemcpyAsync(dbg_scratch.data(), stale_line, 16 * sizeof(double), hipMemcpyDeviceToDevice, s));
+                c.dbg_scratch.resize(16);
+                CUGO_HIP(hipMemcpyAsync(c.dbg_scratch.data(), stale_line, 16 * sizeof(double), hipMemcpyDeviceToDevice, s));
             }
         }
     }
+    ~cugo_chol_hooks()
+    {
+        if (skip_on)
+            cugo_k::chol_dbg_skip_end();
+    }
+    void hash(int slot, const double* ptr, size_t n)
+    {
+        // 11 fronts after the assembly, 12 / 13 / 14 W, L21, fronts after the forward pass, 15 x after the backward
+        // pass, 16 + st: W after the potrf launch of stage st, 40 + st: the fronts after its tile launches (a plan
+        // with more than 24 stages keeps the first 24 of each kind: the two ranges must not overlap)
+        if (c.dbg_hash && slot < 64)
+            cugo_k::launch_hash_words(s, ptr, n, c.dbg_hash + slot);
+    }
+    void after_level(int st)
+    {
+        if (hash_levels && st < 24)
+        {
+            hash(16 + st, c.d_winv.data(), (size_t)c.plan.winv_doubles);
+            hash(40 + st, c.d_fronts.data(), (size_t)c.plan.front_doubles);
+        }
+        if (gap)
+            cugo_k::launch_nop(s);
+    }
+    double* stale_for_potrf(int st) const { return stale_kind == 0 && stale_stage == st ? stale_line : nullptr; }
+    void after_two_phase(int st)
+    {
+        if (stale_kind == 0 && stale_stage == st)
+            cugo_k::launch_swap16(s, stale_line, c.dbg_scratch.data());
+    }
+    void after_backward(int st)
+    {
+        if (stale_kind == 1 && (st == stale_stage || st == stale_stage - 1))
+            cugo_k::launch_swap16(s, stale_line, c.dbg_scratch.data()); // (old content for the next level down only)
+    }
+    void keep_arrays(double* d_x)
+    {
+        if (!keep_on || c.dbg_calls > 16)
+            return; // (dbg_calls counts this call already)
+        const cugo_host::CholPlan& plan = c.plan;
+        const size_t nf = (size_t)plan.front_doubles, nw = (size_t)plan.winv_doubles, nl = (size_t)plan.l21_doubles,
+                     nx = (size_t)6 * plan.n;
+        while (c.keep.size() < (size_t)c.dbg_calls)
+            c.keep.emplace_back(new cugo_host::DevBuf<double>());
+        auto& k = *c.keep[c.dbg_calls - 1];
+        k.resize(nf + nw + nl + 2 * nx + 8);
+        double* dst = k.data();
+        const std::pair<const double*, size_t> parts[] = {{c.d_fronts.data(), nf}, {c.d_winv.data(), nw}, {c.d_l21.data(), nl},
+                                                          {c.d_xnew.data(), nx}, {d_x, nx}};
+        for (const auto& pr : parts)
+        {
+            if (pr.second)
+                CUGO_HIP(hipMemcpyAsync(dst, pr.first, pr.second * sizeof(double), hipMemcpyDeviceToDevice, s));
+            dst += pr.second;
+        }
+        g_last_kept = &c;
+    }
+};
+#define CUGO_HOOK(expr) expr
+#else
+cugo_chol::~cugo_chol() {}
+#define CUGO_HOOK(expr) ((void)0)
+#endif
+
+void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d_bsc, double* d_x,
+                             int32_t* d_fail)
+{
+    hipStream_t s = ctx->stream;
+#ifdef CUGO_DEBUG_HOOKS
+    cugo_chol_hooks hooks(*this);
+#endif
+#ifdef CUGO_STAMPS // (make STAMPS=1: in-kernel cycle stamps of the last launch of every kernel, printed by the fifth call)
     static const bool dbg = std::getenv("CUGO_DEBUG_STAMPS") != nullptr;
     static long long* d_stamps = nullptr;
     if (dbg && !d_stamps)
@@ -342,16 +413,11 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
         CUGO_HIP(hipMemset(d_stamps, 0, 64 * sizeof(long long)));
         cugo_k::set_debug_stamps(d_stamps);
     }
+#endif
     cugo_k::launch_chol_assemble(s, dev, d_fronts.data(), (size_t)plan.front_doubles, d_Hsc, lambda, d_bsc, d_fail,
                                  d_wl_ptr + 3L * plan.clr0, plan.nclr, asm_fronts ? d_wl_ptr + 3L * plan.asm0 : nullptr,
                                  plan.nasm);
-    static const bool hash_levels = !(std::getenv("CUGO_DEBUG_HASH_LEVELS") && std::getenv("CUGO_DEBUG_HASH_LEVELS")[0] == '0');
-    static const bool dbg_gap = std::getenv("CUGO_DEBUG_GAP") != nullptr; // diagnosis: an empty kernel after every level
-    auto hash = [&](int slot, const double* ptr, size_t n) {
-        if (dbg_hash && slot < 64)
-            cugo_k::launch_hash_words(s, ptr, n, dbg_hash + slot);
-    };
-    hash(11, d_fronts.data(), (size_t)plan.front_doubles);
+    CUGO_HOOK(hooks.hash(11, d_fronts.data(), (size_t)plan.front_doubles));
     int pend0 = 0, npend = 0, pend_tile = 64; // update tiles of the previous level, not launched yet
     for (int st = 0; st < plan.n_stages; st++)
     {
@@ -371,30 +437,24 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
         }
         else
         {
+            double* stale = nullptr;
+            double* stale_scratch = nullptr;
+            CUGO_HOOK((stale = hooks.stale_for_potrf(st), stale_scratch = dbg_scratch.data()));
             cugo_k::launch_chol_upper_stage(
                 s, dev, d_fronts.data(), t0, t1 - t0, d_wl_ptr, plan.ea_ptr[st],
                 plan.ea_ptr[st + 1] - plan.ea_ptr[st], plan.eab_ptr[st],
                 plan.eab_ptr[st + 1] - plan.eab_ptr[st], plan.syrk_ptr[st],
-                plan.syrk_ptr[st + 1] - plan.syrk_ptr[st], plan.stage_tile[st], lds_factor, d_fail,
-                stale_kind == 0 && stale_stage == st ? stale_line : nullptr, dbg_scratch.data());
+                plan.syrk_ptr[st + 1] - plan.syrk_ptr[st], plan.stage_tile[st], lds_factor, d_fail, stale, stale_scratch);
             if (plan.stage_tile[st] == 0)
             {
                 cugo_k::launch_chol_two_phase(s, dev, d_fronts.data(), d_wl_ptr + 3L * plan.trsm_ptr[st],
                                               plan.trsm_ptr[st + 1] - plan.trsm_ptr[st],
                                               d_wl_ptr + 3L * plan.syrk_ptr[st],
                                               plan.syrk_ptr[st + 1] - plan.syrk_ptr[st]);
-                if (stale_kind == 0 && stale_stage == st)
-                    cugo_k::launch_swap16(s, stale_line, dbg_scratch.data());
+                CUGO_HOOK(hooks.after_two_phase(st));
             }
         }
-        if (hash_levels)
-        { // (CUGO_DEBUG_HASH_LEVELS=0: only the checksums before and behind the loops — those between the levels
-          // separate the launches, and the deviation they are to localise stays away)
-            hash(16 + st, d_winv.data(), (size_t)plan.winv_doubles);
-            hash(40 + st, d_fronts.data(), (size_t)plan.front_doubles);
-        }
-        if (dbg_gap)
-            cugo_k::launch_nop(s);
+        CUGO_HOOK(hooks.after_level(st));
         // update blocks that cross the ownership boundary: the subtree roots of this level whose parent is
         // replicated go from their owner to every rank (columns 6 ncb .. of the front: one contiguous range)
         bool grouped = false;
@@ -416,9 +476,9 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
     }
     if (npend > 0) // the last level's tiles (the rhs rows of the roots)
         cugo_k::launch_chol_potrf_la(s, dev, d_fronts.data(), 0, 0, d_wl_ptr + 3L * pend0, npend, pend_tile, d_fail);
-    hash(12, d_winv.data(), (size_t)plan.winv_doubles);
-    hash(13, d_l21.data(), (size_t)plan.l21_doubles);
-    hash(14, d_fronts.data(), (size_t)plan.front_doubles);
+    CUGO_HOOK(hooks.hash(12, d_winv.data(), (size_t)plan.winv_doubles));
+    CUGO_HOOK(hooks.hash(13, d_l21.data(), (size_t)plan.l21_doubles));
+    CUGO_HOOK(hooks.hash(14, d_fronts.data(), (size_t)plan.front_doubles));
     for (int st = plan.n_stages - 1; st >= 0; st--)
     {
         const int t0 = plan.stage_task_ptr[st], t1 = plan.stage_task_ptr[st + 1];
@@ -426,16 +486,16 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
         cugo_k::launch_chol_backward_stage(s, dev, d_fronts.data(), t0, t1 - t0, lds_backward, d_xnew.data(),
                                            d_x, d_wl_ptr + 3L * plan.bwg_ptr[st],
                                            plan.bwg_ptr[st + 1] - plan.bwg_ptr[st]);
-        if (stale_kind == 1 && (st == stale_stage || st == stale_stage - 1))
-            cugo_k::launch_swap16(s, stale_line, dbg_scratch.data()); // (old content for the next level down only)
-        const int st_top = st;
-        if (dbg && st_top == plan.n_stages - 1)
+        CUGO_HOOK(hooks.after_backward(st));
+#ifdef CUGO_STAMPS
+        if (dbg && st == plan.n_stages - 1)
         { // keep the top stage's backward stamps (kernel 3) in slots 48.. before stage 0 overwrites them
             CUGO_HIP(hipStreamSynchronize(s));
             CUGO_HIP(hipMemcpy(d_stamps + 48, d_stamps + 24, 8 * sizeof(long long), hipMemcpyDeviceToDevice));
         }
+#endif
     }
-    hash(15, d_xnew.data(), (size_t)6 * plan.n);
+    CUGO_HOOK(hooks.hash(15, d_xnew.data(), (size_t)6 * plan.n));
     if (!plan.xx_lo.empty())
     { // the solution of the other ranks' subtrees, then the un-permutation of the whole vector
         if (bcast_group)
@@ -447,26 +507,8 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
         cugo_k::launch_chol_unpermute(s, dev, d_xnew.data(), d_x);
     }
     CUGO_HIP(hipGetLastError());
-    static const bool keep_on = std::getenv("CUGO_DEBUG_KEEP") != nullptr;
-    if (keep_on && dbg_calls <= 16)
-    { // (dbg_calls counts this call already)
-        const size_t nf = (size_t)plan.front_doubles, nw = (size_t)plan.winv_doubles, nl = (size_t)plan.l21_doubles,
-                     nx = (size_t)6 * plan.n;
-        while (keep.size() < (size_t)dbg_calls)
-            keep.emplace_back(new cugo_host::DevBuf<double>());
-        auto& k = *keep[dbg_calls - 1];
-        k.resize(nf + nw + nl + 2 * nx + 8);
-        double* dst = k.data();
-        const std::pair<const double*, size_t> parts[] = {{d_fronts.data(), nf}, {d_winv.data(), nw}, {d_l21.data(), nl},
-                                                          {d_xnew.data(), nx}, {d_x, nx}};
-        for (const auto& pr : parts)
-        {
-            if (pr.second)
-                CUGO_HIP(hipMemcpyAsync(dst, pr.first, pr.second * sizeof(double), hipMemcpyDeviceToDevice, s));
-            dst += pr.second;
-        }
-        g_last_kept = this;
-    }
+    CUGO_HOOK(hooks.keep_arrays(d_x));
+#ifdef CUGO_STAMPS
     if (dbg)
     {
         long long h[64];
@@ -483,4 +525,5 @@ void cugo_chol::factor_solve(const double* d_Hsc, double lambda, const double* d
                 std::printf("  (cycles since kernel start; last launch of the kernel)\n");
             }
     }
+#endif
 }

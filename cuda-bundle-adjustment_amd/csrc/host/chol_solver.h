@@ -2,6 +2,7 @@
 #include "../kernels/kernels.h"
 #include "chol_symbolic.h"
 #include "hip_util.h"
+#include "options.h"
 
 #include <array>
 #include <functional>
@@ -12,6 +13,7 @@ struct cugo_chol
 {
     cugo_ctx* ctx = nullptr;
     bool analyzed = false;
+    cugo_host::Options opt = cugo_host::Options::from_env(); // the environment switches, read once when the solver is created
     cugo_host::CholPlan plan;
     std::vector<int32_t> trans32; // blk_trans widened for cugo_chol_plan_array
     std::vector<int32_t> asm_info; // (cugo_chol_plan_array)
@@ -39,6 +41,8 @@ struct cugo_chol
     int rank = 0, world = 1;
     std::function<void(double*, size_t, int)> bcast;
     std::function<void(bool)> bcast_group; // brackets the broadcasts that may be fused into one operation
+    ~cugo_chol();
+#ifdef CUGO_DEBUG_HOOKS // ---- diagnosis, only in libcugo_hip_hooks.so (make HOOKS=1) ----
     // diagnosis (CUGO_DEBUG_HASH): 64 checksum slots of the factorisation being queued, or null —
     // 11 fronts after the assembly, 12 / 13 / 14 W, L21, fronts after the forward pass, 15 x after the backward pass,
     // 16 + st: W after the potrf launch of stage st, 40 + st: the fronts after the tile launches of stage st
@@ -51,6 +55,7 @@ struct cugo_chol
     cugo_host::DevBuf<double> dbg_scratch; // (CUGO_DEBUG_STALE: the other version of the line under test)
     void dump_kept(const char* dir);
     void dump_slot(int call, const char* path);
+#endif
     bool own_subtrees() const { return world > 1 && bcast && !plan.owner.empty(); }
 
     void analyze(int n, const int32_t* rowptr, const int32_t* colind);
@@ -61,7 +66,9 @@ struct cugo_chol
                       int32_t* d_fail);
 };
 
+#ifdef CUGO_DEBUG_HOOKS
 // diagnosis: writes the CUGO_DEBUG_KEEP slots of the solver that ran last to dir/call<k>.bin; returns their number
 int cugo_debug_dump_last_solver(const char* dir);
 cugo_chol* cugo_debug_solver(int which); // 0: the solver that ran last with CUGO_DEBUG_KEEP, 1: the pinned one
 void cugo_debug_pin_reference_solver();
+#endif

@@ -752,10 +752,10 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
         max_lvl = std::max(max_lvl, l);
     }
     // ---- 7a. ownership of elimination subtrees (world > 1): proportional mapping ------------------
-    P.owner.assign(ns, opt.world > 1 ? -1 : 0);
+    P.owner.assign(ns, opt.owned ? -1 : 0);
     P.xu_front.clear(), P.xu_stage.clear(), P.xu_owner.clear();
     P.xx_lo.clear(), P.xx_hi.clear(), P.xx_owner.clear();
-    if (opt.world > 1)
+    if (opt.owned)
     {
         // Candidates = subtrees that will go to one rank each; start from the roots of the forest.  While
         // the heaviest candidate is more than half of a rank's fair share, it is replaced by its children
@@ -863,7 +863,7 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
             P.stage_task_ptr.push_back((int)P.task_ptr.size() - 1);
     }
     P.n_stages = (int)P.stage_task_ptr.size() - 1;
-    if (opt.world > 1)
+    if (opt.owned)
     {
         for (int s = 0; s < ns; s++)
             if (P.owner[s] >= 0 && P.sparent[s] >= 0 && P.owner[P.sparent[s]] < 0)

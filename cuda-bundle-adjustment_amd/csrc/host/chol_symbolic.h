@@ -29,6 +29,9 @@ struct CholOptions
     // landmark-sharded run (one process per GPU): this rank's schedule holds the fronts of the elimination
     // subtrees it OWNS plus the replicated top of the tree (CholPlan::owner); world == 1: everything
     int rank = 0, world = 1;
+    // the rank-owned form (ownership, update-block and solution-range broadcasts) — normally world > 1; it can be
+    // forced for world == 1 (everything below the top belongs to rank 0): the one-GPU rehearsal of the form
+    bool owned = false;
     static CholOptions from_env();
 };
 

@@ -86,7 +86,9 @@ void* cache_alloc(size_t bytes, bool pinned, size_t* got_bytes)
     }
     void* p = nullptr;
     if (pinned)
-        CUGO_HIP(hipHostMalloc(&p, cls, hipHostMallocDefault));
+        // coherent (fine-grained) on purpose, whatever HIP_HOST_COHERENT says: the host polls words of these blocks
+        // that a kernel writes with a system-scope release (Engine::optimize, the trial's sequence number)
+        CUGO_HIP(hipHostMalloc(&p, cls, hipHostMallocCoherent));
     else
         CUGO_HIP(hipMalloc(&p, cls));
     {

@@ -18,6 +18,7 @@
 #include "../kernels/kernels.h"
 #include "chol_solver.h"
 #include "hip_util.h"
+#include "options.h"
 #include "rccl_comm.h"
 #include "schur_plan.h"
 #include "structure_gpu.h"
@@ -28,6 +29,14 @@ namespace cugo_host
 
 namespace
 {
+inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#endif
+}
 thread_local std::string g_last_error;
 using Clock = std::chrono::steady_clock;
 double ms_since(Clock::time_point t0)
@@ -69,6 +78,7 @@ struct Engine::Impl : cugo_k::LaunchHook
     int xchg_calls = 0;
     bool profile = false;
     bool plan_only = false; // host side only (no device): see Engine::Engine
+    Options opt = Options::from_env(); // the environment switches, read once when the optimiser is created
 
     int Pall = 0, Lall = 0, P = 0, L = 0, E = 0;
     int shard_l0 = 0, shard_l1 = 0; // landmark index range owned by this rank
@@ -248,6 +258,7 @@ struct Engine::Impl : cugo_k::LaunchHook
     // top of the tree (chol_symbolic: CholPlan::owner) and gets what crosses the boundary by broadcast
     void bind_solver_exchange()
     {
+        join_pattern(); // (the helper's analyze_host() reads chol.rank / world / bcast)
         chol.rank = rank, chol.world = world;
         if (world > 1)
         {
@@ -312,7 +323,7 @@ Engine::Engine(bool plan_only) : impl_(new Impl)
     impl_->ctx.device = dev;
     impl_->ctx.stream = cache_stream_acquire();
     impl_->chol.ctx = &impl_->ctx;
-    impl_->profile = std::getenv("CUGO_PROFILE") != nullptr;
+    impl_->profile = impl_->opt.profile;
 }
 
 Engine::~Engine()
@@ -335,6 +346,8 @@ Engine::~Engine()
             cache_stream_release(s2);
     }
 }
+
+Options& Engine::options() { return impl_->opt; }
 
 void Engine::set_kernel_timing(bool on)
 {
@@ -378,7 +391,8 @@ static constexpr unsigned kMaxHostThreads = 16;
 // CUGO_INIT_TIMING=1: per-section host times of initialize() on stderr (diagnosis only)
 struct InitLaps
 {
-    bool on = std::getenv("CUGO_INIT_TIMING") != nullptr;
+    bool on;
+    explicit InitLaps(bool enabled) : on(enabled) {}
     Clock::time_point t = Clock::now();
     void lap(const char* what)
     {
@@ -403,8 +417,11 @@ FlatGraph& Engine::staging()
 void Engine::initialize(FlatGraph& g)
 {
     const auto t0 = Clock::now();
-    InitLaps laps;
     Impl& m = *impl_;
+    InitLaps laps(m.opt.init_timing);
+    // the helper thread of the previous initialize() reads m.P / m.L, the co-visibility lists and the solver's
+    // (rank, world): nothing below may change them while it runs
+    m.join_pattern();
     hipStream_t s = m.ctx.stream;
     m.Pall = g.Pall, m.Lall = g.Lall, m.P = g.P, m.L = g.L;
     m.rk = g.rk;
@@ -572,15 +589,14 @@ void Engine::initialize(FlatGraph& g)
         auto same = [](const auto& a, const auto& b) {
             return a.size() == b.size() && (a.empty() || std::memcmp(a.data(), b.data(), a.size() * sizeof(a[0])) == 0);
         };
-        const bool pat_same = !m.pattern_dirty && !std::getenv("CUGO_NO_STRUCTURE_REUSE") && m.P == m.pat_P &&
+        const bool pat_same = !m.pattern_dirty && m.opt.structure_reuse && m.P == m.pat_P &&
                               m.L == m.pat_L && same(m.cov_ptr, m.pat_cov_ptr) && same(m.cov_pose, m.pat_cov_pose);
         m.pat_async_ok = false;
         if (!pat_same)
         {
             m.pattern_dirty = true;
-            const char* env = std::getenv("CUGO_ASYNC_STRUCTURE");
-            const bool device_build = !m.plan_only && !std::getenv("CUGO_SCHUR_PLAN") && !std::getenv("CUGO_HOST_STRUCTURE");
-            if (device_build && !(env && env[0] == '0') && m.P > 0 && !m.cov_pose.empty())
+            const bool device_build = !m.plan_only && !m.opt.schur_plan && !m.opt.host_structure;
+            if (device_build && m.opt.async_structure && m.P > 0 && !m.cov_pose.empty())
             {
                 if (!m.s2)
                     m.s2 = cache_stream_acquire();
@@ -728,16 +744,21 @@ void Engine::initialize(FlatGraph& g)
     // ---- upload of the slot arrays and the estimates: copies from pageable memory block their caller, so a
     // helper thread issues them while this one builds the pose-major view and hashes the topology (a plan-only
     // engine has no device: it skips to the topology signature)
+    std::exception_ptr up_err; // (declared before the Joiner: the thread may still assign to it while unwinding)
     struct Joiner
     {
         std::thread t;
+        hipStream_t s = nullptr;
+        bool wait_stream = false;
         ~Joiner()
         {
             if (t.joinable())
                 t.join();
+            if (wait_stream && s) // unwinding: the staging vectors of the copies in flight are about to go
+                (void)hipStreamSynchronize(s);
         }
     } uploader;
-    std::exception_ptr up_err;
+    uploader.s = s, uploader.wait_stream = !m.plan_only;
     if (!m.plan_only)
     {
         m.d_e_pose.resize(m.h_e_pose.size()), m.d_e_lm.resize(m.h_e_lm.size()), m.d_flags.resize(m.h_flags.size());
@@ -767,8 +788,7 @@ void Engine::initialize(FlatGraph& g)
                 up_err = std::current_exception();
             }
         };
-        const char* env = std::getenv("CUGO_UPLOAD_THREAD"); // 0: the copies are issued by this thread
-        if (env && env[0] == '0')
+        if (!m.opt.upload_thread) // (CUGO_UPLOAD_THREAD=0: the copies are issued by this thread)
         {
             uploads();
             if (up_err)
@@ -823,8 +843,7 @@ void Engine::initialize(FlatGraph& g)
     m.d_Hll.resize(9 * (size_t)m.L + 16), m.d_invHll.resize(9 * (size_t)m.L + 16);
     {
         // block streams: 18 doubles per edge slot, or 18 floats (= 9 doubles of storage)
-        const char* env = std::getenv("CUGO_FLOAT32");
-        m.ev.block_f32 = (m.f32_blocks || (env && env[0] == '1')) ? 1 : 0;
+        m.ev.block_f32 = (m.f32_blocks || m.opt.float32) ? 1 : 0;
         const size_t per_edge = m.ev.block_f32 ? 9 : 18;
         m.d_Hpl.resize(per_edge * (size_t)E + 16);
         m.d_T.release(); // allocated on demand (gather kernels only), see optimize()
@@ -847,6 +866,7 @@ void Engine::initialize(FlatGraph& g)
         if (up_err)
             std::rethrow_exception(up_err);
         CUGO_HIP(hipStreamSynchronize(s)); // host staging vectors go out of scope
+        uploader.wait_stream = false;
         uploads_done = true;
     };
 
@@ -863,8 +883,7 @@ void Engine::initialize(FlatGraph& g)
         // list-free, but measured slower than the gather pair (355 vs 152 us per Schur complement on the
         // kitti_00 shape): its per-product accumulation into LDS is a chain of dependent LDS round trips
         // 
-        const char* env = std::getenv("CUGO_HSC_ROWS");
-        m.rows_on = !m.plan_only && env && env[0] == '1' && !std::getenv("CUGO_SCHUR_PLAN");
+        m.rows_on = !m.plan_only && m.opt.hsc_rows && !m.opt.schur_plan;
         if (m.rows_on)
         {
             finish_uploads();
@@ -921,7 +940,7 @@ void Engine::initialize(FlatGraph& g)
         const bool hit = h == m.structure_sig && std::memcmp(dims, m.sig_dims, sizeof dims) == 0 &&
                          same(m.h_e_pose, m.sig_e_pose) && same(m.h_e_lm, m.sig_e_lm) &&
                          same(m.h_flags, m.sig_flags) && same(m.cov_pose, m.sig_cov_pose);
-        if (!hit || std::getenv("CUGO_NO_STRUCTURE_REUSE"))
+        if (!hit || !m.opt.structure_reuse)
             m.structure_dirty = true;
         m.structure_sig = h;
         std::memcpy(m.pending_dims, dims, sizeof dims);
@@ -959,9 +978,8 @@ void Engine::fill_structure_stats(int B, double products, double offdiag_product
     // measured 13.69 vs 11.45 ms per step (kitti_00 shape), 59.6 vs 41.2 ms (10k-pose graph)
     m.strip_on = false;
     {
-        const char* env = std::getenv("CUGO_HSC_STRIP");
         const size_t M = (size_t)offdiag_products;
-        if (!m.plan_only && !m.splan_on && m.hs.d_off_ei && M > 0 && env && env[0] == '1')
+        if (!m.plan_only && !m.splan_on && m.hs.d_off_ei && M > 0 && m.opt.hsc_strip)
         {
             m.d_pose_pos.resize((size_t)std::max(m.E, 1) + 16), m.d_off_pi.resize(M + 16);
             cugo_k::launch_list_pos(m.ctx.stream, m.ev, m.h_pose_ptr[m.Pall], M, m.hs.d_off_ei, m.d_pose_pos.data(),
@@ -1038,7 +1056,7 @@ void Engine::build_structure()
 {
     Impl& m = *impl_;
     const auto t0 = Clock::now();
-    InitLaps laps;
+    InitLaps laps(m.opt.init_timing);
     hipStream_t s = m.ctx.stream;
     const int P = m.P, L = m.L;
     // ---- device-side build: pairs per landmark -> stable radix sort by pose pair -> runs = off-diagonal
@@ -1052,7 +1070,7 @@ void Engine::build_structure()
         m.pat_err = nullptr;
         std::rethrow_exception(e);
     }
-    if (!m.plan_only && (m.E > 0 || shard) && !std::getenv("CUGO_SCHUR_PLAN") && !std::getenv("CUGO_HOST_STRUCTURE") &&
+    if (!m.plan_only && (m.E > 0 || shard) && !m.opt.schur_plan && !m.opt.host_structure &&
         P > 0 && !m.cov_pose.empty())
     {
         // phase 1 (unless the helper thread of initialize() has done it, or the lists are those of the
@@ -1209,7 +1227,7 @@ void Engine::build_structure()
     // product) and the plan costs 4 ms more to build, so the gather kernels stay the default
     // (DESIGN.md section 4b).  Unusable if a landmark's active edges straddle two 256-slot groups.
     SchurPlanHost sp;
-    if (std::getenv("CUGO_SCHUR_PLAN"))
+    if (m.opt.schur_plan)
         build_schur_plan(m.E, P, m.h_e_pose.data(), m.h_e_lm.data(), m.h_flags.data(), m.hsc_rowptr.data(),
                          m.hsc_colind.data(), sp);
     m.splan_on = sp.usable;
@@ -1352,11 +1370,12 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
     // what an accepted trial with rho near 1 gives (ref: cuda_graph_optimisation.cpp:97-99, the lower clamp).
     // Accepted with another lambda: the Schur complement recomputes T (as without the fusion).  Rejected:
     // H is rebuilt from the kept estimates before the retry.  Same arithmetic on the same data in every case.
-    const char* spec_env = std::getenv("CUGO_SPECULATE");
-    const bool speculate = !sharded && !m.profile && !(spec_env && spec_env[0] == '0');
+    const bool speculate = !sharded && !m.profile && m.opt.speculate;
     // diagnosis: CUGO_DEBUG_HASH=<file> — position-weighted integer checksums of the arrays every stage of the
     // first trial of an iteration leaves behind, computed by kernels queued in the same stream (no host
     // synchronisation: the flow of the loop stays what it is), appended to the file when optimize() returns
+    // (hooks build only, make HOOKS=1: the product build has neither the switch nor the checksum kernel)
+#ifdef CUGO_DEBUG_HOOKS
     const char* hash_file = std::getenv("CUGO_DEBUG_HASH");
     if (hash_file)
     {
@@ -1367,10 +1386,11 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
         if (hash_file)
             cugo_k::launch_hash_words(s, p, words, m.d_hash.data() + 64 * (size_t)iteration + slot);
     };
-    const char* tev_env = std::getenv("CUGO_TRIAL_EVENT"); // 0: wait for the whole stream (A/B)
-    const bool trial_event = !(tev_env && tev_env[0] == '0');
-    const char* poll_env = std::getenv("CUGO_TRIAL_POLL"); // 0: wait by event / stream synchronisation
-    const bool trial_poll = !m.profile && !(poll_env && poll_env[0] == '0');
+#else
+    auto hash = [](int, int, const void*, size_t) {};
+#endif
+    const bool trial_event = m.opt.trial_event;                // (CUGO_TRIAL_EVENT=0: wait for the whole stream, A/B)
+    const bool trial_poll = !m.profile && m.opt.trial_poll;    // (CUGO_TRIAL_POLL=0: wait by event / stream synchronisation)
     bool have_build = false;      // the build pass of this iteration is already queued
     double built_lambda = -1.0;   // ... with invHll / T for this damping (< 0: none)
 
@@ -1387,8 +1407,7 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
         const bool use_rows = m.rows_on && cugo_k::schur_rows_usable(m.hs, m.max_row_nnz);
         if (!m.splan_on && !use_rows && m.d_T.size() == 0)
             m.d_T.resize((m.ev.block_f32 ? 9 : 18) * (size_t)m.E + 16);
-        const char* fuse_env = std::getenv("CUGO_FUSE_T");
-        const bool fuse_allowed = !(fuse_env && fuse_env[0] == '0');
+        const bool fuse_allowed = m.opt.fuse_t;
         const bool can_fuse = fuse_allowed && !m.splan_on && m.lm_in_one_group;
         const bool fused_T = have_build ? (can_fuse && built_lambda == lambda) : (can_fuse && iteration > 0);
         if (!have_build)
@@ -1459,8 +1478,9 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
                 cugo_k::launch_schur(s, m.ev, m.hs, lambda, 0, m.d_Hpp.data(), m.bp(),
                                      m.d_Hll.data(), m.bl(), m.d_Hpl.data(), m.d_invHll.data(),
                                      m.splan_on || use_rows ? nullptr : m.d_T.data(), m.bsc(), m.Hsc(), fused_T && q == 0,
-                                     use_rows ? cugo_k::SchurRows{m.d_pose_rec.data(), m.max_row_nnz, nullptr}
-                                              : cugo_k::SchurRows{nullptr, 0, m.strip_on ? m.d_off_pi.data() : nullptr});
+                                     use_rows ? cugo_k::SchurRows{m.d_pose_rec.data(), m.max_row_nnz, nullptr, m.opt.hsc_mfma, m.opt.hsc_xcd}
+                                              : cugo_k::SchurRows{nullptr, 0, m.strip_on ? m.d_off_pi.data() : nullptr,
+                                                                  m.opt.hsc_mfma, m.opt.hsc_xcd});
             });
             if (sharded)
                 m.exchange(m.d_sys.data(), 36 * (size_t)m.hs.n_blocks + 6 * (size_t)m.P, 0);
@@ -1473,11 +1493,15 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
                 hash(iteration, 6, m.d_invHll.data(), 9 * (size_t)m.L);
             }
             auto tn = Clock::now();
+#ifdef CUGO_DEBUG_HOOKS
             m.chol.dbg_hash = hash_file && q == 0 ? m.d_hash.data() + 64 * (size_t)iteration : nullptr;
+#endif
             m.timed("cholesky", [&] {
                 m.chol.factor_solve(m.Hsc(), lambda, m.bsc(), m.xp(), d_fail);
             });
+#ifdef CUGO_DEBUG_HOOKS
             m.chol.dbg_hash = nullptr;
+#endif
             sync_prof(PROF_NUMERIC, tn);
             if (q == 0)
                 hash(iteration, 7, m.xp(), 6 * (size_t)m.P);
@@ -1550,19 +1574,36 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
                 // the pinned block (k_sum_partials2, system-scope release): the host polls that word — no event,
                 // no stream synchronisation, and whatever is queued behind the trial keeps running
                 const volatile double* seq = m.h_scal.data() + 5;
+                const auto w0 = Clock::now();
+                auto next_query = w0 + std::chrono::milliseconds(10);
                 for (unsigned long spin = 1; *seq != (double)m.trial_seq; spin++)
                 {
-                    __builtin_ia32_pause();
-                    if ((spin & 0xFFFFF) == 0)
-                    { // every ~10 ms: a stream that is idle or failed will never deliver
-                        const hipError_t q = hipStreamQuery(s);
-                        if (q != hipErrorNotReady)
-                        {
-                            CUGO_HIP(q);
-                            if (*seq != (double)m.trial_seq)
-                                throw std::runtime_error("cugo: the result of an LM trial never arrived");
-                        }
+                    cpu_relax();
+                    if ((spin & 0x3FF) != 0)
+                        continue;
+                    // a trial of a large graph takes milliseconds: after the first 200 us the core is offered to
+                    // others between polls, and every ~10 ms the stream is asked whether it is still working
+                    const auto now = Clock::now();
+                    if (now - w0 > std::chrono::microseconds(200))
+                        std::this_thread::yield();
+                    if (now < next_query)
+                        continue;
+                    next_query = now + std::chrono::milliseconds(10);
+                    const hipError_t qe = hipStreamQuery(s);
+                    if (qe == hipErrorNotReady)
+                        continue;
+                    CUGO_HIP(qe); // a failed stream will never deliver
+                    // the stream is idle: everything queued has run, so the word is there (give the write a moment to
+                    // become visible to this core before calling it lost)
+                    bool there = false;
+                    for (int k = 0; k < 100000 && !there; k++)
+                    {
+                        std::atomic_thread_fence(std::memory_order_acquire);
+                        there = *seq == (double)m.trial_seq;
+                        cpu_relax();
                     }
+                    if (!there)
+                        throw std::runtime_error("cugo: the result of an LM trial never arrived");
                 }
                 std::atomic_thread_fence(std::memory_order_acquire);
             }
@@ -1623,6 +1664,7 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
         if (q == maxq || rho < 1e-6 || !std::isfinite(lambda))
             break;
     }
+#ifdef CUGO_DEBUG_HOOKS
     if (hash_file)
     {
         std::vector<unsigned long long> h(m.d_hash.size());
@@ -1640,6 +1682,7 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
             std::fclose(fp);
         }
     }
+#endif
     m.collect_times();
 }
 

@@ -13,6 +13,7 @@ namespace cugo_host
 {
 
 class RcclComm;
+struct Options;
 
 // Result of flattening a graph (ref: VertexSet::generateEstimateData + EdgeSet::init,
 // src/optimisable_graph.hpp:84-126,474-572).  Indices: free vertices first.
@@ -81,6 +82,9 @@ public:
     Engine(const Engine&) = delete;
     Engine& operator=(const Engine&) = delete;
 
+    // the run-time switches of this optimiser (options.h): a snapshot of the environment taken when it was
+    // created; cugo_graph_set_option changes single ones afterwards
+    Options& options();
     void set_shard(int rank, int world, cugo_exchange_fn fn, void* user);
     // native exchange: RCCL communicator over the ranks of the job (shared by all optimisers of the
     // process); all-reduces then run on the solver's stream without a host synchronisation

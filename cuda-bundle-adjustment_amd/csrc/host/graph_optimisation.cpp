@@ -11,6 +11,7 @@
 #include <stdexcept>
 
 #include "engine.h"
+#include "options.h"
 #include "thread_pool.h"
 
 namespace cugo
@@ -77,6 +78,21 @@ std::vector<double> CudaGraphOptimisationImpl::structureStats() const
 
 void CudaGraphOptimisationImpl::setKernelTiming(bool on) { engine_->set_kernel_timing(on); }
 
+bool CudaGraphOptimisationImpl::setOption(const char* name, int value)
+{
+    cugo_host::Options& o = engine_->options();
+    const std::string n = name ? name : "";
+    if (n == "flatten_reuse")
+        o.flatten_reuse = value != 0;
+    else if (n == "structure_reuse")
+        o.structure_reuse = value != 0;
+    else if (n == "init_timing")
+        o.init_timing = value != 0;
+    else
+        return false;
+    return true;
+}
+
 void CudaGraphOptimisationImpl::kernelTimes(std::vector<std::string>& names, std::vector<double>& ms,
                                             std::vector<int>& launches) const
 {
@@ -109,7 +125,8 @@ void CudaGraphOptimisationImpl::initialize()
     if (vertexSets.empty() || edgeSets.empty())
         throw std::runtime_error("cugo: initialize() needs at least one vertex set and one edge set");
 
-    const bool timing = std::getenv("CUGO_INIT_TIMING") != nullptr;
+    const cugo_host::Options& eopt = engine_->options();
+    const bool timing = eopt.init_timing;
     auto lap_t = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
         if (!timing)
@@ -129,7 +146,7 @@ void CudaGraphOptimisationImpl::initialize()
     // reference's own sample, main.cpp:168-190 — call initialize() again on an unchanged graph.
     // CUGO_NO_FLATTEN_REUSE=1 turns it off.
     {
-        bool same = flattenValid_ && !std::getenv("CUGO_NO_FLATTEN_REUSE") && !std::getenv("CUGO_NO_STRUCTURE_REUSE") &&
+        bool same = flattenValid_ && eopt.flatten_reuse && eopt.structure_reuse &&
                     flattenOptions_[0] == options.perEdgeInformation && flattenOptions_[1] == options.perEdgeCamera &&
                     flattenOptions_[2] == options.useFloat32 &&
                     flattenCounts_.size() == vertexSets.size() + edgeSets.size();
@@ -401,7 +418,7 @@ void CudaGraphOptimisationImpl::initialize()
 
 void CudaGraphOptimisationImpl::optimize(int niterations)
 {
-    const bool timing = std::getenv("CUGO_INIT_TIMING") != nullptr;
+    const bool timing = engine_->options().init_timing;
     auto lap_t = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
         if (!timing)

@@ -4,6 +4,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+
+#include "options.h"
 #include <type_traits>
 
 #include <cstdio>
@@ -183,4 +185,5 @@ struct cugo_ctx
     int device = 0;
     hipStream_t stream = nullptr;
     cugo_host::DevBuf<double> scratch; // reduction partials
+    cugo_host::Options opt = cugo_host::Options::from_env(); // the environment switches, read once at cugo_ctx_create
 };

@@ -2252,14 +2252,6 @@ void launch_max_diagonal(hipStream_t s, const double* d_Hpp, int nP, const doubl
     CUGO_LAUNCH(k_max_partials, dim3(1), dim3(BS), 0, s, rs.d_partials, nb, d_out);
 }
 
-// CUGO_HSC_MFMA=0: the off-diagonal blocks of Hsc on the vector lanes (k_hsc_offdiag) instead of the matrix cores
-// (2: only the off-diagonal kernel)
-static int hsc_mfma()
-{
-    const char* e = std::getenv("CUGO_HSC_MFMA"); // (read per call: the A/B tool switches it inside one process)
-    return !e ? 1 : e[0] == '0' ? 0 : e[0] == '2' ? 2 : 1;
-}
-
 template <typename S>
 static void launch_schur_t(hipStream_t s, const cugo_edges& e, const cugo_hsc_struct& hs, double lambda,
                            int damp_hsc_diag, const double* d_Hpp, const double* d_bp, const double* d_Hll,
@@ -2317,15 +2309,14 @@ static void launch_schur_t(hipStream_t s, const cugo_edges& e, const cugo_hsc_st
         CUGO_LAUNCH_T(k_hsc_offdiag_strip, S, dim3(xcd_grid(ev.P)), dim3(HS_BS), hs_lds_bytes(), s, ev, hs.d_rowptr,
                       hs.d_off_ptr, hs.d_off_ei, rows.d_off_pi, hs.d_off_ej, d_Hpl, (const S*)d_T, d_Hsc);
     }
-    else if (hs.n_blocks > 0 && hsc_mfma())
-    {
+    else if (hs.n_blocks > 0 && rows.mfma)
+    { // (rows.mfma == 0, CUGO_HSC_MFMA=0: the vector-lane kernels below; 2: only the off-diagonal kernel here)
         // a contiguous range of blocks per XCD (CUGO_HSC_XCD=0: dispatch order).  In-process A/B: 39.35 vs 41.80 ms
         // per step on the 10k-pose graph, 11.38 vs 11.36 ms on the kitti_00 shape — with the LDS port out of the
         // way the kernel is bound by its L2 misses, and rows that share T operands now meet in one L2 (the
         // vector-lane kernel, bound by LDS reads, was slower with this mapping: 123 vs 112 us)
-        const char* ex = std::getenv("CUGO_HSC_XCD");
         ::cugo_k::LaunchScope _scope("k_hsc_offdiag_mfma", s);
-        if (!(ex && ex[0] == '0'))
+        if (rows.xcd)
             hipLaunchKernelGGL((k_hsc_offdiag_mfma<S, true>), dim3(xcd_grid(div_up(hs.n_blocks, BS / 64))), dim3(BS), 0, s,
                                hs.n_blocks, hs.d_off_ptr, hs.d_off_ei, hs.d_off_ej, d_Hpl, (const S*)d_T, d_Hsc);
         else
@@ -2335,7 +2326,7 @@ static void launch_schur_t(hipStream_t s, const cugo_edges& e, const cugo_hsc_st
     else if (hs.n_blocks > 0)
         CUGO_LAUNCH_T(k_hsc_offdiag, S, dim3(div_up(hs.n_blocks, BS / 64)), dim3(BS), 0, s,
                       hs.n_blocks, hs.d_off_ptr, hs.d_off_ei, hs.d_off_ej, d_Hpl, (const S*)d_T, d_Hsc);
-    if (ev.P > 0 && hsc_mfma() == 1)
+    if (ev.P > 0 && rows.mfma == 1)
         CUGO_LAUNCH_T(k_hsc_diag_mfma, S, dim3(xcd_grid(ev.P)), dim3(HM_BS), 0, s, ev,
                       hs.d_rowptr, damp_hsc_diag ? lambda : 0.0, d_Hpp, d_bp, d_bl, d_Hpl, (const S*)d_T,
                       d_Hsc, d_bsc);

@@ -786,12 +786,42 @@ __device__ __forceinline__ int opaque_lane()
 
 // diagnosis (CUGO_DEBUG_DELAY=n): chosen waves / workgroups of k_up_potrf sleep ~25 k cycles at chosen points.  A
 // kernel without a race gives the same bits whatever runs late.
+// Only in the hooks build (make HOOKS=1): in the product build DBG_DELAY is the constant 0 and every pattern folds away.
+#ifdef CUGO_DEBUG_HOOKS
+#define DBG_DELAY(p) ((p).dbg_delay)
+#else
+#define DBG_DELAY(p) 0
+#endif
 __device__ __forceinline__ void dbg_sleep()
 {
 #pragma unroll 1
     for (int i = 0; i < 3; i++)
         __builtin_amdgcn_s_sleep(127);
 }
+// The other kernels of the factorisation — trsm / syrk / fused tiles / backward substitution — hand over between their
+// phases through barriers only.  CUGO_DEBUG_DELAY=10..14 (hooks build) puts chosen waves to sleep BEHIND EVERY ONE of
+// those barriers (10: odd waves, 11: even waves, 12: waves 2 3 6 7 ..., 13: wave 0 alone, 14: all but wave 0): a
+// hand-over that relies on two waves leaving a barrier at about the same time gives other bits under one of them.
+#ifdef CUGO_DEBUG_HOOKS
+__device__ int g_dbg_tile_delay = 0; // (set by the launch functions from CholPlanDev::dbg_delay)
+__device__ __forceinline__ void dbg_tile_delay()
+{
+    const int d = g_dbg_tile_delay;
+    if (d < 10)
+        return;
+    const int w = (int)(threadIdx.x >> 6);
+    if ((d == 10 && (w & 1)) || (d == 11 && !(w & 1)) || (d == 12 && (w & 2)) || (d == 13 && w == 0) || (d == 14 && w != 0))
+        dbg_sleep();
+}
+#define TILE_SYNC()        \
+    do                     \
+    {                      \
+        __syncthreads();   \
+        dbg_tile_delay();  \
+    } while (0)
+#else
+#define TILE_SYNC() __syncthreads()
+#endif
 
 __device__ __forceinline__ void stamp_wave(int kernel, int slot)
 {
@@ -1412,7 +1442,7 @@ __device__ __forceinline__ void dev_trsm_w(double* __restrict__ F, long ld, int 
                 Bt[k * PSTB + r] = v[u];
         }
     }
-    __syncthreads();
+    TILE_SYNC();
     stamp(1, 3);
     double4_t acc = {0, 0, 0, 0};
 #pragma unroll
@@ -1449,7 +1479,7 @@ __device__ __forceinline__ void dev_trsm_w(double* __restrict__ F, long ld, int 
         }
     }
     stamp(1, 4);
-    __syncthreads();
+    TILE_SYNC();
 }
 
 // U(ti,tj) -= L21(ti rows) L21(tj rows)^T, 64x64 tiles on the f64 matrix cores.  The whole
@@ -1539,7 +1569,7 @@ __device__ __forceinline__ void dev_syrk_tiles(double* __restrict__ F, long ld, 
                     }
                 }
             }
-            __syncthreads();
+            TILE_SYNC();
             {
                 const double* Pa = diag ? Pi : Pj;
                 for (int k0 = 0; k0 < kn; k0 += 4)
@@ -1551,7 +1581,7 @@ __device__ __forceinline__ void dev_syrk_tiles(double* __restrict__ F, long ld, 
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(kok ? a : 0.0, b, acc, 0, 0, 0);
                 }
             }
-            __syncthreads();
+            TILE_SYNC();
         }
         stamp(4, 3);
 #pragma unroll
@@ -1684,7 +1714,7 @@ __device__ __forceinline__ void dev_trsyrk_tile(double* __restrict__ F, long ld,
             if (wdst[u] >= 0)
                 Wl[wdst[u]] = wv[u];
         stamp(4, 2);
-        __syncthreads();
+        TILE_SYNC();
         stamp(4, 3);
         // ---- X = B W^T for this wave's row group and column blocks (both panels)
         double4_t xi[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, xj[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -1714,7 +1744,7 @@ __device__ __forceinline__ void dev_trsyrk_tile(double* __restrict__ F, long ld,
             }
         }
         stamp(4, 4);
-        __syncthreads(); // every wave has read B: the panels may be overwritten with X
+        TILE_SYNC(); // every wave has read B: the panels may be overwritten with X
 #pragma unroll
         for (int h = 0; h < 2; h++)
         {
@@ -1736,7 +1766,7 @@ __device__ __forceinline__ void dev_trsyrk_tile(double* __restrict__ F, long ld,
                 }
             }
         }
-        __syncthreads();
+        TILE_SYNC();
         stamp(4, 5);
         if (!solo)
         { // ---- U(ti,tj) -= X_i X_j^T, one 16x16 sub-tile per wave
@@ -1882,7 +1912,7 @@ __device__ __forceinline__ void dev_trsyrk_tile32(double* __restrict__ F, long l
     for (int u = 0; u < 6; u++)
         if (wdst[u] >= 0)
             Wl[wdst[u]] = wv[u];
-    __syncthreads();
+    TILE_SYNC();
     // ---- X = B W^T for this wave's row group and column block (both panels)
     double4_t xi = {0, 0, 0, 0}, xj = {0, 0, 0, 0};
     if (cb >= 0)
@@ -1901,7 +1931,7 @@ __device__ __forceinline__ void dev_trsyrk_tile32(double* __restrict__ F, long l
             }
         }
     }
-    __syncthreads(); // every wave has read B: the panels may be overwritten with X
+    TILE_SYNC(); // every wave has read B: the panels may be overwritten with X
     if (cb >= 0)
     {
         const int row = 32 * ti + 16 * rg + ln;
@@ -1916,7 +1946,7 @@ __device__ __forceinline__ void dev_trsyrk_tile32(double* __restrict__ F, long l
                 L21[(long)c * ld2 + row] = xi[q];
         }
     }
-    __syncthreads();
+    TILE_SYNC();
     if (!solo && w < 4)
     { // ---- U(ti,tj) -= X_i X_j^T, one 16x16 sub-tile per wave
         const double* Pa = diag ? Pi : Pj;
@@ -2031,7 +2061,7 @@ __device__ __forceinline__ void dev_backward(const CholPlanDev& p, const double*
     }
     for (int jj = ncs + threadIdx.x; jj < ncp; jj += blockDim.x)
         vs[jj] = 0.0;
-    __syncthreads();
+    TILE_SYNC();
     stamp(3, 2);
     // v_j = y_j - sum_i L21[i,j] x_R[i]
     {
@@ -2064,7 +2094,7 @@ __device__ __forceinline__ void dev_backward(const CholPlanDev& p, const double*
         if (l8 == 0 && colok)
             vs[j] = y - s;
     }
-    __syncthreads();
+    TILE_SYNC();
     stamp(3, 3);
     // x_j = sum_k W[k][j] v_k over k >= 16*floor(j/16) (W lower triangular, zeros above the
     // diagonal inside the diagonal block); Wg is column-major, so the sum runs along a column
@@ -2087,7 +2117,7 @@ __device__ __forceinline__ void dev_backward(const CholPlanDev& p, const double*
     }
     stamp(3, 4);
     __threadfence_block();
-    __syncthreads();
+    TILE_SYNC();
 }
 
 constexpr int BIG = 1024; // workgroup size of the latency-critical single-front kernels
@@ -2198,7 +2228,7 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
     if ((int)blockIdx.x >= npotrf)
     { // items of the pivot columns first, then of the boundary columns
         const int b = blockIdx.x - npotrf;
-        if (p.dbg_delay == 6)
+        if (DBG_DELAY(p) == 6)
             dbg_sleep();
         const int32_t* it = b < neap ? wl_eap + 3 * b : wl_eab + 3 * (b - neap);
         dev_extend_add(p, fronts, it[0], it[1], it[2], 2); // everything below the parents' F11
@@ -2206,7 +2236,7 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
         return;
     }
     stamp(0, 0);
-    if (p.dbg_delay == 5)
+    if (DBG_DELAY(p) == 5)
         dbg_sleep();
     dbg_fill_lds(p, lds);
     // the front's scalars from the task's 64-byte record (one scalar load instead of task -> front -> arrays)
@@ -2247,7 +2277,7 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
     }
     if (p.panel16)
     { // 16-column L D L^T panels, W built behind them (dev_potrf16)
-        dev_potrf16(ncp, lds, p.winv + fwoff, fail, mirror_now, p.dbg_delay);
+        dev_potrf16(ncp, lds, p.winv + fwoff, fail, mirror_now, DBG_DELAY(p));
         stamp_value(0, 6, ncs);
         stamp(0, 7);
         kernel_release(p);
@@ -2465,7 +2495,7 @@ __device__ __forceinline__ void dev_backward_ahead(const CholPlanDev& p, const i
         const int ib = i / 6;
         xr[i] = xnew[6L * rows[ib] + (i - 6 * ib)];
     }
-    __syncthreads();
+    TILE_SYNC();
     const int j = j0 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (j < ncs)
     {
@@ -2538,6 +2568,7 @@ __global__ void k_flag_to_double(int32_t* __restrict__ flag)
     *reinterpret_cast<double*>(flag) = v ? 1.0 : 0.0;
 }
 
+#ifdef CUGO_DEBUG_HOOKS
 // Fault injection (diagnosis; CUGO_DEBUG_SKIP=call:launch:workgroup, read by the solver): ONE
 // workgroup of ONE launch of one factorisation returns at once, so everything it would have written keeps the value
 // the previous factorisation left there — the supposed failure, made on purpose, to compare its results with the
@@ -2553,6 +2584,12 @@ static inline CholPlanDev with_lds(const CholPlanDev& p, size_t lds_bytes, const
     CholPlanDev q = p;
     q.lds_doubles = (int)(lds_bytes / sizeof(double));
     q.dbg_skip_wg = -1;
+    static int tile_delay_on_device = 0;
+    if (p.dbg_delay != tile_delay_on_device)
+    { // (a blocking copy: diagnosis only)
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_tile_delay), &p.dbg_delay, sizeof(int));
+        tile_delay_on_device = p.dbg_delay;
+    }
     if (g_skip.dump || g_skip.target_launch >= 0)
     {
         if (g_skip.dump)
@@ -2563,6 +2600,10 @@ static inline CholPlanDev with_lds(const CholPlanDev& p, size_t lds_bytes, const
     }
     return q;
 }
+#else
+// (product build: the plan goes to the kernels as it is — no per-launch copy, no hooks)
+static inline const CholPlanDev& with_lds(const CholPlanDev& p, size_t, const char*, int, int = 0) { return p; }
+#endif
 void ensure_lds(const void* fn, size_t bytes)
 {
     if (bytes > 48 * 1024)
@@ -2573,6 +2614,7 @@ void ensure_lds(const void* fn, size_t bytes)
 
 namespace cugo_k
 {
+#ifdef CUGO_DEBUG_HOOKS
 void chol_dbg_skip_begin(int target_launch, int target_wg, const char* dump_path)
 {
     if (g_skip.dump)
@@ -2587,6 +2629,7 @@ void chol_dbg_skip_end()
         std::fclose(g_skip.dump), g_skip.dump = nullptr;
     g_skip.target_launch = -1;
 }
+#endif
 
 size_t chol_lds_factor_bytes(int nc_max)
 { // subtree / potrf kernels: L11 + dinv + inverted diagonal blocks + one trsm B tile, or the syrk panels
@@ -2676,8 +2719,12 @@ void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fron
     ensure_lds(reinterpret_cast<const void*>(k_up_potrf), chol_lds_potrf_bytes());
     CUGO_LAUNCH(k_up_potrf, dim3(ntasks + neap + nea), dim3(BIG), chol_lds_potrf_bytes(), s, with_lds(p, chol_lds_potrf_bytes(), "k_up_potrf", ntasks + neap + nea, ntasks), d_fronts,
                 task0, ntasks, d_wl + 3L * eap0, neap, d_wl + 3L * ea0, d_fail);
+#ifdef CUGO_DEBUG_HOOKS
     if (dbg_line) // (CUGO_DEBUG_STALE: the tile launch sees the line as it was before this potrf launch ...
         launch_swap16(s, dbg_line, dbg_scratch);
+#else
+    (void)dbg_line, (void)dbg_scratch;
+#endif
     if (tile == 0)
         return; // two-phase level: the caller queues launch_chol_two_phase
     if (nsy > 0 && tile == 32)
@@ -2692,8 +2739,10 @@ void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fron
         CUGO_LAUNCH(k_up_trsyrk, dim3(nsy), dim3(BIG), trsyrk_lds() * sizeof(double), s,
                     with_lds(p, trsyrk_lds() * sizeof(double), "k_up_trsyrk", nsy), d_fronts, d_wl + 3L * sy0);
     }
+#ifdef CUGO_DEBUG_HOOKS
     if (dbg_line) // ... and everything later sees what the potrf launch wrote)
         launch_swap16(s, dbg_line, dbg_scratch);
+#endif
 }
 
 void launch_chol_potrf_la(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0, int ntasks,
@@ -2719,6 +2768,7 @@ void launch_chol_lead(hipStream_t s, const CholPlanDev& p, double* d_fronts, con
                 d_fronts, d_lead, nlead, d_eap, neap, d_eab);
 }
 
+#ifdef CUGO_DEBUG_HOOKS // diagnosis kernels: only in libcugo_hip_hooks.so
 __global__ __launch_bounds__(256) void k_hash_words(const unsigned long long* __restrict__ p, size_t n,
                                                     unsigned long long* __restrict__ out)
 {
@@ -2742,6 +2792,7 @@ void launch_hash_words(hipStream_t s, const void* p, size_t n_words, unsigned lo
     const int nb = (int)std::min<size_t>(512, (n_words + 255) / 256);
     hipLaunchKernelGGL(k_hash_words, dim3(nb), dim3(256), 0, s, static_cast<const unsigned long long*>(p), n_words, out);
 }
+#endif
 void launch_flag_to_double(hipStream_t s, int32_t* d_flag) { CUGO_LAUNCH(k_flag_to_double, dim3(1), dim3(1), 0, s, d_flag); }
 
 void launch_chol_unpermute(hipStream_t s, const CholPlanDev& p, const double* d_xnew, double* d_x)

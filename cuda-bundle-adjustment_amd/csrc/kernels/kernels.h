@@ -78,6 +78,11 @@ struct SchurRows
     // the edge list of its pose (launch_list_pos).  Given, the off-diagonal blocks are formed one block row per
     // workgroup with the row's T blocks staged in LDS once; same sums, bit for bit
     const int32_t* d_off_pi = nullptr;
+    // which form of the H-side gather kernels (Options::hsc_mfma / hsc_xcd, read once per context / optimiser):
+    // 1 both on the matrix cores, 2 only the off-diagonal one, 0 the vector-lane kernels; blocks dealt to the XCDs
+    // in contiguous ranges or in dispatch order
+    int mfma = 1;
+    bool xcd = true;
 };
 // d_pose_pos [n_edges] scratch/out: position of every slot in its pose's list; d_off_pi [M] out
 void launch_list_pos(hipStream_t s, const cugo_edges& ev, int n_list, size_t M, const int32_t* d_off_ei,
@@ -137,11 +142,13 @@ struct CholPlanDev
     int nc_max;                // widest pivot block (scalars)
     int ea_lds;                // potrf: children's contributions to F11 go straight into its LDS copy
     int panel16;               // potrf: 16-column register panels (CUGO_PANEL16=0: the 6-column LDS panels)
+#ifdef CUGO_DEBUG_HOOKS // (make HOOKS=1 -> libcugo_hip_hooks.so; the product build carries none of this)
     int kernel_acquire;        // CUGO_KERNEL_ACQUIRE: bit 0 = every kernel of the factorisation starts with an agent-scope acquire fence, bit 1 = ends with a release fence
-    int dbg_delay;             // diagnosis (CUGO_DEBUG_DELAY): which waves / workgroups of k_up_potrf sleep (chol_kernels.hip: dbg_sleep)
+    int dbg_delay;             // diagnosis (CUGO_DEBUG_DELAY): which waves / workgroups of the factorisation's kernels sleep (chol_kernels.hip: dbg_sleep)
     int zero_lds;              // diagnosis (CUGO_DEBUG_ZERO_LDS=1 / 2): every kernel fills its LDS with zeros / NaNs first
     int lds_doubles;           // (set per launch: the dynamic LDS of this launch, for that fill)
     int dbg_skip_wg;           // (set per launch, -1: none) fault injection: this workgroup returns at once (CUGO_DEBUG_SKIP)
+#endif
     const int32_t* col0;       // first pivot column (new ordering, block units)
     const int32_t* rows_ptr;   // [n_fronts+1] into rows: boundary block rows (new ordering)
     const int32_t* rows;
@@ -195,8 +202,10 @@ void launch_chol_upper_stage(hipStream_t s, const CholPlanDev& p, double* d_fron
                              int ntasks, const int32_t* d_wl, int eap0, int neap, int ea0, int nea,
                              int sy0, int nsy, int tile, size_t lds_bytes, int32_t* d_fail,
                              double* dbg_line = nullptr, double* dbg_scratch = nullptr);
+#ifdef CUGO_DEBUG_HOOKS
 // diagnosis (CUGO_DEBUG_STALE): exchanges the 16 doubles at `line` with those at `scratch`
 void launch_swap16(hipStream_t s, double* line, double* scratch);
+#endif
 // two-phase form of a level's tile work (stage_tile == 0): trsm items (front, first row below the pivots,
 // rows) then syrk items (front, linear tile index, tile columns)
 void launch_chol_two_phase(hipStream_t s, const CholPlanDev& p, double* d_fronts, const int32_t* d_trsm, int ntrsm,
@@ -215,14 +224,15 @@ void launch_chol_lead(hipStream_t s, const CholPlanDev& p, double* d_fronts, con
 void launch_chol_backward_stage(hipStream_t s, const CholPlanDev& p, double* d_fronts, int task0,
                                 int ntasks, size_t lds_bytes, double* d_xnew, double* d_x,
                                 const int32_t* d_wl_gemv, int ngemv);
-// LDS bytes of the factor kernels (L11 + one 64-row tile) and of the backward kernel
-// diagnosis (CUGO_DEBUG_HASH): *out += the sum of the n 64-bit words at p (integer sum: order-independent)
-void launch_nop(hipStream_t s);
+#ifdef CUGO_DEBUG_HOOKS
+void launch_nop(hipStream_t s); // diagnosis (CUGO_DEBUG_GAP): an empty kernel
 // fault injection (CUGO_DEBUG_SKIP): the launches of the factorisation that follows are counted from 0; workgroup
 // target_wg of launch target_launch returns at once; dump_path: the launch table (index, kernel, grid, first items) goes there
 void chol_dbg_skip_begin(int target_launch, int target_wg, const char* dump_path);
-void chol_dbg_skip_end(); // diagnosis (CUGO_DEBUG_GAP): an empty kernel
+void chol_dbg_skip_end();
+// diagnosis (CUGO_DEBUG_HASH): *out += the sum of the n 64-bit words at p (integer sum: order-independent)
 void launch_hash_words(hipStream_t s, const void* p, size_t n_words, unsigned long long* out);
+#endif
 void launch_flag_to_double(hipStream_t s, int32_t* d_flag); // int32 0 / 1 -> double 0.0 / 1.0 in the same 8-byte slot
 void launch_chol_unpermute(hipStream_t s, const CholPlanDev& p, const double* d_xnew, double* d_x);
 void set_debug_stamps(long long* d_buf); // diagnostic s_memtime stamps (nullptr = off)

@@ -148,6 +148,9 @@ public:
     /** initialize() calls that found the graph unchanged and refreshed only the estimates */
     int flattenReuses() const { return flattenReuses_; }
     bool useFloat32() const { return options.useFloat32; }
+    /** a run-time switch of this optimiser ("flatten_reuse", "structure_reuse", "init_timing"; the optimiser took a
+     *  snapshot of the CUGO_* environment variables when it was created); false: unknown name */
+    bool setOption(const char* name, int value);
 
 private:
     bool verbose = false;

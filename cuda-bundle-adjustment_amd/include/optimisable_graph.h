@@ -16,6 +16,7 @@
 #include <cstdint>
 #include <map>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "cugo_types.h"
@@ -26,28 +27,120 @@ namespace cugo
 class BaseEdge;
 class BaseEdgeSet;
 
-// ordered set of edges with O(1) insert and O(n) erase (sets are small per vertex)
+// The reference's edge container is `std::unordered_set<BaseEdge*>` (ref: src/optimisable_graph.h:34; handed out
+// by Vertex::getEdges() :129 and EdgeSet::get() :753).  This one has the same member surface — find, count,
+// insert -> pair<iterator, bool> (a set: a second insert of the same edge is refused), emplace, erase(key) -> count,
+// erase(iterator) -> next, range insert, begin / end / cbegin / cend, size, empty, clear, reserve — so code written
+// against the reference's type compiles and behaves the same, but it ITERATES IN INSERTION ORDER: the flattened
+// edge order (and with it every floating-point sum) is then the same from run to run, which an unordered_set of
+// pointers does not give.  Storage: the edges in a vector; from 32 elements on an open-addressing index (pointer ->
+// position) answers find / count / the duplicate test of insert in O(1).  erase keeps the order (O(n) move) and
+// lets the index be rebuilt by the next lookup.
 class EdgeContainer
 {
 public:
-    using iterator = std::vector<BaseEdge*>::const_iterator;
-    iterator begin() const { return v_.begin(); }
-    iterator end() const { return v_.end(); }
-    std::size_t size() const { return v_.size(); }
-    bool empty() const { return v_.empty(); }
-    std::size_t count(BaseEdge* e) const { return std::find(v_.begin(), v_.end(), e) != v_.end(); }
-    void insert(BaseEdge* e) { v_.push_back(e); }
-    void erase(BaseEdge* e)
+    using key_type = BaseEdge*;
+    using value_type = BaseEdge*;
+    using size_type = std::size_t;
+    using iterator = std::vector<BaseEdge*>::const_iterator; // (as in a set, elements are not assignable through iterators)
+    using const_iterator = iterator;
+
+    iterator begin() const noexcept { return v_.begin(); }
+    iterator end() const noexcept { return v_.end(); }
+    const_iterator cbegin() const noexcept { return v_.begin(); }
+    const_iterator cend() const noexcept { return v_.end(); }
+    size_type size() const noexcept { return v_.size(); }
+    bool empty() const noexcept { return v_.empty(); }
+
+    iterator find(BaseEdge* e) const
     {
-        auto it = std::find(v_.begin(), v_.end(), e);
-        if (it != v_.end())
-            v_.erase(it);
+        if (v_.size() < kIndexFrom)
+            return std::find(v_.begin(), v_.end(), e);
+        if (!indexed_)
+            rebuild();
+        const std::size_t mask = tab_.size() - 1;
+        for (std::size_t h = hash(e) & mask;; h = (h + 1) & mask)
+        {
+            const uint32_t q = tab_[h];
+            if (q == 0)
+                return v_.end();
+            if (v_[q - 1] == e)
+                return v_.begin() + (q - 1);
+        }
     }
-    void clear() { v_.clear(); }
-    void reserve(std::size_t n) { v_.reserve(n); }
+    size_type count(BaseEdge* e) const { return find(e) != v_.end() ? 1 : 0; }
+    std::pair<iterator, bool> insert(BaseEdge* e)
+    {
+        const iterator it = find(e);
+        if (it != v_.end())
+            return {it, false};
+        v_.push_back(e);
+        if (v_.size() >= kIndexFrom)
+        {
+            if (!indexed_ || 2 * v_.size() > tab_.size())
+                rebuild();
+            else
+                put(e, (uint32_t)v_.size());
+        }
+        return {v_.end() - 1, true};
+    }
+    std::pair<iterator, bool> emplace(BaseEdge* e) { return insert(e); }
+    template <typename It>
+    void insert(It first, It last)
+    {
+        for (; first != last; ++first)
+            insert(*first);
+    }
+    size_type erase(BaseEdge* e)
+    {
+        const iterator it = find(e);
+        if (it == v_.end())
+            return 0;
+        erase(it);
+        return 1;
+    }
+    iterator erase(iterator pos)
+    {
+        indexed_ = false; // positions behind `pos` move: the next lookup rebuilds the index
+        return v_.erase(pos);
+    }
+    void clear() noexcept
+    {
+        v_.clear();
+        tab_.clear();
+        indexed_ = false;
+    }
+    void reserve(size_type n) { v_.reserve(n); }
 
 private:
+    static constexpr std::size_t kIndexFrom = 32;
+    static std::size_t hash(const BaseEdge* e) noexcept
+    {
+        std::uint64_t x = (std::uint64_t) reinterpret_cast<std::uintptr_t>(e);
+        x ^= x >> 33, x *= 0xff51afd7ed558ccdull, x ^= x >> 29;
+        return (std::size_t)x;
+    }
+    void put(BaseEdge* e, uint32_t pos1) const
+    {
+        const std::size_t mask = tab_.size() - 1;
+        std::size_t h = hash(e) & mask;
+        while (tab_[h] != 0)
+            h = (h + 1) & mask;
+        tab_[h] = pos1;
+    }
+    void rebuild() const
+    {
+        std::size_t cap = 64;
+        while (cap < 4 * v_.size()) // load factor between 1/4 and 1/2
+            cap *= 2;
+        tab_.assign(cap, 0);
+        for (std::size_t i = 0; i < v_.size(); i++)
+            put(v_[i], (uint32_t)(i + 1));
+        indexed_ = true;
+    }
     std::vector<BaseEdge*> v_;
+    mutable std::vector<uint32_t> tab_; // open addressing, linear probing: position + 1 of the edge, 0 = free
+    mutable bool indexed_ = false;
 };
 
 // ------------------------------------------------------------------ change tracking ----

@@ -204,15 +204,6 @@ int cugo_chol_analyze(cugo_chol* s, int n_block_rows, const int32_t* h_rowptr,
  * d_fail[0] (int32 device, 0 = ok) — ref: solve()->bool, zero pivot tol 1e-14. */
 int cugo_chol_factor_solve(cugo_chol* s, const double* d_Hsc, double lambda, const double* d_bsc,
                            double* d_x, int32_t* d_fail);
-/* diagnosis only (no counterpart in the reference): with CUGO_DEBUG_KEEP=1 a solver keeps device copies of the fronts,
- * W, L21 and the solution after each of its first 16 factor_solve calls; this writes those of the solver that ran last
- * (its graph still open) to dir/call<k>.bin: int64[8] header {fronts, W, L21, x permuted, x: doubles}, then the arrays. */
-int cugo_debug_dump(const char* dir, int* n_calls);
-/* the solver that ran last becomes "the reference" (which = 1 below; its graph has to stay open); one slot of either
- * solver (which = 0: the one that ran last) to a file of the same layout; a named plan array of either solver */
-int cugo_debug_pin_reference(void);
-int cugo_debug_dump_call(int which, int call, const char* path);
-int cugo_debug_plan_array(int which, const char* name, const int32_t** out);
 /* statistics of the analysis: nnz(L) in scalars, factorisation flops, #supernodes, #stages */
 int cugo_chol_stats(const cugo_chol* s, double* nnzL, double* flops, int* n_supernodes,
                     int* n_stages, double* front_bytes);
@@ -309,6 +300,14 @@ int cugo_shard_range(int n_landmarks_total, const int32_t* edges_per_landmark, i
  * counter below says how often that happened (CUGO_NO_FLATTEN_REUSE=1 disables it). */
 int cugo_graph_initialize(cugo_graph* g);
 int cugo_graph_flatten_reuses(cugo_graph* g);
+/* Run-time switches of one optimiser.  Every optimiser takes a snapshot of the CUGO_* environment variables when it
+ * is created (README.md lists them; nothing is read per call); this changes a single switch afterwards:
+ *   "flatten_reuse"   (0 = CUGO_NO_FLATTEN_REUSE: flatten and upload the whole graph in every initialize)
+ *   "structure_reuse" (0 = CUGO_NO_STRUCTURE_REUSE: Hsc pattern, lists, ordering, symbolic factor rebuilt every time —
+ *                      what a caller that builds a new graph per call, e.g. ORB-SLAM2, pays)
+ *   "init_timing"     (1 = CUGO_INIT_TIMING: per-section host times of initialize / optimize on stderr)
+ * Returns CUGO_ERR_INVALID for an unknown name. */
+int cugo_graph_set_option(cugo_graph* g, const char* name, int value);
 int cugo_graph_optimize(cugo_graph* g, int n_iters);  /* ref: optimize(n)  :153 */
 int cugo_graph_n_stats(cugo_graph* g);                /* ref: batchStatistics() :158 */
 int cugo_graph_get_stats(cugo_graph* g, int32_t* iteration, double* chi2, int cap);

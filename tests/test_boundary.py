@@ -176,3 +176,104 @@ def test_kernel_seam_executes_in_block_solver_order(tmp_path):
         np.testing.assert_allclose(got_pose, want, rtol=0, atol=1e-12)
     finally:
         ctx.close()
+
+
+EDGE_CONTAINER_SNIPPET = r"""
+// Code written against the reference's edge container (ref: src/optimisable_graph.h:34,
+// `using EdgeContainer = std::unordered_set<BaseEdge*>`, handed out by Vertex::getEdges() :129 and
+// EdgeSet::get() :753): the members such a caller uses, compiled once against the real std::unordered_set
+// (-DUSE_STD) and once against the mirrored header, with the same observable results.
+#include <cassert>
+#include <cstdio>
+#include <vector>
+#ifdef USE_STD
+#include <unordered_set>
+struct BaseEdge { int tag; };
+using EdgeContainer = std::unordered_set<BaseEdge*>;
+#else
+#include "ba_types.h"
+using cugo::BaseEdge;
+using cugo::EdgeContainer;
+struct E : cugo::MonoEdge { };
+#endif
+
+template <typename Edge>
+int run()
+{
+    std::vector<Edge> store(100);
+    EdgeContainer c;
+    assert(c.empty() && c.size() == 0 && c.begin() == c.end());
+    for (auto& e : store)
+    {
+        auto r = c.insert(&e);                       // insert -> pair<iterator, bool>
+        assert(r.second && *r.first == &e);
+    }
+    assert(!c.insert(&store[7]).second);             // a set: the second insert is refused
+    assert(c.size() == 100 && !c.empty());
+    assert(c.count(&store[42]) == 1);
+    EdgeContainer::iterator it = c.find(&store[42]); // find + erase(iterator) -> next
+    assert(it != c.end() && *it == &store[42]);
+    EdgeContainer::iterator next = c.erase(it);
+    (void)next;
+    assert(c.count(&store[42]) == 0 && c.find(&store[42]) == c.end() && c.size() == 99);
+    assert(c.erase(&store[42]) == 0 && c.erase(&store[43]) == 1 && c.size() == 98);   // erase(key) -> count
+    std::size_t n = 0;
+    for (EdgeContainer::const_iterator k = c.cbegin(); k != c.cend(); ++k)
+        n += (*k != nullptr);
+    for (BaseEdge* e : c)
+        n += (e != nullptr);
+    assert(n == 2 * 98);
+    std::vector<BaseEdge*> more{&store[42], &store[43], &store[0]};
+    c.insert(more.begin(), more.end());              // range insert, duplicates dropped
+    assert(c.size() == 100);
+    c.emplace(&store[1]);
+    assert(c.size() == 100);
+    c.reserve(1000);
+    c.clear();
+    assert(c.empty() && c.find(&store[0]) == c.end());
+    return 0;
+}
+
+int main()
+{
+#ifdef USE_STD
+    run<BaseEdge>();
+#else
+    run<E>();
+    // ... and through the objects that hand the container out
+    cugo::PoseVertex p(0, cugo::Se3D(), false);
+    cugo::LandmarkVertex l(0, cugo::Vec3d(), false);
+    E e;
+    e.setVertex(&p, 0), e.setVertex(&l, 1);
+    cugo::MonoEdgeSet es;
+    es.addEdge(&e);
+    assert(p.getEdges().count(&e) == 1 && l.getEdges().find(&e) != l.getEdges().end());
+    assert(es.get().size() == 1 && es.get().count(&e) == 1);
+    p.getEdges().erase(p.getEdges().find(&e));
+    assert(p.getEdges().empty());
+#endif
+    std::puts("ok");
+    return 0;
+}
+"""
+
+
+@pytest.mark.parametrize("against", ["std_unordered_set", "mirrored_header"])
+def test_edge_container_has_the_member_surface_of_the_reference_type(tmp_path, against):
+    """ref: src/optimisable_graph.h:34 — callers of getEdges() / EdgeSet::get() use find / erase(iterator) /
+    insert().second / count / empty on a std::unordered_set<BaseEdge*>; cugo::EdgeContainer (insertion-ordered for
+    run-to-run reproducibility) has the same members with the same results: the snippet runs against both."""
+    src, exe = tmp_path / "ec.cpp", tmp_path / "ec"
+    src.write_text(EDGE_CONTAINER_SNIPPET)
+    # (-Wno-ignored-qualifiers: `const int dim()` is the reference's own signature, ref: src/optimisable_graph.h:695)
+    cmd = ["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-Wno-unused-parameter", "-Wno-ignored-qualifiers",
+           str(src), "-o", str(exe)]
+    if against == "std_unordered_set":
+        cmd += ["-DUSE_STD"]
+    else:
+        libdir = os.path.join(ROOT, "cuda-bundle-adjustment_amd")
+        cmd += ["-I", INC, "-L", libdir, "-lcugo_hip", "-Wl,-rpath," + libdir]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-4000:]
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout + r.stderr

@@ -42,8 +42,8 @@ def main():
         graphs.append(g)
     times = [[] for _ in vals]
     if dirty:
-        os.environ["CUGO_NO_STRUCTURE_REUSE"] = "1"
-        os.environ["CUGO_NO_FLATTEN_REUSE"] = "1"
+        for g in graphs:
+            g.set_option("structure_reuse", 0); g.set_option("flatten_reuse", 0)
     for r in range(reps):
         for k, g in enumerate(graphs):
             put(vals[k])

@@ -11,6 +11,8 @@ import ctypes as C, importlib, os, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ["CUGO_DEBUG_KEEP"] = "1"
+# the arrays are kept (and cugo_debug_* exported) by the hooks build only: make -C cuda-bundle-adjustment_amd HOOKS=1
+os.environ.setdefault("CUGO_LIB", os.path.join(ROOT, "cuda-bundle-adjustment_amd", "libcugo_hip_hooks.so"))
 cugo = importlib.import_module("cuda-bundle-adjustment_amd")
 import numpy as np
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000

@@ -6,6 +6,9 @@ optimisers; counts the runs whose chi2 trace or final poses differ from the firs
                                                               deviation comes in bursts, so blocks of runs cannot be compared)"""
 import importlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get("CUGO_DEBUG_HASH"):  # in-stream checksums exist in the hooks build only (make HOOKS=1)
+    os.environ.setdefault("CUGO_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                   "cuda-bundle-adjustment_amd", "libcugo_hip_hooks.so"))
 cugo = importlib.import_module("cuda-bundle-adjustment_amd")
 import numpy as np
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200

@@ -158,11 +158,16 @@ def main():
         # data-path collectives are RCCL calls inside the library, on the solver's stream
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")  # one node: RCCL's bootstrap over loopback
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        import datetime
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
         # every rank first checks — without entering a collective — that librccl loads and that it has a
-        # device of its own; only if ALL ranks can, they enter ncclCommInitRank together (a rank failing
-        # inside the collective would leave the others blocked in it)
+        # device of its own.  If some rank cannot, ALL ranks take the host-staged gloo rehearsal path together
+        # (value withheld).  If all can, they enter ncclCommInitRank together, each in a helper thread with a
+        # deadline: a rank whose init fails or does not return in time reports 0, the ranks agree over gloo, and on
+        # disagreement EVERY rank exits non-zero at once (os._exit: a thread stuck inside RCCL cannot be joined) —
+        # no rank is left waiting in a collective for one that gave up.
         import ctypes
+        import threading
         can = 1.0
         try:
             ctypes.CDLL("librccl.so.1")
@@ -171,29 +176,49 @@ def main():
                 ctypes.CDLL("/opt/rocm/lib/librccl.so.1")
             except OSError:
                 can = 0.0
-        if ndev < world:
-            can = 0.0   # RCCL refuses two ranks of one communicator on the same device
+        if ndev < world and os.environ.get("CUGO_BENCH_ASSUME_DEVICES") != "1":
+            can = 0.0   # RCCL refuses two ranks of one communicator on the same device (the override: a rehearsal of
+                        # the refused init itself — every rank must then exit non-zero, see below)
+        if os.environ.get("CUGO_BENCH_FORCE_GLOO") == "1":
+            can = 0.0   # rehearsal of the fallback path on a box that could run RCCL
         pre = torch.tensor([can])
         dist.all_reduce(pre, op=dist.ReduceOp.MIN)
-        try:
-            if float(pre.item()) < 0.5:
-                raise RuntimeError("librccl or one GPU per rank not available on every rank")
+        if float(pre.item()) < 0.5:
+            comm = None
+            exchange_form = ("FALLBACK: callback + torch.distributed gloo through host memory (librccl or one GPU per "
+                             "rank not available on every rank): a rehearsal of the sharded path, not a scaling point")
+        else:
             box = [cugo.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
-            comm = cugo.Comm(box[0], rank, world)
-            ok = torch.tensor([1.0])
-        except Exception as e:  # keep the run alive: the callback form through gloo (host staging)
-            sys.stderr.write("rank %d: native RCCL communicator failed (%s)\n" % (rank, e))
-            comm = None
-            ok = torch.tensor([0.0])
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if float(ok.item()) < 0.5:
-            if comm is not None:
-                comm.close()
-            comm = None
-            exchange_form = "FALLBACK: callback + torch.distributed gloo through host memory (native RCCL communicator could not be created)"
-        else:
-            exchange_form = "native: ncclAllReduce on the solver's stream inside libcugo_hip.so"
+            result = {}
+
+            def init_comm():
+                try:
+                    if os.environ.get("CUGO_BENCH_FAIL_RANK") == str(rank):   # test hook: this rank fails its init
+                        raise RuntimeError("CUGO_BENCH_FAIL_RANK: induced failure")
+                    if os.environ.get("CUGO_BENCH_HANG_RANK") == str(rank):   # test hook: this rank never returns
+                        threading.Event().wait()
+                    cugo.set_device(local_rank % ndev)   # (the current device is per thread)
+                    result["comm"] = cugo.Comm(box[0], rank, world)
+                except Exception as e:  # noqa: BLE001
+                    result["error"] = e
+            deadline = float(os.environ.get("CUGO_BENCH_COMM_TIMEOUT", "180"))
+            th = threading.Thread(target=init_comm, daemon=True)
+            th.start()
+            th.join(deadline)
+            mine_ok = 1.0 if ("comm" in result and not th.is_alive()) else 0.0
+            if mine_ok < 0.5:
+                sys.stderr.write("rank %d: ncclCommInitRank %s\n" % (
+                    rank, "failed: %s" % result["error"] if "error" in result else "did not return within %.0f s" % deadline))
+            ok = torch.tensor([mine_ok])
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok.item()) < 0.5:
+                sys.stderr.write("rank %d: not every rank has a communicator: all ranks exit\n" % rank)
+                sys.stderr.flush()
+                os._exit(3)
+            comm = result["comm"]
+            exchange_form = ("native: RCCL on the solver's stream inside libcugo_hip.so (ncclAllReduce; with rank-owned "
+                             "elimination subtrees ncclReduceScatter + grouped ncclBroadcast)")
     views = {}
 
     def host_exchange(ptr, n, op):
@@ -207,6 +232,13 @@ def main():
         h = t.cpu()
         if op >= 2:   # broadcast from rank op - 2 (rank-owned elimination subtrees)
             dist.broadcast(h, src=op - 2)
+        elif op == -1:  # reduce-scatter of `world` equal segments (ownership-keyed exchange of the Schur system)
+            seg = n // world
+            # gloo has no reduce-scatter: all-reduce on the host, keep the own segment (a rehearsal path only)
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            own = h[rank * seg:(rank + 1) * seg].clone()
+            h.fill_(float("nan"))
+            h[rank * seg:(rank + 1) * seg] = own
         else:
             dist.all_reduce(h, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX)
         t.copy_(h)
@@ -514,8 +546,11 @@ def main():
                                    % (args.workload, P, L, nedges, args.iters),
                        "timed_region": "initialize(); optimize(%d) per step, contiguous (ref "
                                        "samples/sample_ba_from_file/main.cpp:185-190), structure clean" % args.iters,
-                       "parallelism": ("landmark-sharded x%d, RCCL all-reduce of [Hsc|bsc] per LM trial on the "
-                                       "solver's stream, LL^T by rank-owned elimination subtrees under a replicated top" % world) if world > 1 else "single GPU",
+                       "parallelism": ("landmark-sharded x%d; per LM trial the Schur system [Hsc|bsc] is exchanged by RCCL on "
+                                       "the solver's stream — all-reduce with the LL^T replicated, or (graphs with >= "
+                                       "CUGO_OWN_MIN_GFLOP per factorisation) reduce-scatter keyed on front ownership "
+                                       "with the LL^T split into rank-owned elimination subtrees under a replicated top"
+                                       % world) if world > 1 else "single GPU",
                        "lm_iterations_per_step": iters_total / args.steps,
                        "block_storage": "float (Hpl, Hpl*invHll streams; BASELINE config 5)" if args.float32 else "double"},
             "ba_10iter_seconds": elapsed / args.steps,
@@ -545,6 +580,11 @@ def main():
             trials = max(1, (xstats["calls"] - 3) // 2)
             out["exchange"] = {"form": exchange_form, "calls_per_step": xstats["calls"], "bytes_per_step": xstats["bytes"],
                                "payload_bytes_per_trial": 8.0 * (36 * sstats["hsc_blocks"] + 6 * (P - 1)) + 16.0,
+                               "schur_system_bytes_received_per_rank_and_trial": sstats.get("xchg_sys_bytes"),
+                               "schur_system_bytes_full_allreduce": sstats.get("xchg_sys_full_bytes"),
+                               "schur_system_exchange": ("reduce-scatter keyed on front ownership + all-reduce of the top's part"
+                                                         if sstats.get("xchg_sys_bytes", 0) < sstats.get("xchg_sys_full_bytes", 0)
+                                                         else "all-reduce (replicated factorisation)"),
                                "trials_per_step": trials,
                                "cholesky": {"rank_flops": sstats.get("chol_rank_flops"),
                                             "replicated_top_flops": sstats.get("chol_top_flops"),

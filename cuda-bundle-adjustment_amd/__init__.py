@@ -318,7 +318,7 @@ class Graph:
         keys = ["hsc_blocks", "products", "nnzL", "chol_flops", "supernodes", "stages", "front_bytes",
                 "offdiag_products", "up_potrf_flops", "up_trsm_flops", "up_syrk_flops", "up_ea_bytes",
                 "backward_bytes", "schur_slots", "chol_rank_flops", "chol_top_flops", "chol_bcast_bytes",
-                "chol_bcasts", "trial_sync_retries"]
+                "chol_bcasts", "trial_sync_retries", "xchg_sys_bytes", "xchg_sys_full_bytes"]
         return dict(zip(keys[:n], o[:n].tolist()))
 
 

@@ -56,7 +56,7 @@ struct cugo_chol
     void dump_kept(const char* dir);
     void dump_slot(int call, const char* path);
 #endif
-    bool own_subtrees() const { return world > 1 && bcast && !plan.owner.empty(); }
+    bool own_subtrees() const { return bcast && plan.owned; }
 
     void analyze(int n, const int32_t* rowptr, const int32_t* colind);
     void analyze_host(int n, const int32_t* rowptr, const int32_t* colind); // without upload()

@@ -811,6 +811,34 @@ void chol_analyze(int n, const int32_t* rowptr, const int32_t* colind, const Cho
     else
         for (int s = 0; s < ns; s++)
             P.rank_flops += work[s];
+    P.owned = opt.owned;
+    P.xs_seg = P.xs_top = 0;
+    P.xs_off.clear();
+    if (opt.owned)
+    { // layout of the ownership-keyed exchange (CholPlan::xs_off)
+        const size_t B = P.blk_front.size();
+        P.xs_off.assign(B + (size_t)n, 0);
+        std::vector<int64_t> fill(opt.world + 1, 0); // [world] = the top
+        auto slot = [&](int f) { return P.owner[f] < 0 ? opt.world : P.owner[f]; };
+        for (size_t k = 0; k < B; k++)
+        {
+            const int q = slot(P.blk_front[k]);
+            P.xs_off[k] = fill[q], fill[q] += 36;
+        }
+        for (int p = 0; p < n; p++)
+        { // bsc row p lands in the rhs row of the front that holds column iperm[p]
+            const int q = slot(P.col_front[P.iperm[p]]);
+            P.xs_off[B + p] = fill[q], fill[q] += 6;
+        }
+        for (int r = 0; r < opt.world; r++)
+            P.xs_seg = std::max(P.xs_seg, fill[r]);
+        P.xs_seg = (P.xs_seg + 15) & ~int64_t(15); // (segments start on 128-byte boundaries)
+        P.xs_top = fill[opt.world];
+        for (size_t k = 0; k < B; k++)
+            P.xs_off[k] += (int64_t)slot(P.blk_front[k]) * P.xs_seg;
+        for (int p = 0; p < n; p++)
+            P.xs_off[B + p] += (int64_t)slot(P.col_front[P.iperm[p]]) * P.xs_seg;
+    }
     auto mine = [&](int s) { return P.owner[s] < 0 || P.owner[s] == opt.rank; };
     // stage 0 tasks: maximal lower subtrees (root = lower front whose parent is not lower)
     std::vector<int> task_root_of(ns, -1);

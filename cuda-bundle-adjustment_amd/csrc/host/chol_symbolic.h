@@ -113,6 +113,15 @@ struct CholPlan
     // solution ranges that cross it: block columns [lo, hi) (new ordering) solved by `owner` alone
     std::vector<int32_t> xx_lo, xx_hi, xx_owner;
     double rank_flops = 0, top_flops = 0; // factorisation work of this rank's own subtrees / of the replicated top
+    bool owned = false; // this plan is in the rank-owned form (CholOptions::owned)
+    // Ownership-keyed exchange of the Schur system (owned form): a rank only needs the SUM over ranks of the Hsc
+    // blocks and right-hand-side rows that are assembled into fronts it factors — its own subtrees and the
+    // replicated top.  Packed buffer: `world` segments of xs_seg doubles (segment r: the units of rank r's fronts,
+    // blocks first, padded to the longest segment) followed by xs_top doubles (the top's units); the segments are
+    // reduce-scattered (rank r receives segment r), the top part is all-reduced.  xs_off[u]: offset of unit u in
+    // that buffer — u < B: Hsc block u (36 doubles), u >= B: the right-hand-side row of pose u - B (6 doubles).
+    int64_t xs_seg = 0, xs_top = 0;
+    std::vector<int64_t> xs_off;
 
     std::vector<int32_t> blk_front, blk_row, blk_col; // per Hsc block
     std::vector<uint8_t> blk_trans;

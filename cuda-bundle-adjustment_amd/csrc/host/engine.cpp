@@ -260,7 +260,8 @@ struct Engine::Impl : cugo_k::LaunchHook
     {
         join_pattern(); // (the helper's analyze_host() reads chol.rank / world / bcast)
         chol.rank = rank, chol.world = world;
-        if (world > 1)
+        xs_ready = false;
+        if (world > 1 || comm) // (a 1-rank communicator can run the owned form too: CUGO_OWN_SUBTREES=1, the rehearsal)
         {
             chol.bcast = [this](double* d, size_t n, int root) { broadcast(d, n, root); };
             chol.bcast_group = [this](bool start) {
@@ -271,6 +272,59 @@ struct Engine::Impl : cugo_k::LaunchHook
         else
             chol.bcast = nullptr, chol.bcast_group = nullptr;
         pattern_dirty = true; // the plan depends on (rank, world)
+    }
+    // ---- the per-trial exchange of the Schur system [Hsc | bsc] --------------------------------------------------
+    // Replicated factorisation: every rank needs all of it — one sum all-reduce.  Rank-owned elimination subtrees
+    // (chol_symbolic.h: CholPlan::owner): a rank assembles only the blocks and right-hand-side rows of its own
+    // fronts and of the replicated top, so the system is packed by ownership (CholPlan::xs_off), the `world`
+    // segments are REDUCE-SCATTERED (rank r receives the sum of segment r: 1 / world of the bytes) and the top's
+    // part is all-reduced (reduce-scatter + all-gather of the top's rows), then the received units go back to
+    // their places in d_sys.  CUGO_REDUCE_SCATTER=0: the all-reduce also in the owned form.
+    DevBuf<int64_t> d_xs_off;
+    DevBuf<double> d_xbuf;
+    bool xs_ready = false; // d_xs_off / d_xbuf are those of the plan at hand
+    void prepare_owned_exchange(hipStream_t s)
+    {
+        xs_ready = false;
+        const CholPlan& pl = chol.plan;
+        if (!chol.own_subtrees() || !opt.reduce_scatter || pl.xs_off.empty())
+            return;
+        d_xs_off.upload(pl.xs_off, s);
+        d_xbuf.resize((size_t)(pl.xs_seg * world + pl.xs_top) + 16);
+        d_xbuf.zero(s); // (the padding behind the shorter segments travels, and is never read)
+        CUGO_HIP(hipStreamSynchronize(s));
+        xs_ready = true;
+    }
+    void reduce_scatter(double* d, size_t n_seg)
+    {
+        xchg_bytes += 8.0 * (double)n_seg; // (bytes this rank receives)
+        xchg_calls++;
+        if (comm)
+        {
+            timed("exchange", [&] { comm->reduce_scatter(d, n_seg, ctx.stream); });
+            return;
+        }
+        if (!xfn)
+            throw std::runtime_error("cugo: sharded run without a communicator or an exchange function");
+        CUGO_HIP(hipStreamSynchronize(ctx.stream));
+        xfn(d, n_seg * (size_t)world, -1, xuser);
+    }
+    void exchange_system()
+    {
+        const size_t n = 36 * (size_t)hs.n_blocks + 6 * (size_t)P;
+        if (!xs_ready)
+        {
+            exchange(d_sys.data(), n, 0);
+            return;
+        }
+        const CholPlan& pl = chol.plan;
+        const int B = hs.n_blocks;
+        cugo_k::launch_xs_pack(ctx.stream, d_xs_off.data(), B, P, d_sys.data(), d_xbuf.data());
+        reduce_scatter(d_xbuf.data(), (size_t)pl.xs_seg);
+        if (pl.xs_top > 0)
+            exchange(d_xbuf.data() + pl.xs_seg * world, (size_t)pl.xs_top, 0);
+        cugo_k::launch_xs_unpack(ctx.stream, d_xs_off.data(), B, P, d_xbuf.data(), d_sys.data(), (long)(pl.xs_seg * rank),
+                                 (long)(pl.xs_seg * (rank + 1)), (long)(pl.xs_seg * world));
     }
     // broadcast of n doubles at d from rank `root` (update blocks / solution ranges of rank-owned elimination
     // subtrees).  Callback form: op code 2 + root.
@@ -1013,6 +1067,17 @@ void Engine::fill_structure_stats(int B, double products, double offdiag_product
             bytes += 8.0 * 6.0 * (pl.xx_hi[k] - pl.xx_lo[k]);
         sstats_.chol_bcast_bytes = bytes, sstats_.chol_bcasts = (double)(pl.xu_front.size() + pl.xx_lo.size());
     }
+    // sharded: what the per-trial exchange of the Schur system hands to this rank
+    sstats_.xchg_sys_full_bytes = sstats_.xchg_sys_bytes = 0;
+    if (m.world > 1 || m.comm)
+    {
+        if (!m.plan_only)
+            m.prepare_owned_exchange(m.ctx.stream);
+        const auto& pl = m.chol.plan;
+        sstats_.xchg_sys_full_bytes = 8.0 * (36.0 * B + 6.0 * m.P);
+        const bool keyed = m.plan_only ? (pl.owned && m.opt.reduce_scatter && !pl.xs_off.empty()) : m.xs_ready;
+        sstats_.xchg_sys_bytes = keyed ? 8.0 * (double)(pl.xs_seg + pl.xs_top) : sstats_.xchg_sys_full_bytes;
+    }
     sstats_.up_potrf_flops = m.chol.plan.up_potrf_flops;
     sstats_.up_trsm_flops = m.chol.plan.up_trsm_flops;
     sstats_.up_syrk_flops = m.chol.plan.up_syrk_flops;
@@ -1483,7 +1548,7 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
                                                                   m.opt.hsc_mfma, m.opt.hsc_xcd});
             });
             if (sharded)
-                m.exchange(m.d_sys.data(), 36 * (size_t)m.hs.n_blocks + 6 * (size_t)m.P, 0);
+                m.exchange_system();
             sync_prof(PROF_SCHUR, ts);
             if (q == 0)
             {

@@ -53,6 +53,10 @@ struct StructureStats
     // (update blocks into the top + solution ranges), number of those broadcasts
     double chol_rank_flops = 0, chol_top_flops = 0, chol_bcast_bytes = 0, chol_bcasts = 0;
     double trial_sync_retries = 0; // waits for an LM trial that returned before its result was there (expected: 0)
+    // sharded run: bytes of the Schur system [Hsc | bsc] this rank RECEIVES per LM trial — with rank-owned
+    // subtrees only its own segment (reduce-scatter) and the top's part (all-reduce) — and what the full
+    // all-reduce of the system would hand to it
+    double xchg_sys_bytes = 0, xchg_sys_full_bytes = 0;
 };
 
 enum ProfItem

@@ -73,7 +73,8 @@ std::vector<double> CudaGraphOptimisationImpl::structureStats() const
     return {s.hsc_blocks,     s.products,      s.nnzL,          s.chol_flops,  s.supernodes,
             s.stages,         s.front_bytes,   s.offdiag_products, s.up_potrf_flops,
             s.up_trsm_flops,  s.up_syrk_flops, s.up_ea_bytes,   s.backward_bytes, s.schur_slots,
-            s.chol_rank_flops, s.chol_top_flops, s.chol_bcast_bytes, s.chol_bcasts, s.trial_sync_retries};
+            s.chol_rank_flops, s.chol_top_flops, s.chol_bcast_bytes, s.chol_bcasts, s.trial_sync_retries,
+            s.xchg_sys_bytes, s.xchg_sys_full_bytes};
 }
 
 void CudaGraphOptimisationImpl::setKernelTiming(bool on) { engine_->set_kernel_timing(on); }

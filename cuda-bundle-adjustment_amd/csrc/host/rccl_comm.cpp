@@ -24,6 +24,7 @@ struct Api
     decltype(&ncclCommDestroy) comm_destroy = nullptr;
     decltype(&ncclAllReduce) all_reduce = nullptr;
     decltype(&ncclBroadcast) broadcast = nullptr;
+    decltype(&ncclReduceScatter) reduce_scatter = nullptr;
     decltype(&ncclGroupStart) group_start = nullptr;
     decltype(&ncclGroupEnd) group_end = nullptr;
     decltype(&ncclGetErrorString) error_string = nullptr;
@@ -46,6 +47,7 @@ Api& api()
         a.comm_destroy = reinterpret_cast<decltype(a.comm_destroy)>(dlsym(a.handle, "ncclCommDestroy"));
         a.all_reduce = reinterpret_cast<decltype(a.all_reduce)>(dlsym(a.handle, "ncclAllReduce"));
         a.broadcast = reinterpret_cast<decltype(a.broadcast)>(dlsym(a.handle, "ncclBroadcast"));
+        a.reduce_scatter = reinterpret_cast<decltype(a.reduce_scatter)>(dlsym(a.handle, "ncclReduceScatter"));
         a.group_start = reinterpret_cast<decltype(a.group_start)>(dlsym(a.handle, "ncclGroupStart"));
         a.group_end = reinterpret_cast<decltype(a.group_end)>(dlsym(a.handle, "ncclGroupEnd"));
         a.error_string = reinterpret_cast<decltype(a.error_string)>(dlsym(a.handle, "ncclGetErrorString"));
@@ -99,6 +101,16 @@ void RcclComm::broadcast(double* d_buf, size_t n, int root, hipStream_t s)
     if (!api().broadcast)
         throw std::runtime_error("cugo: librccl.so has no ncclBroadcast");
     check(api().broadcast(d_buf, d_buf, n, ncclDouble, root, static_cast<ncclComm_t>(comm_), s), "ncclBroadcast");
+}
+
+void RcclComm::reduce_scatter(double* d_buf, size_t n_seg, hipStream_t s)
+{
+    if (!api().reduce_scatter)
+        throw std::runtime_error("cugo: librccl.so has no ncclReduceScatter");
+    // in place: the receive buffer is this rank's segment of the send buffer (rccl.h: recvbuff == sendbuff + rank * recvcount)
+    check(api().reduce_scatter(d_buf, d_buf + (size_t)rank_ * n_seg, n_seg, ncclDouble, ncclSum,
+                               static_cast<ncclComm_t>(comm_), s),
+          "ncclReduceScatter");
 }
 
 // the broadcasts between group(true) and group(false) are issued as ONE fused operation (ncclGroupStart / End):

@@ -24,6 +24,9 @@ public:
     void all_reduce(double* d_buf, size_t n, int op, hipStream_t s);
     // in-place broadcast of n doubles from rank `root` on `s`; asynchronous
     void broadcast(double* d_buf, size_t n, int root, hipStream_t s);
+    // in-place sum reduce-scatter of world() segments of n_seg doubles starting at d_buf: afterwards segment rank()
+    // of THIS rank holds the sum over ranks of that segment (the other segments: unspecified); asynchronous
+    void reduce_scatter(double* d_buf, size_t n_seg, hipStream_t s);
     // broadcasts issued between group(true) and group(false) form one fused operation
     void group(bool start);
     int rank() const { return rank_; }

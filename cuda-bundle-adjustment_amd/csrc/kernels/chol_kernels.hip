@@ -2560,6 +2560,33 @@ __global__ __launch_bounds__(CBS) void k_unpermute(CholPlanDev p, const double* 
         xout[6L * p.perm[i / 6] + i % 6] = xnew[i];
 }
 
+// Ownership-keyed exchange of the Schur system (chol_symbolic.h: CholPlan::xs_off): sys = [Hsc (36 B) | bsc (6 n)] in
+// block / pose order  <->  the packed buffer whose segment r holds what rank r's fronts assemble and whose tail holds
+// what the replicated top assembles.  Pack copies every unit (this rank's partial sums of all of them go out); unpack
+// brings back only the units this rank will assemble: offsets in [lo, hi) — its own segment — or from top0 on.
+__global__ __launch_bounds__(CBS) void k_xs_pack(const int64_t* __restrict__ off, int B, int n,
+                                                 const double* __restrict__ sys, double* __restrict__ xbuf)
+{
+    const long i = (long)blockIdx.x * CBS + threadIdx.x;
+    const long nH = 36L * B;
+    if (i >= nH + 6L * n)
+        return;
+    const long dst = i < nH ? off[i / 36] + i % 36 : off[B + (i - nH) / 6] + (i - nH) % 6;
+    xbuf[dst] = sys[i];
+}
+__global__ __launch_bounds__(CBS) void k_xs_unpack(const int64_t* __restrict__ off, int B, int n,
+                                                   const double* __restrict__ xbuf, double* __restrict__ sys,
+                                                   long lo, long hi, long top0)
+{
+    const long i = (long)blockIdx.x * CBS + threadIdx.x;
+    const long nH = 36L * B;
+    if (i >= nH + 6L * n)
+        return;
+    const long o = i < nH ? off[i / 36] : off[B + (i - nH) / 6];
+    if ((o >= lo && o < hi) || o >= top0)
+        sys[i] = xbuf[o + (i < nH ? i % 36 : (i - nH) % 6)];
+}
+
 // the zero-pivot flag (int32 in an 8-byte slot) as a double in the same slot: ranks that factor different
 // subtrees see different flags, and the flag then rides in the sum all-reduce of the trial's scalars
 __global__ void k_flag_to_double(int32_t* __restrict__ flag)
@@ -2794,6 +2821,21 @@ void launch_hash_words(hipStream_t s, const void* p, size_t n_words, unsigned lo
 }
 #endif
 void launch_flag_to_double(hipStream_t s, int32_t* d_flag) { CUGO_LAUNCH(k_flag_to_double, dim3(1), dim3(1), 0, s, d_flag); }
+
+void launch_xs_pack(hipStream_t s, const int64_t* d_off, int B, int n, const double* d_sys, double* d_xbuf)
+{
+    const long total = 36L * B + 6L * n;
+    if (total > 0)
+        CUGO_LAUNCH(k_xs_pack, dim3((unsigned)((total + CBS - 1) / CBS)), dim3(CBS), 0, s, d_off, B, n, d_sys, d_xbuf);
+}
+void launch_xs_unpack(hipStream_t s, const int64_t* d_off, int B, int n, const double* d_xbuf, double* d_sys, long lo,
+                      long hi, long top0)
+{
+    const long total = 36L * B + 6L * n;
+    if (total > 0)
+        CUGO_LAUNCH(k_xs_unpack, dim3((unsigned)((total + CBS - 1) / CBS)), dim3(CBS), 0, s, d_off, B, n, d_xbuf, d_sys,
+                    lo, hi, top0);
+}
 
 void launch_chol_unpermute(hipStream_t s, const CholPlanDev& p, const double* d_xnew, double* d_x)
 {

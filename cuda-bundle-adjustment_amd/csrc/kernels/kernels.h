@@ -235,6 +235,11 @@ void launch_hash_words(hipStream_t s, const void* p, size_t n_words, unsigned lo
 #endif
 void launch_flag_to_double(hipStream_t s, int32_t* d_flag); // int32 0 / 1 -> double 0.0 / 1.0 in the same 8-byte slot
 void launch_chol_unpermute(hipStream_t s, const CholPlanDev& p, const double* d_xnew, double* d_x);
+// ownership-keyed exchange of [Hsc | bsc] (chol_symbolic.h: CholPlan::xs_off; d_off [B + n] packed offsets):
+// every unit of d_sys into the packed buffer / the units at packed offsets [lo, hi) or >= top0 back into d_sys
+void launch_xs_pack(hipStream_t s, const int64_t* d_off, int B, int n, const double* d_sys, double* d_xbuf);
+void launch_xs_unpack(hipStream_t s, const int64_t* d_off, int B, int n, const double* d_xbuf, double* d_sys, long lo,
+                      long hi, long top0);
 void set_debug_stamps(long long* d_buf); // diagnostic s_memtime stamps (nullptr = off)
 size_t chol_lds_factor_bytes(int nc_max);
 size_t chol_lds_backward_bytes(int nc_max, long ld_max);

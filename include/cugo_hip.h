@@ -261,6 +261,9 @@ int cugo_graph_set_robust_kernel(cugo_graph* g, int dim, int type, double delta)
  * (op 0 = sum, 1 = max) before it returns, or — op >= 2 — overwritten on every rank with rank
  * (op - 2)'s content (a broadcast: the update blocks and solution ranges of the elimination subtrees a
  * rank owns in the sparse LL^T; CUGO_OWN_SUBTREES=0 keeps the factorisation replicated and never asks). */
+/* op == -1: a sum REDUCE-SCATTER of `world` equal segments (n_doubles / world doubles each): on return segment `rank`
+ * of the buffer must hold the sum over ranks of that segment (the other segments are not read afterwards) — the
+ * ownership-keyed exchange of the Schur system: a rank only needs the Hsc blocks its own fronts assemble. */
 typedef void (*cugo_exchange_fn)(void* d_buf, size_t n_doubles, int op, void* user);
 /* ref: EdgeSet::setOutlierThreshold (src/optimisable_graph.h:737-740) + updateEdges
  * (optimisable_graph.hpp:603-640): at the end of cugo_graph_optimize every edge of the set (dim 2

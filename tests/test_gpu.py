@@ -889,6 +889,13 @@ def run_sharded_in_threads(d, world, niter, want_sstats=False):
             barrier.wait()
             if op >= 2:  # broadcast from rank op - 2 (rank-owned elimination subtrees)
                 tot = bufs[op - 2].copy()
+            elif op == -1:  # reduce-scatter of `world` equal segments: this rank gets the sum of ITS segment only
+                seg = n // world
+                tot = np.full(n, np.nan)   # (nothing outside the own segment may be read afterwards)
+                acc = bufs[0][rank * seg:(rank + 1) * seg].copy()
+                for r in range(1, world):  # fixed rank order
+                    acc = acc + bufs[r][rank * seg:(rank + 1) * seg]
+                tot[rank * seg:(rank + 1) * seg] = acc
             else:
                 tot = bufs[0].copy()
                 for r in range(1, world):  # fixed rank order
@@ -964,11 +971,18 @@ def test_synth10k_eight_shards_with_owned_subtrees():
         # a rank's factorisation: its own subtrees + the replicated top — well under the whole
         assert own[r] + top < 0.45 * whole
         assert res[r]["sstats"]["chol_bcast_bytes"] < 0.5 * 8 * 36 * res[r]["sstats"]["hsc_blocks"]
+        # the per-trial exchange of [Hsc | bsc] is keyed on front ownership: a rank RECEIVES its own segment
+        # (reduce-scatter) and the top's part (all-reduce), not the whole system.  The callback of this emulation
+        # hands back NaNs outside the own segment, so a unit read from elsewhere would wreck the trajectory above.
+        ss = res[r]["sstats"]
+        full = 8 * 36 * ss["hsc_blocks"]
+        assert ss["xchg_sys_full_bytes"] >= full
+        assert ss["xchg_sys_bytes"] <= (1.0 / 8 + top / whole + 0.10) * full, (ss["xchg_sys_bytes"] / full, top / whole)
     assert max(own) < 1.6 * (sum(own) / 8)   # balanced within 60 %
-    print("config 4, 8 shards: replicated top %.1f %% of the factorisation, own shares %s %%; broadcast %.1f MB per trial "
-          "(all-reduce payload %.1f MB)" % (100 * top / whole, [round(100 * o / whole, 1) for o in own],
-                                            res[0]["sstats"]["chol_bcast_bytes"] / 1e6,
-                                            8 * 36 * res[0]["sstats"]["hsc_blocks"] / 1e6))
+    print("config 4, 8 shards: replicated top %.1f %% of the factorisation, own shares %s %%; broadcast %.1f MB per trial; "
+          "Schur system received per rank and trial %.1f MB (all-reduce payload %.1f MB)"
+          % (100 * top / whole, [round(100 * o / whole, 1) for o in own], res[0]["sstats"]["chol_bcast_bytes"] / 1e6,
+             res[0]["sstats"]["xchg_sys_bytes"] / 1e6, res[0]["sstats"]["xchg_sys_full_bytes"] / 1e6))
 
 
 def test_kitti00_two_shards_match_unsharded(kitti00):
@@ -987,6 +1001,31 @@ def test_kitti00_two_shards_match_unsharded(kitti00):
         trials = sum(max(s["trials"], 0) + 1 for s in res[r]["stats"])
         assert res[r]["xstats"]["calls"] >= 3 + 2 * 10 and res[r]["xstats"]["calls"] <= 3 + 2 * trials + 2
     assert [s["chi2"] for s in res[0]["stats"]] == [s["chi2"] for s in res[1]["stats"]]  # ranks agree bitwise
+
+
+@pytest.mark.parametrize("form", ["default", "owned"])
+def test_kitti00_eight_shards_match_unsharded(kitti00, form, monkeypatch):
+    """BASELINE config 3 at its real world size: kitti_00 landmark-sharded over 8 ranks (eight optimisers in threads
+    on one GPU, exchange through the callback).  "default": the policy of a real run — 1.6 GFLOP per factorisation is
+    below CUGO_OWN_MIN_GFLOP, so the LL^T stays replicated and the system is all-reduced; "owned": rank-owned
+    elimination subtrees forced, with the ownership-keyed reduce-scatter.  Both reproduce the unsharded trajectory
+    and the oracle's, all ranks bitwise equal."""
+    if form == "owned":
+        monkeypatch.setenv("CUGO_OWN_SUBTREES", "1")
+    d = kitti00["d"]
+    res = run_sharded_in_threads(d, 8, 10, want_sstats=True)
+    single = run_graph(d, 10)
+    for r in range(8):
+        assert res[r] is not None and res[r]["nedges"] == 561116
+        assert_trajectories_match(res[r]["stats"], single["stats"], 1e-11)
+        assert_trajectories_match(res[r]["stats"], kitti00["ref"], 1e-10)
+        assert rmse(res[r]["pose"], single["pose"]) < 1e-11 and rmse(res[r]["lm"], single["lm"]) < 1e-10
+        assert [s["chi2"] for s in res[r]["stats"]] == [s["chi2"] for s in res[0]["stats"]]  # ranks agree bitwise
+        ss = res[r]["sstats"]
+        if form == "owned":
+            assert ss["chol_bcasts"] >= 2 and ss["xchg_sys_bytes"] < 0.75 * ss["xchg_sys_full_bytes"]
+        else:
+            assert ss["chol_bcasts"] == 0 and ss["xchg_sys_bytes"] == ss["xchg_sys_full_bytes"]
 
 
 def test_synth10k_full_size(oracle_lib):
@@ -1033,6 +1072,39 @@ def test_native_comm_single_rank(oracle_lib):
     assert np.array_equal(pose, single["pose"])
     B = single["sstats"]["hsc_blocks"]
     assert xs["calls"] >= 3 + 2 * 6 and xs["bytes"] >= 6 * 8 * (36 * B + 6 * 149)
+
+
+def test_native_comm_single_rank_runs_the_owned_form(oracle_lib, monkeypatch):
+    """The multi-GPU path of the factorisation under a ONE-rank native communicator (the rehearsal a single GPU
+    allows; RCCL refuses two ranks on one device): with CUGO_OWN_SUBTREES=1 every elimination subtree below the top
+    belongs to rank 0, and every collective of the owned form is really issued on the solver's stream inside
+    libcugo_hip.so — ncclReduceScatter of the packed Schur system + ncclAllReduce of the top's part, the update
+    blocks into the top by ncclBroadcast inside ncclGroupStart / End after their level, the solution ranges by
+    grouped ncclBroadcast, the zero-pivot flag riding in the all-reduce of (F-hat, scale).  With one rank every one
+    of them is the identity, so the run must be BITWISE the plain single-GPU run."""
+    d, _ = synth_problem(oracle_lib, 400, 8000, 33000, seed=11, lc=200)
+    single = run_graph(d, 6)
+    monkeypatch.setenv("CUGO_OWN_SUBTREES", "1")
+    comm = cugo.Comm(cugo.comm_unique_id(), 0, 1)
+    g = cugo.graph_from_arrays(d)
+    g.set_comm(comm)
+    g.initialize(); g.optimize(6)
+    st, pose, lm, xs, ss = g.stats(), g.poses(), g.landmarks(), g.exchange_stats(), g.structure_stats()
+    # a second call on the same optimiser re-uses structure, plan and exchange buffers
+    g.set_poses(np.arange(400, dtype=np.int32), d["pose"]); g.set_landmarks(np.arange(8000, dtype=np.int32), d["lm"])
+    g.initialize(); g.optimize(6)
+    st2 = g.stats()
+    g.close()
+    comm.close()
+    assert [s["chi2"] for s in st] == [s["chi2"] for s in single["stats"]]
+    assert [s["chi2"] for s in st2] == [s["chi2"] for s in single["stats"]]
+    assert np.array_equal(pose, single["pose"]) and np.array_equal(lm, single["lm"])
+    # the form really ran: a replicated top above owned subtrees, update blocks and solution ranges broadcast,
+    # the system reduce-scattered (one segment = everything below the top) + the top's part all-reduced
+    assert ss["chol_top_flops"] > 0 and ss["chol_rank_flops"] > 0 and ss["chol_bcasts"] >= 2
+    assert ss["xchg_sys_bytes"] >= ss["xchg_sys_full_bytes"] > 0   # (one rank: everything, plus the segment's padding)
+    trials = sum(max(s["trials"], 0) + 1 for s in st)
+    assert xs["calls"] >= 3 + 3 * 6 and xs["calls"] <= 3 + 3 * trials + 3
 
 
 def test_sharded_two_ranks_on_one_gpu_matches_single(oracle_lib):

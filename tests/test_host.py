@@ -496,7 +496,7 @@ def test_plan_only_rank_owned_subtrees_partition_the_factorisation(lib, world, m
     whole = g.structure_stats()
     g.close()
     assert whole["chol_top_flops"] == 0 and whole["chol_rank_flops"] > 0
-    own, top = [], None
+    own, top, recv = [], None, None
     for r in range(world):
         g = cugo.graph_from_arrays(d, plan_only=True)
         g.set_shard(r, world, lambda ptr, n, op: None)
@@ -507,5 +507,11 @@ def test_plan_only_rank_owned_subtrees_partition_the_factorisation(lib, world, m
         top = s["chol_top_flops"] if top is None else top
         assert s["chol_top_flops"] == top and s["chol_bcasts"] >= 1
         own.append(s["chol_rank_flops"])
+        # the ownership-keyed exchange of the Schur system: every rank receives one (padded) segment + the top's
+        # part — the same number of bytes on every rank, at least 1 / world of the system and well under all of it
+        full = 8.0 * (36 * s["hsc_blocks"] + 6 * 899)
+        assert s["xchg_sys_full_bytes"] == full
+        recv = s["xchg_sys_bytes"] if recv is None else recv
+        assert s["xchg_sys_bytes"] == recv and full / world <= recv < 0.9 * full
     assert abs(sum(own) + top - whole["chol_rank_flops"]) <= 1e-9 * whole["chol_rank_flops"]
     assert all(o > 0 for o in own) and max(own) + top < 0.9 * whole["chol_rank_flops"]

@@ -310,6 +310,20 @@ def main():
     gpu_chi = [s["chi2"] for s in stats[0]]
     gpu_pose, gpu_lm = timed[0].poses(), timed[0].landmarks()
     xstats = timed[0].exchange_stats() if world > 1 else None
+    # every rank must have taken the same LM decisions and ended every iteration on the same chi2 (the exchanged
+    # sums are the same bits on every rank): checked over the rendezvous group, reported in the line
+    ranks_agree = None
+    if world > 1:
+        mine = torch.tensor([s["chi2"] for st in stats for s in st] + [float(s["trials"]) for st in stats for s in st],
+                            dtype=torch.float64)
+        n_mine = torch.tensor([mine.numel()], dtype=torch.int64)
+        n_all = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(n_all, n_mine)
+        ranks_agree = all(int(t.item()) == mine.numel() for t in n_all)
+        if ranks_agree:
+            every = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine)
+            ranks_agree = all(torch.equal(t, every[0]) for t in every)
 
     extras = {}
     if not args.no_extras:
@@ -577,7 +591,11 @@ def main():
             out["value"] = None
             out["invalid"] = "native RCCL communicator unavailable: host-staged gloo fallback, value withheld"
         if world > 1 and xstats:
-            trials = max(1, (xstats["calls"] - 3) // 2)
+            trials = sum(max(s["trials"], 0) + 1 for s in stats[0])
+            out["ranks_agree_bitwise_on_chi2_and_trials"] = ranks_agree
+            if not ranks_agree:
+                out["value"] = None
+                out["invalid"] = "the ranks ended on different chi2 / trial counts"
             out["exchange"] = {"form": exchange_form, "calls_per_step": xstats["calls"], "bytes_per_step": xstats["bytes"],
                                "payload_bytes_per_trial": 8.0 * (36 * sstats["hsc_blocks"] + 6 * (P - 1)) + 16.0,
                                "schur_system_bytes_received_per_rank_and_trial": sstats.get("xchg_sys_bytes"),

@@ -397,18 +397,32 @@ def main():
     for g in graphs:
         g.close()
 
-    # ---- per-kernel device time: HIP events on the solver's stream, separate pass -------------
+    # ---- device time by kernel group and by kernel: HIP events on the solver's stream, two passes of their own ---
+    # pass A (groups): ONE event per group boundary, so the group times add up exactly to the device time of that
+    # optimize(10) — figures that fit inside the step; pass B (kernels): an event pair round every launch.  A pair
+    # brackets the kernel AND its dispatch (1 - 2 us that an un-instrumented stream hides behind the kernel before):
+    # the per-kernel averages are upper bounds of the kernel durations, fractions computed from them lower bounds;
+    # the rocprofv3 average of the same kernel (committed trace) and the fraction it gives are printed beside them
     groups, kernels, roofline = {}, {}, None
+    groups_fit = None
     if not args.no_extras:
         gk = new_graph()
         gk.initialize()
         gk.optimize(1)
         reset(gk)
         gk.initialize()
-        gk.set_kernel_timing(True)
+        gk.set_kernel_timing(2)
+        tA = time.perf_counter()
         gk.optimize(args.iters)
-        ktimes = gk.kernel_times()
+        passA_ms = (time.perf_counter() - tA) * 1e3
+        gtimes = gk.kernel_times()
+        reset(gk)
+        gk.initialize()
+        gk.set_kernel_timing(1)
+        gk.optimize(args.iters)
+        ktimes = {k: v for k, v in gk.kernel_times().items() if k.startswith("k_")}
         gk.close()
+        ktimes.update({k: v for k, v in gtimes.items() if not k.startswith("k_")})
         shard = max(1, world)
         n_fact = max(1, ktimes.get("cholesky", {}).get("launches", 1))
         El, Ll, Pf, B = nedges / shard, L / shard, P - 1, sstats["hsc_blocks"]
@@ -430,6 +444,7 @@ def main():
             avg_ms = kt["ms"] / kt["launches"]
             ent = {"avg_ms": avg_ms, "launches": kt["launches"], "total_ms": kt["ms"]}
             if name.startswith("k_"):
+
                 if name in rp_avg:
                     ent["rocprof_avg_us"] = rp_avg[name]
                 if name in pmc and world == 1 and not args.float32:
@@ -444,6 +459,8 @@ def main():
                                peak=FP64_PEAK_TFLOPS, unit="TFLOP/s")
                 if "achieved" in ent:
                     ent["frac"] = ent["achieved"] / ent["peak"]
+                    if "rocprof_avg_us" in ent:  # the same count over the committed rocprofv3 average
+                        ent["frac_from_rocprof_avg"] = ent["frac"] * avg_ms / (ent["rocprof_avg_us"] * 1e-3)
                 kernels[name] = ent
                 continue
             sb = survey_bytes(name, El, Pf, Ll, B)
@@ -470,6 +487,13 @@ def main():
                 "achieved": tile_flops * n_fact / (tot_ms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": tile_flops * n_fact / (tot_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                 "avg_ms": tot_ms / max(1, sum(k["launches"] for k in tk))}
+        # the groups come from pass A: they add up to the device time of its optimize(10), which fits in the step
+        gsum = sum(v["total_ms"] for v in groups.values())
+        groups_fit = {"sum_of_groups_ms": gsum, "pass_wall_ms": passA_ms, "ms_per_step": elapsed / args.steps * 1e3,
+                      "fits": bool(gsum <= passA_ms * 1.001 and gsum <= elapsed / args.steps * 1e3 * 1.02),
+                      "note": "groups: one event per group boundary in a pass of its own (their sum is the device time "
+                              "between the first and the last event of optimize()); kernels: event pairs per launch in "
+                              "another pass, the measured cost of a pair taken off"}
         rated = {k: v for k, v in kernels.items() if "achieved" in v}
         if rated:
             dominant = max(rated, key=lambda k: rated[k]["total_ms"])
@@ -480,9 +504,11 @@ def main():
                         if d.get("traffic") else None,
                         "avg_launch_ms": d["avg_ms"], "launches": d["launches"],
                         "rocprof_avg_us": d.get("rocprof_avg_us"), "rocprof_source": rp_src,
-                        "timing": "HIP events on the solver's stream in a separate pass of optimize(%d) "
-                                  "(events add ~2 us per launch; the rocprofv3 average of the same kernel is beside it)"
-                                  % args.iters,
+                        "frac_from_rocprof_avg": d.get("frac_from_rocprof_avg"),
+                        "timing": "HIP event pairs on the solver's stream in a separate pass of optimize(%d): a pair "
+                                  "brackets the kernel and its dispatch (1 - 2 us that an un-instrumented stream hides), so "
+                                  "avg_launch_ms is an upper bound and frac a lower bound; rocprof_avg_us is the same "
+                                  "kernel in the committed rocprofv3 trace" % args.iters,
                         "note": "fp64 MFMA peak == fp64 vector peak (78.6 TF) on MI355X; the multifrontal "
                                 "Cholesky kernels are latency / critical-path bound (DESIGN.md section 5)"}
 
@@ -548,7 +574,7 @@ def main():
     if rank == 0:
         chol_share = None
         if "cholesky" in groups and not args.no_extras:
-            # both from the HIP-event pass: the same per-launch event overhead sits in each
+            # from the boundary-event pass: the groups add up to the device time of optimize()
             tot = sum(v["total_ms"] for k, v in groups.items() if k != "exchange")
             chol_share = groups["cholesky"]["total_ms"] / max(tot, 1e-9)
         out = {
@@ -573,6 +599,7 @@ def main():
             "cpu_baseline": cpu,
             "parity": parity,
             "kernel_groups": groups,
+            "kernel_groups_fit_the_step": groups_fit,
             "kernels": kernels,
             "structure": sstats,
             "chi2": gpu_chi,
@@ -580,12 +607,12 @@ def main():
         out.update(extras)
         # the regimes a caller can be in, beside the headline (config survives the driver's parsing):
         # ORB-SLAM2 builds a new graph per BA call, i.e. pays `structure_dirty`
-        out["config"]["regimes_ms_per_step"] = {
-            "headline_estimates_only_changed": elapsed / args.steps * 1e3,
-            "reflatten": extras.get("reflatten", {}).get("ms_per_step"),
-            "structure_dirty_new_graph": extras.get("structure_dirty", {}).get("ms_per_step"),
-            "optimize_only": extras.get("optimize_only", {}).get("ms_per_step"),
-            "cold_first_call": (cold["initialize_ms"] + cold["optimize1_ms"]) if cold else None}
+        # (scalar keys: a nested dict does not survive the driver's parsing of `config`)
+        out["config"]["regime_headline_ms"] = elapsed / args.steps * 1e3
+        out["config"]["regime_reflatten_ms"] = extras.get("reflatten", {}).get("ms_per_step")
+        out["config"]["regime_new_graph_ms"] = extras.get("structure_dirty", {}).get("ms_per_step")
+        out["config"]["regime_optimize_only_ms"] = extras.get("optimize_only", {}).get("ms_per_step")
+        out["config"]["regime_cold_first_call_ms"] = (cold["initialize_ms"] + cold["optimize1_ms"]) if cold else None
         if world > 1 and comm is None:
             # a run that fell back to host staging through gloo is not a scaling point: no throughput
             out["value"] = None

@@ -304,11 +304,12 @@ class Graph:
         check(lib().cugo_graph_set_float32(self._g, int(on)))
 
     def set_kernel_timing(self, on):
+        """1: event pairs per kernel group and per kernel; 2: one event per group boundary (sums exactly); 0: off"""
         lib().cugo_graph_set_kernel_timing(self._g, int(on))
 
     def kernel_times(self):
-        buf = C.create_string_buffer(2048); ms = np.zeros(32); cnt = np.zeros(32, np.int32)
-        n = lib().cugo_graph_kernel_times(self._g, buf, 2048, _p(ms, _f64p), _p(cnt, _i32p), 32)
+        buf = C.create_string_buffer(8192); ms = np.zeros(96); cnt = np.zeros(96, np.int32)
+        n = lib().cugo_graph_kernel_times(self._g, buf, 8192, _p(ms, _f64p), _p(cnt, _i32p), 96)
         names = buf.value.decode().split("\n")[:n]
         return {names[i]: dict(ms=float(ms[i]), launches=int(cnt[i])) for i in range(n)}
 

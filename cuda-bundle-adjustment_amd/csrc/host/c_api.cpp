@@ -700,7 +700,7 @@ int cugo_graph_set_float32(cugo_graph* g, int on)
 }
 int cugo_graph_set_kernel_timing(cugo_graph* g, int on)
 {
-    g->opt->setKernelTiming(on != 0);
+    g->opt->setKernelTiming(on);
     return CUGO_OK;
 }
 int cugo_graph_kernel_times(cugo_graph* g, char* names, int buf_len, double* ms, int32_t* launches, int cap)

@@ -154,8 +154,23 @@ struct Engine::Impl : cugo_k::LaunchHook
     }
     std::vector<uint8_t> sig_flags;
 
-    // optional HIP-event timing of kernel groups
-    bool ktiming = false;
+    // optional HIP-event timing: 1 = an event pair round every kernel group AND every kernel (each pair adds a few
+    // microseconds to what it brackets: per-kernel figures, never sums), 2 = ONE event at every group boundary —
+    // the group times then add up exactly to the device time between the first and the last event of optimize()
+    int ktiming = 0;
+    struct Mark
+    {
+        int label;
+        hipEvent_t e;
+    };
+    std::vector<Mark> marks; // (mode 2)
+    void mark(int label)
+    {
+        Mark mk{label, nullptr};
+        CUGO_HIP(hipEventCreate(&mk.e));
+        CUGO_HIP(hipEventRecord(mk.e, ctx.stream));
+        marks.push_back(mk);
+    }
     struct KEv
     {
         int label;
@@ -180,6 +195,12 @@ struct Engine::Impl : cugo_k::LaunchHook
     {
         if (!ktiming)
         {
+            f();
+            return;
+        }
+        if (ktiming == 2)
+        {
+            mark(klabel(name));
             f();
             return;
         }
@@ -212,6 +233,21 @@ struct Engine::Impl : cugo_k::LaunchHook
     }
     void collect_times()
     {
+        if (!marks.empty())
+        { // mode 2: the time from a group's mark to the next mark belongs to the group
+            mark(-1);
+            CUGO_HIP(hipStreamSynchronize(ctx.stream));
+            for (size_t i = 0; i + 1 < marks.size(); i++)
+            {
+                float ms = 0;
+                CUGO_HIP(hipEventElapsedTime(&ms, marks[i].e, marks[i + 1].e));
+                kms[marks[i].label] += ms;
+                kcount[marks[i].label]++;
+            }
+            for (auto& mk : marks)
+                (void)hipEventDestroy(mk.e);
+            marks.clear();
+        }
         if (kev.empty())
             return;
         CUGO_HIP(hipStreamSynchronize(ctx.stream));
@@ -403,10 +439,10 @@ Engine::~Engine()
 
 Options& Engine::options() { return impl_->opt; }
 
-void Engine::set_kernel_timing(bool on)
+void Engine::set_kernel_timing(int mode)
 {
-    impl_->ktiming = on;
-    cugo_k::set_launch_hook(on ? impl_ : nullptr);
+    impl_->ktiming = mode;
+    cugo_k::set_launch_hook(mode == 1 ? impl_ : nullptr);
 }
 
 std::vector<Engine::KernelTime> Engine::kernel_times() const

@@ -118,7 +118,9 @@ public:
     static const char* profile_name(int i);
     // per-kernel-group device times measured with HIP events on the engine's stream
     // (enabled by set_kernel_timing; adds event overhead, so not used inside timed runs)
-    void set_kernel_timing(bool on);
+    // mode 1: event pairs round every kernel group and every kernel (per-kernel figures; each pair adds a few us);
+    // mode 2: one event per group boundary (group times that add up exactly to the device time of optimize()); 0: off
+    void set_kernel_timing(int mode);
     struct KernelTime
     {
         std::string name;

@@ -77,7 +77,7 @@ std::vector<double> CudaGraphOptimisationImpl::structureStats() const
             s.xchg_sys_bytes, s.xchg_sys_full_bytes};
 }
 
-void CudaGraphOptimisationImpl::setKernelTiming(bool on) { engine_->set_kernel_timing(on); }
+void CudaGraphOptimisationImpl::setKernelTiming(int mode) { engine_->set_kernel_timing(mode); }
 
 bool CudaGraphOptimisationImpl::setOption(const char* name, int value)
 {

@@ -140,8 +140,10 @@ public:
     /** B, M, nnz(L), flops, supernodes, stages, front bytes, off-diagonal products, then per
      *  factorisation: potrf / trsm / syrk flops, extend-add bytes, backward bytes */
     std::vector<double> structureStats() const;
-    /** HIP-event timing of kernel groups on the solver's stream (diagnostic; adds overhead) */
-    void setKernelTiming(bool on);
+    /** HIP-event timing on the solver's stream (diagnostic).  1: an event pair round every kernel group and every
+     *  kernel (per-kernel figures; each pair adds a few microseconds to what it brackets); 2: one event per group
+     *  boundary — group times that add up exactly to the device time of optimize(); 0: off */
+    void setKernelTiming(int mode);
     void kernelTimes(std::vector<std::string>& names, std::vector<double>& ms, std::vector<int>& launches) const;
     /** GraphOptimisationOptions::useFloat32 after construction; takes effect at the next initialize() */
     void setUseFloat32(bool on) { options.useFloat32 = on; }

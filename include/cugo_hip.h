@@ -326,8 +326,10 @@ int cugo_graph_n_active_edges(cugo_graph* g);
  * (block_solver.cpp:470-488).  names is a '\n' separated list written into buf. */
 int cugo_graph_time_profile(cugo_graph* g, char* names_buf, int buf_len, double* ms, int cap);
 int cugo_graph_set_verbose(cugo_graph* g, int verbose);
-/* HIP-event timing of the kernel groups (build, errors, schur, cholesky, backsubst_update) on
- * the solver's own stream; diagnostic (adds event overhead). names: '\n' separated. */
+/* HIP-event timing on the solver's own stream (diagnostic).  on = 1: an event pair round every kernel group (build,
+ * errors, schur, cholesky, backsubst_update, exchange) and every kernel — per-kernel figures; a pair brackets the kernel
+ * and its dispatch, 1 - 2 us more than the kernel's own duration, so these are never to be summed; on = 2: ONE event per group boundary, so that the group times add up exactly to the device time
+ * between the first and the last event of cugo_graph_optimize; 0: off.  names: '\n' separated. */
 int cugo_graph_set_kernel_timing(cugo_graph* g, int on);
 /* fp32-internal mode (ref: the USE_FLOAT32 build option, CMakeLists.txt:8; here a run-time switch,
  * GraphOptimisationOptions::useFloat32): float storage of the Hpl / Hpl*Hll^-1 block streams,

@@ -130,7 +130,7 @@ struct Engine::Impl : cugo_k::LaunchHook
     bool splan_on = false;
     GpuStructure gstruct;  // Hsc pattern + contribution lists built on the device (structure_gpu.h)
     bool structure_dirty = true;
-    uint64_t structure_sig = 0; // hash of the flattened topology the structure was built for
+    bool sig_valid = false; // sig_* hold the topology the structure at hand was built from
     // ... and the topology itself (compared on a hash hit), saved by build_structure()
     int sig_dims[8] = {0}, pending_dims[8] = {0};
     std::vector<int32_t> sig_e_pose, sig_e_lm, sig_cov_pose;
@@ -476,7 +476,6 @@ void Engine::exchange_stats(double& bytes, int& calls) const
     bytes = impl_->xchg_bytes, calls = impl_->xchg_calls;
 }
 
-static constexpr unsigned kMaxHostThreads = 16;
 
 // CUGO_INIT_TIMING=1: per-section host times of initialize() on stderr (diagnosis only)
 struct InitLaps
@@ -550,7 +549,7 @@ void Engine::initialize(FlatGraph& g)
         };
         // Callers usually add the edges landmark by landmark (ORB-SLAM2 walks its map points):
         // then the counting sort is the identity and only the counts are needed.
-        std::vector<uint8_t> chunk_sorted(kMaxHostThreads, 1);
+        std::vector<uint8_t> chunk_sorted(pool_threads(), 1);
         parallel_chunks((size_t)Etot, 100000, [&](size_t a, size_t b, unsigned t) {
             bool ok = true;
             for (size_t e = std::max<size_t>(a, 1); e < b; e++)
@@ -568,7 +567,7 @@ void Engine::initialize(FlatGraph& g)
             {
                 int32_t first = -1, nfirst = 0, last = -1, nlast = 0;
             };
-            std::vector<Side> side(kMaxHostThreads);
+            std::vector<Side> side(pool_threads());
             parallel_chunks((size_t)Etot, 100000, [&](size_t a, size_t b, unsigned t) {
                 if (a == b)
                     return;
@@ -600,28 +599,95 @@ void Engine::initialize(FlatGraph& g)
         }
         else
         {
-            parallel_chunks((size_t)m.Lall, 65536, [&](size_t la, size_t lb, unsigned) {
-                for (int e = 0; e < Etot; e++)
+            // Not sorted as a whole — but callers add their edges set by set and, inside a set, landmark by
+            // landmark (the reference sample: all mono edges, then all stereo edges, each in landmark order): the
+            // container order is a FEW sorted runs.  Then the counting sort is a merge of runs: a thread owns a
+            // landmark range, finds its part of every run by binary search and lays the edges of each landmark
+            // down run after run (= container order: stable).  O(E) work in all, where the general path below
+            // has every thread scan all edges twice.
+            std::vector<int32_t> run_start(1, 0);
+            {
+                const unsigned ntd = pool_threads();
+                std::vector<std::vector<int32_t>> desc(ntd);
+                parallel_chunks((size_t)Etot, 100000, [&](size_t a, size_t b, unsigned t) {
+                    for (size_t e = std::max<size_t>(a, 1); e < b && desc[t].size() <= 64; e++)
+                        if (elm[e - 1] > elm[e])
+                            desc[t].push_back((int32_t)e);
+                });
+                for (const auto& d : desc)
+                    run_start.insert(run_start.end(), d.begin(), d.end());
+            }
+            const int nruns = (int)run_start.size();
+            run_start.push_back(Etot);
+            if (nruns <= 64)
+            {
+                const unsigned nt = std::max(1u, std::min<unsigned>(pool_threads(), (unsigned)std::max(1, m.Lall / 1024)));
+                std::vector<int64_t> base(nt + 1, 0);
+                auto lrange = [&](unsigned t) { return (size_t)m.Lall * t / nt; };
+                auto run_lo = [&](int r, size_t l) {
+                    return (int32_t)(std::lower_bound(elm + run_start[r], elm + run_start[r + 1], (int32_t)l) - elm);
+                };
+                struct MergeCtx
                 {
-                    const size_t l = (size_t)elm[e];
-                    if (l >= la && l < lb)
-                        lm_cnt[l + 1]++;
-                }
-            });
-            for (int l = 0; l < m.Lall; l++)
-                lm_cnt[l + 1] += lm_cnt[l];
-            parallel_chunks((size_t)m.Lall, 65536, [&](size_t la, size_t lb, unsigned) {
-                if (la == lb)
-                    return;
-                std::vector<int32_t> pos(lm_cnt.begin() + la, lm_cnt.begin() + lb);
-                for (int e = 0; e < Etot; e++)
-                {
-                    const size_t l = (size_t)elm[e];
-                    if (l >= la && l < lb)
-                        order[pos[l - la]++] = e;
-                }
-                sort_by_pose(la, lb);
-            });
+                    const std::function<void(unsigned)>* fn;
+                };
+                auto run_threads = [&](const std::function<void(unsigned)>& fn) {
+                    MergeCtx c{&fn};
+                    pool_run(
+                        nt, [](void* p, unsigned t) { (*static_cast<MergeCtx*>(p)->fn)(t); }, &c);
+                };
+                run_threads([&](unsigned t) {
+                    int64_t c = 0;
+                    for (int r = 0; r < nruns; r++)
+                        c += run_lo(r, lrange(t + 1)) - run_lo(r, lrange(t));
+                    base[t + 1] = c;
+                });
+                for (unsigned t = 0; t < nt; t++)
+                    base[t + 1] += base[t];
+                run_threads([&](unsigned t) {
+                    const size_t la = lrange(t), lb = lrange(t + 1);
+                    if (la == lb)
+                        return;
+                    std::vector<int32_t> cur(nruns), lim(nruns);
+                    for (int r = 0; r < nruns; r++)
+                        cur[r] = run_lo(r, la), lim[r] = run_lo(r, lb);
+                    int32_t pos = (int32_t)base[t];
+                    for (size_t l = la; l < lb; l++)
+                    {
+                        lm_cnt[l] = pos; // (start of landmark l; lm_cnt[Lall] is set below)
+                        for (int r = 0; r < nruns; r++)
+                            while (cur[r] < lim[r] && elm[cur[r]] == (int32_t)l)
+                                order[pos++] = cur[r]++;
+                    }
+                });
+                lm_cnt[m.Lall] = Etot;
+                parallel_chunks((size_t)m.Lall, 65536, [&](size_t la, size_t lb, unsigned) { sort_by_pose(la, lb); });
+            }
+            else
+            {
+                parallel_chunks((size_t)m.Lall, 65536, [&](size_t la, size_t lb, unsigned) {
+                    for (int e = 0; e < Etot; e++)
+                    {
+                        const size_t l = (size_t)elm[e];
+                        if (l >= la && l < lb)
+                            lm_cnt[l + 1]++;
+                    }
+                });
+                for (int l = 0; l < m.Lall; l++)
+                    lm_cnt[l + 1] += lm_cnt[l];
+                parallel_chunks((size_t)m.Lall, 65536, [&](size_t la, size_t lb, unsigned) {
+                    if (la == lb)
+                        return;
+                    std::vector<int32_t> pos(lm_cnt.begin() + la, lm_cnt.begin() + lb);
+                    for (int e = 0; e < Etot; e++)
+                    {
+                        const size_t l = (size_t)elm[e];
+                        if (l >= la && l < lb)
+                            order[pos[l - la]++] = e;
+                    }
+                    sort_by_pose(la, lb);
+                });
+            }
         }
     }
     laps.lap("engine: landmark sort");
@@ -685,6 +751,7 @@ void Engine::initialize(FlatGraph& g)
         if (!pat_same)
         {
             m.pattern_dirty = true;
+            m.plan_uploaded = false;
             const bool device_build = !m.plan_only && !m.opt.schur_plan && !m.opt.host_structure;
             if (device_build && m.opt.async_structure && m.P > 0 && !m.cov_pose.empty())
             {
@@ -703,6 +770,10 @@ void Engine::initialize(FlatGraph& g)
                         prof_[PROF_BUILD_STRUCTURE] += ms_since(t0p);
                         const auto t1p = Clock::now();
                         mm.chol.analyze_host(mm.P, mm.hsc_rowptr.data(), mm.hsc_colind.data());
+                        // ... and the plan goes to the device from here as well (second stream; upload() waits for
+                        // its copies): the first optimize() then only builds the contribution lists
+                        mm.chol.upload(mm.s2);
+                        mm.plan_uploaded = true;
                         prof_[PROF_SYMBOLIC] += ms_since(t1p);
                         mm.pat_async_ok = true;
                     }
@@ -893,10 +964,10 @@ void Engine::initialize(FlatGraph& g)
     m.h_pose_ptr.assign(m.Pall + 1, 0);
     m.h_pose_edge.assign(std::max(E, 1), 0);
     {
-        const size_t serial_below = (size_t)m.Pall * kMaxHostThreads > (size_t)E ? (size_t)E + 1 : 100000;
+        const size_t serial_below = (size_t)m.Pall * pool_threads() > (size_t)E ? (size_t)E + 1 : 100000;
         const int32_t* ep = m.h_e_pose.data();
         const int32_t* src = slot_src.data();
-        std::vector<std::vector<int32_t>> hist(kMaxHostThreads);
+        std::vector<std::vector<int32_t>> hist(pool_threads());
         const unsigned nt = parallel_chunks((size_t)E, serial_below, [&](size_t a, size_t b, unsigned t) {
             std::vector<int32_t>& h = hist[t];
             h.assign(m.Pall, 0);
@@ -984,58 +1055,36 @@ void Engine::initialize(FlatGraph& g)
     }
     // Re-use of the Hsc structure, ordering and symbolic factor across optimize() calls when
     // the topology is unchanged (ref: the isDirty logic of BlockSolver::buildStructure,
-    // block_solver.cpp:151-216, which skips the rebuild for clean edge sets).  Decided by a
-    // hash of the flattened topology, so a changed fixed flag is noticed too.
+    // block_solver.cpp:151-216, which skips the rebuild for clean edge sets).  Decided by comparing the
+    // flattened topology — slots, flags (a changed fixed flag is noticed too) and co-visibility lists — with
+    // the copy the structure at hand was built from: a parallel memcmp that stops at the first difference (a new
+    // graph costs next to nothing here; rounds 1-3 hashed all of it first, 0.4 ms of every full initialize()).
     {
-        uint64_t h = 1469598103934665603ull;
-        auto mix = [&h](const void* p, size_t n) {
-            // 64-bit FNV-style hash of fixed 64 KiB pieces (hashed in parallel), then of their digests
-            constexpr size_t piece = 1u << 16;
-            const size_t np = (n + piece - 1) / piece;
-            std::vector<uint64_t> dig(np);
-            const unsigned char* base = static_cast<const unsigned char*>(p);
-            parallel_chunks(np, 4, [&](size_t a, size_t b, unsigned) {
-                for (size_t q = a; q < b; q++)
-                {
-                    const unsigned char* c0 = base + q * piece;
-                    const size_t len = std::min(piece, n - q * piece);
-                    uint64_t d = 1469598103934665603ull ^ len;
-                    size_t i = 0;
-                    for (; i + 8 <= len; i += 8)
-                    {
-                        uint64_t w;
-                        std::memcpy(&w, c0 + i, 8);
-                        d = (d ^ w) * 1099511628211ull;
-                    }
-                    for (; i < len; i++)
-                        d = (d ^ c0[i]) * 1099511628211ull;
-                    dig[q] = d;
-                }
-            });
-            for (uint64_t d : dig)
-                h = (h ^ d) * 1099511628211ull;
-            h = (h ^ n) * 1099511628211ull;
-        };
         const int dims[8] = {m.Pall, m.Lall, m.P, m.L, E, m.rank, m.world, Etot};
-        mix(dims, sizeof dims);
-        mix(m.h_e_pose.data(), sizeof(int32_t) * m.h_e_pose.size());
-        mix(m.h_e_lm.data(), sizeof(int32_t) * m.h_e_lm.size());
-        mix(m.h_flags.data(), m.h_flags.size());
-        mix(m.cov_pose.data(), sizeof(int32_t) * m.cov_pose.size());
-        // the hash only rejects fast: on a hit the arrays the structure was built from are compared
-        // (a 64-bit collision must not replay a plan of another topology)
         auto same = [](const auto& a, const auto& b) {
-            return a.size() == b.size() && (a.empty() || std::memcmp(a.data(), b.data(), a.size() * sizeof(a[0])) == 0);
+            if (a.size() != b.size())
+                return false;
+            const size_t bytes = a.size() * sizeof(a[0]);
+            if (bytes == 0)
+                return true;
+            const char* pa = reinterpret_cast<const char*>(a.data());
+            const char* pb = reinterpret_cast<const char*>(b.data());
+            std::atomic<bool> eq{true};
+            parallel_chunks(bytes, 1u << 18, [&](size_t lo, size_t hi, unsigned) {
+                for (size_t o = lo; o < hi && eq.load(std::memory_order_relaxed); o += 1u << 16)
+                    if (std::memcmp(pa + o, pb + o, std::min<size_t>(1u << 16, hi - o)) != 0)
+                        eq.store(false, std::memory_order_relaxed);
+            });
+            return eq.load();
         };
-        const bool hit = h == m.structure_sig && std::memcmp(dims, m.sig_dims, sizeof dims) == 0 &&
+        const bool hit = m.opt.structure_reuse && m.sig_valid && std::memcmp(dims, m.sig_dims, sizeof dims) == 0 &&
                          same(m.h_e_pose, m.sig_e_pose) && same(m.h_e_lm, m.sig_e_lm) &&
                          same(m.h_flags, m.sig_flags) && same(m.cov_pose, m.sig_cov_pose);
-        if (!hit || !m.opt.structure_reuse)
+        if (!hit)
             m.structure_dirty = true;
-        m.structure_sig = h;
         std::memcpy(m.pending_dims, dims, sizeof dims);
     }
-    laps.lap("engine: topology hash");
+    laps.lap("engine: topology compare");
     finish_uploads();
     laps.lap("engine: upload sync");
     prof_[PROF_INITIALIZE] += ms_since(t0);
@@ -1048,6 +1097,8 @@ void Engine::fill_structure_stats(int B, double products, double offdiag_product
     Impl& m = *impl_;
     // remember what this structure was built from (Engine::initialize compares on a hash hit)
     std::memcpy(m.sig_dims, m.pending_dims, sizeof m.sig_dims);
+    m.sig_valid = m.opt.structure_reuse; // (re-use switched off: nothing will ever be compared with these)
+    if (m.sig_valid)
     {
         // (7 MB on the kitti_00 shape, on the path of a new graph's first optimize(): copied by the pool)
         auto copy = [](auto& dst, const auto& src) {
@@ -1195,12 +1246,13 @@ void Engine::build_structure()
         if (ok && build_lists_gpu(s, m.E, P, m.Lall, m.d_e_pose.data(), m.d_flags.data(), m.d_lm_ptr.data(), m.gstruct))
         {
             laps.lap("structure: contribution lists (device)");
-            if (m.pattern_dirty || !m.plan_uploaded)
+            if (!m.plan_uploaded) // (the helper thread of initialize() uploads the plans it analyses)
             {
                 m.chol.upload(s);
                 m.plan_uploaded = true;
-                m.pat_P = P, m.pat_L = L, m.pat_cov_ptr = m.cov_ptr, m.pat_cov_pose = m.cov_pose;
             }
+            if (m.pattern_dirty)
+                m.pat_P = P, m.pat_L = L, m.pat_cov_ptr = m.cov_ptr, m.pat_cov_pose = m.cov_pose;
             m.pattern_dirty = false;
             m.gstruct.scratch.release(), m.gstruct.scratch2.release();
             const int B = m.gstruct.B;
@@ -1213,7 +1265,7 @@ void Engine::build_structure()
             m.splan_on = false;
             double nff = 0;
             {
-                std::vector<int64_t> part(kMaxHostThreads, 0);
+                std::vector<int64_t> part(pool_threads(), 0);
                 parallel_chunks((size_t)m.E, 100000, [&](size_t a, size_t b, unsigned t) {
                     int64_t c = 0;
                     for (size_t e = a; e < b; e++)
@@ -1250,7 +1302,7 @@ void Engine::build_structure()
     // The three passes below are independent per pose row: contiguous row ranges, balanced by
     // their number of co-visibility entries, go to a few host threads (SLAM calls BA with a new
     // topology every time, so this "cold" work is paid on every call there).
-    const unsigned nth = m.cov_pose.size() < 200000 ? 1u : std::max(1u, std::min(kMaxHostThreads, std::thread::hardware_concurrency()));
+    const unsigned nth = m.cov_pose.size() < 200000 ? 1u : std::max(1u, pool_threads());
     std::vector<int> row_split(nth + 1, P);
     row_split[0] = 0;
     for (unsigned t = 1; t < nth; t++)

@@ -5,6 +5,9 @@
 #include "thread_pool.h"
 
 #include <pthread.h>
+#include <sched.h>
+
+#include <cstdlib>
 
 #include <algorithm>
 #include <atomic>
@@ -90,9 +93,25 @@ Pool* g_pool = nullptr;
 std::once_flag g_once;
 std::atomic<bool> g_forked{false};
 
+// Width of the pool: the CPUs this process may run on (its affinity mask: a container's share of a 256-thread
+// host, not the host), at most kPoolCap; CUGO_HOST_THREADS overrides.  The walks are memory-latency bound (edge and
+// vertex objects scattered over the heap), so they scale with threads until the cores of the share are used up;
+// measured on the MI355X box (EPYC 9575F): DESIGN.md section 6a.
+constexpr unsigned kPoolCap = 64;
 unsigned wanted_threads()
 {
-    return std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    static const unsigned n = [] {
+        unsigned cpus = std::thread::hardware_concurrency();
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0)
+            cpus = std::min<unsigned>(cpus ? cpus : 1u, (unsigned)CPU_COUNT(&set));
+        unsigned want = std::min(kPoolCap, cpus);
+        if (const char* e = std::getenv("CUGO_HOST_THREADS"))
+            want = std::min(kPoolCap, (unsigned)std::max(1, std::atoi(e)));
+        return std::max(1u, want);
+    }();
+    return n;
 }
 
 void create_pool()

@@ -6,7 +6,7 @@
 namespace cugo_host
 {
 
-unsigned pool_threads(); // chunks worth asking for (<= 16)
+unsigned pool_threads(); // chunks worth asking for: the CPUs of the share of this process (<= 64; CUGO_HOST_THREADS)
 // fn(ctx, c) for c in [0, chunks), spread over the pool; returns when all chunks are done
 void pool_run(unsigned chunks, void (*fn)(void*, unsigned), void* ctx);
 

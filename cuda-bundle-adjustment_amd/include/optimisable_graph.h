@@ -272,7 +272,7 @@ void hostPoolRun(unsigned chunks, void (*fn)(void*, unsigned), void* ctx);
 } // namespace detail
 
 // Runs f(begin, end, chunk) over [0, n) split into contiguous chunks on the library's host
-// threads (one chunk, in the caller, for small n).  Returns the number of chunks (<= 16).  The
+// threads (one chunk, in the caller, for small n).  Returns the number of chunks (<= detail::hostPoolThreads()).  The
 // vertex/edge walks of initialize()/optimize() are memory-latency bound pointer chasing: they
 // scale with threads.
 template <typename F>
@@ -343,7 +343,7 @@ public:
     int countFree() const noexcept override
     {
         const std::vector<T*>& ids = idOrder();
-        std::vector<int> part(16, 0);
+        std::vector<int> part(detail::hostPoolThreads(), 0);
         parallelChunks(ids.size(), [&](size_t a, size_t b, unsigned t) {
             int c = 0;
             for (size_t i = a; i < b; i++)
@@ -361,7 +361,7 @@ public:
     {
         const std::vector<T*>& ids = idOrder();
         const size_t total = ids.size();
-        std::vector<int> cfree(17, 0), cfix(17, 0);
+        std::vector<int> cfree(detail::hostPoolThreads() + 1, 0), cfix(detail::hostPoolThreads() + 1, 0);
         const unsigned nt = parallelChunks(total, [&](size_t a, size_t b, unsigned t) {
             int c = 0;
             for (size_t i = a; i < b; i++)

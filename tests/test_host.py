@@ -515,3 +515,33 @@ def test_plan_only_rank_owned_subtrees_partition_the_factorisation(lib, world, m
         assert s["xchg_sys_bytes"] == recv and full / world <= recv < 0.9 * full
     assert abs(sum(own) + top - whole["chol_rank_flops"]) <= 1e-9 * whole["chol_rank_flops"]
     assert all(o > 0 for o in own) and max(own) + top < 0.9 * whole["chol_rank_flops"]
+
+
+def test_landmark_major_sort_paths_give_the_same_structure(lib):
+    """Engine::initialize orders the edges landmark-major by one of three paths — the container order is already
+    sorted (one edge set, landmark by landmark), it is a few sorted runs (one per edge set: merged), or anything
+    (every thread scans all edges) — and all of them must lay out the same graph: same Hsc pattern, products,
+    symbolic factor (plan-only graphs: host side only)."""
+    d = cugo.synth(300, 5000, 21000, seed=12, n_loop_closures=60, stereo_fraction=0.5)
+    order = np.lexsort((d["e_pose"], d["e_lm"]))           # landmark by landmark
+    rng = np.random.default_rng(3)
+    shuffled = rng.permutation(len(d["e_lm"]))
+
+    def stats(perm, all_mono=False):
+        e = dict(d)
+        for k in ("e_pose", "e_lm", "e_stereo", "e_meas", "e_omega"):
+            e[k] = d[k][perm]
+        if all_mono:
+            e["e_stereo"] = np.zeros_like(e["e_stereo"])
+        g = cugo.graph_from_arrays(e, plan_only=True)
+        g.initialize()
+        s = g.structure_stats()
+        g.close()
+        return s
+    runs = stats(order)                   # two edge sets (mono, stereo), each sorted: the merge of runs
+    anyorder = stats(shuffled)            # many descents: the general path
+    assert runs == anyorder
+    one_sorted = stats(order, all_mono=True)      # one set, sorted: the identity path
+    one_shuffled = stats(shuffled, all_mono=True)
+    assert one_sorted == one_shuffled
+    assert one_sorted["hsc_blocks"] == runs["hsc_blocks"] and one_sorted["products"] == runs["products"]

@@ -144,6 +144,11 @@ struct Engine::Impl : cugo_k::LaunchHook
     bool pat_async_ok = false;   // the helper finished a pattern + host plan for the current lists
     bool pattern_dirty = true;   // the pattern / plan in gstruct / chol are not those of the current lists
     bool plan_uploaded = false;
+    // the helper's progress, for the caller of initialize(): 1 = the pattern is in gstruct (the contribution lists
+    // can be built as soon as the slots are on the device), -1 = it was not built; and whether the lists of the
+    // structure at hand were already built at the end of initialize()
+    std::atomic<int> pat_stage{0};
+    bool lists_built = false;
     int pat_P = -1, pat_L = -1;
     std::vector<int32_t> pat_cov_ptr, pat_cov_pose; // the lists the pattern in gstruct / chol was built from
     hipStream_t s2 = nullptr;
@@ -733,6 +738,7 @@ void Engine::initialize(FlatGraph& g)
                                      std::to_string(dup_lm.load()) + "): duplicate (pose, landmark) edges are not supported");
     }
     laps.lap("engine: co-visibility");
+    bool helper_started = false;
     // ---- the co-visibility lists decide the Hsc pattern: if they changed, its build, the ordering and the
     // symbolic factorisation start NOW, beside the rest of this function (see Impl::pat_thread)
     m.join_pattern();
@@ -748,6 +754,8 @@ void Engine::initialize(FlatGraph& g)
         const bool pat_same = !m.pattern_dirty && m.opt.structure_reuse && m.P == m.pat_P &&
                               m.L == m.pat_L && same(m.cov_ptr, m.pat_cov_ptr) && same(m.cov_pose, m.pat_cov_pose);
         m.pat_async_ok = false;
+        m.lists_built = false;
+        m.pat_stage.store(0, std::memory_order_relaxed);
         if (!pat_same)
         {
             m.pattern_dirty = true;
@@ -765,7 +773,11 @@ void Engine::initialize(FlatGraph& g)
                         CUGO_HIP(hipSetDevice(mm.ctx.device));
                         const auto t0p = Clock::now();
                         if (!build_pattern_gpu(mm.s2, mm.P, mm.L, mm.cov_ptr.data(), mm.cov_pose.data(), mm.gstruct))
+                        {
+                            mm.pat_stage.store(-1, std::memory_order_release);
                             return;
+                        }
+                        mm.pat_stage.store(1, std::memory_order_release);
                         mm.hsc_rowptr = mm.gstruct.h_rowptr, mm.hsc_colind = mm.gstruct.h_colind;
                         prof_[PROF_BUILD_STRUCTURE] += ms_since(t0p);
                         const auto t1p = Clock::now();
@@ -780,8 +792,10 @@ void Engine::initialize(FlatGraph& g)
                     catch (...)
                     {
                         mm.pat_err = std::current_exception();
+                        mm.pat_stage.store(-1, std::memory_order_release);
                     }
                 });
+                helper_started = true;
             }
         }
     }
@@ -1087,6 +1101,17 @@ void Engine::initialize(FlatGraph& g)
     laps.lap("engine: topology compare");
     finish_uploads();
     laps.lap("engine: upload sync");
+    // The contribution lists need the pattern (the helper's first 0.4 ms) and the slots on the device (just now):
+    // they are built here, on this stream, while the helper is still ordering and analysing — off the critical
+    // path of the first optimize()
+    if (helper_started && m.structure_dirty && !m.plan_only)
+    {
+        while (m.pat_stage.load(std::memory_order_acquire) == 0)
+            std::this_thread::yield();
+        if (m.pat_stage.load(std::memory_order_acquire) == 1)
+            m.lists_built = build_lists_gpu(s, m.E, m.P, m.Lall, m.d_e_pose.data(), m.d_flags.data(), m.d_lm_ptr.data(), m.gstruct);
+        laps.lap("engine: contribution lists");
+    }
     prof_[PROF_INITIALIZE] += ms_since(t0);
     if (m.plan_only && m.structure_dirty)
         build_structure(); // no optimize() will follow: the structure is all there is to do
@@ -1243,7 +1268,9 @@ void Engine::build_structure()
         laps.lap("structure: pattern + symbolic (unless done beside initialize)");
         // phase 2: the contribution lists from the slots on the device
         const auto t2 = Clock::now();
-        if (ok && build_lists_gpu(s, m.E, P, m.Lall, m.d_e_pose.data(), m.d_flags.data(), m.d_lm_ptr.data(), m.gstruct))
+        const bool have_lists = m.lists_built && m.pat_async_ok; // (built at the end of initialize() for this pattern)
+        m.lists_built = false;
+        if (ok && (have_lists || build_lists_gpu(s, m.E, P, m.Lall, m.d_e_pose.data(), m.d_flags.data(), m.d_lm_ptr.data(), m.gstruct)))
         {
             laps.lap("structure: contribution lists (device)");
             if (!m.plan_uploaded) // (the helper thread of initialize() uploads the plans it analyses)

@@ -540,81 +540,81 @@ __global__ __launch_bounds__(BS) void k_build_edges(EV ev, const double* __restr
     }
 }
 
-// NV accumulators of one workgroup -> NV sums, fixed order.  Row v of the LDS buffer holds the BS
-// per-thread values of accumulator v (row stride RS = BS + 8 doubles: rows start 16 banks apart);
-// thread (v, g), g < 8, sums the 32 values g, g+8, g+16, ... of its row — the 8 lanes of a row
-// read consecutive addresses, so the walk is (almost) conflict-free, where a contiguous 32-value
-// slice per thread puts all 64 lanes of a wave on one bank — then thread v adds the 8 partials.
-constexpr int RS = BS + 8;
-template <int NV>
-__device__ __forceinline__ void block_reduce_vec(const double (&acc)[NV], double* sm /*NV*RS*/,
-                                                 double* out /*NV, LDS*/)
-{
-    const int t = threadIdx.x;
-#pragma unroll
-    for (int v = 0; v < NV; v++)
-        sm[v * RS + t] = acc[v];
-    __syncthreads();
-    if (t < NV * 8) // NV*8 <= BS required
-    {
-        const int v = t >> 3, g = t & 7;
-        const double* p = sm + v * RS + g;
-        double s = 0;
-#pragma unroll 8
-        for (int i = 0; i < BS / 8; i++)
-            s += p[8 * i];
-        sm[v * RS + g] = s; // slots g, g+8, ... of a row are read by this thread only: no hazard
-    }
-    __syncthreads();
-    if (t < NV)
-    {
-        double s = 0;
-#pragma unroll
-        for (int g = 0; g < 8; g++)
-            s += sm[t * RS + g];
-        out[t] = s;
-    }
-    __syncthreads();
-}
-
 // index of (r,c), r<=c in the packed upper triangle of a 6x6
 __device__ __forceinline__ constexpr int tri6(int r, int c) { return r * 6 - r * (r - 1) / 2 + (c - r); }
 
 // ---------------------------------------------------------------- build: poses ---------
+// 32 accumulators per lane -> their 64-lane sums, in 32 shuffles: at every step a lane keeps one half of its live
+// values and hands the other half to its partner (lane ^ 32, 16, 8, 4, 2), so the number of live values halves while
+// the number of lanes summed doubles; a last exchange with lane ^ 1 completes the sum.  Afterwards a[0] of lane L
+// holds the sum of accumulator L >> 1 over the whole wave.  Fixed order: bit-reproducible.  (A butterfly over all 32
+// values would take 6 x 32 shuffles; through LDS the 27 x 256 values of a workgroup cost 57 KB of LDS per workgroup —
+// two workgroups per CU, which is what bounded k_build_poses: latency, not arithmetic.)
+__device__ __forceinline__ void wave_reduce32(double (&a)[32])
+{
+    const int lane = threadIdx.x & 63;
+#define CUGO_HALVE(N, OFF)                                     \
+    {                                                          \
+        const bool hi = (lane & OFF) != 0;                     \
+        _Pragma("unroll") for (int i = 0; i < N; i++)          \
+        {                                                      \
+            const double send = hi ? a[i] : a[i + N];          \
+            const double keep = hi ? a[i + N] : a[i];          \
+            a[i] = keep + __shfl_xor(send, OFF, 64);           \
+        }                                                      \
+    }
+    CUGO_HALVE(16, 32)
+    CUGO_HALVE(8, 16)
+    CUGO_HALVE(4, 8)
+    CUGO_HALVE(2, 4)
+    CUGO_HALVE(1, 2)
+#undef CUGO_HALVE
+    a[0] += __shfl_xor(a[0], 1, 64);
+}
+
 // Hpp[p] = sum w JP^T JP, bp[p] = sum w JP^T e; one workgroup per pose, one lane per edge.
 // The edge geometry comes from the 64-byte records k_build_edges left behind (Xc, e, w, camera
 // index, stereo bit): each wave fetches the records of its 64 edges with 4 load instructions
 // (4 lanes x 16 B per record: one cache line per edge instead of ~8 scattered lines for the
 // planar measurement / index / landmark gathers), parks them in LDS and every lane reads its own.
+// The 27 sums of a wave are formed in registers (wave_reduce32), the four waves' partial sums meet in 1 KB of LDS:
+// 19 KB of LDS per workgroup, so that every pose of a kitti_00-sized graph is resident at once.
+constexpr int BP_W = BS / 64;
 __global__ __launch_bounds__(BS) void k_build_poses(EV ev, const double* __restrict__ rec,
                                                     double* __restrict__ Hpp,
                                                     double* __restrict__ bp)
 {
-    extern __shared__ double smem[];
-    double* red = smem;            // 27*RS
-    double* out = smem + 27 * RS;  // 27 (+5 pad)
-    // per wave: 64 records x 9 doubles, inside the reduction area (not in use before the barrier below)
-    double* stage = smem + (threadIdx.x >> 6) * (64 * 9);
+    __shared__ double stage_all[BP_W][64 * 9]; // per wave: 64 records x 9 doubles
+    __shared__ double wsum[BP_W][32];
+    double* stage = stage_all[threadIdx.x >> 6];
     const int p = blockIdx.x;
     const int lane = threadIdx.x & 63;
-    double acc[27];
+    double acc[32];
 #pragma unroll
-    for (int i = 0; i < 27; i++)
+    for (int i = 0; i < 32; i++)
         acc[i] = 0;
     const int i0 = ev.pose_ptr[p], i1 = ev.pose_ptr[p + 1];
     const double2* rec2 = reinterpret_cast<const double2*>(rec);
-    for (int ibase = i0 + (threadIdx.x & ~63); ibase < i1; ibase += BS)
-    { // wave-uniform loop: this wave's 64 list entries [ibase, ibase + 64)
-        const int i = ibase + lane;
-        const int e = ev.pose_edge[min(i, i1 - 1)];
+    // The work of a workgroup is a chain of dependent round trips (list entry -> record -> arithmetic), not
+    // arithmetic: the entries of TWO rounds (this wave's 64 list entries [ibase, ibase + 64) and the 64 a workgroup
+    // width further on) are fetched together, then the records of both, and only then are they consumed — a pose
+    // with up to 512 edges (the kitti_00 shape: ~424) pays the chain once.
+    auto fetch = [&](int e, double2 (&v)[4]) {
 #pragma unroll
         for (int q = 0; q < 4; q++)
         { // 16 records per instruction: lanes 4j..4j+3 read the 4 quarters of record 16q + j
             const int j = 16 * q + (lane >> 2), part = lane & 3;
             const int ej = __shfl(e, j, 64);
-            const double2 v = rec2[4 * (size_t)ej + part];
-            stage[9 * j + 2 * part] = v.x;
-            stage[9 * j + 2 * part + 1] = v.y;
+            v[q] = rec2[4 * (size_t)ej + part];
+        }
+    };
+    auto consume = [&](const double2 (&v)[4], int i) {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            const int j = 16 * q + (lane >> 2), part = lane & 3;
+            stage[9 * j + 2 * part] = v[q].x;
+            stage[9 * j + 2 * part + 1] = v[q].y;
         }
         wave_sync_lds();
         if (i < i1)
@@ -647,18 +647,44 @@ __global__ __launch_bounds__(BS) void k_build_poses(EV ev, const double* __restr
             }
         }
         wave_sync_lds(); // the slot is refilled by the next round
+    };
+    for (int ibase = i0 + (threadIdx.x & ~63); ibase < i1; ibase += 2 * BS)
+    { // wave-uniform loop
+        const int ia = ibase + lane, ib = ia + BS;
+        const bool second = ibase + BS < i1; // (wave-uniform)
+        const int ea = ev.pose_edge[min(ia, i1 - 1)];
+        const int eb = ev.pose_edge[min(ib, i1 - 1)];
+        double2 va[4], vb[4];
+        fetch(ea, va);
+        fetch(eb, vb); // (unconditional: the clamped entries are valid, and a branch here would serialise the two chains)
+        consume(va, ia);
+        if (second)
+            consume(vb, ib);
     }
-    __syncthreads(); // every wave is done with its staging slot: the area becomes the reduction buffer
-    block_reduce_vec<27>(acc, red, out);
+    wave_reduce32(acc);
+    if (!(lane & 1))
+        wsum[threadIdx.x >> 6][lane >> 1] = acc[0];
+    __syncthreads();
     const int t = threadIdx.x;
-    if (t < 36)
+    if (t < 42)
     {
-        const int r = t % 6, c = t / 6;
-        const int a = r < c ? r : c, b = r < c ? c : r;
-        Hpp[36 * (size_t)p + t] = out[tri6(a, b)];
+        int k;
+        if (t < 36)
+        {
+            const int r = t % 6, c = t / 6;
+            k = tri6(r < c ? r : c, r < c ? c : r);
+        }
+        else
+            k = 21 + (t - 36);
+        double sum = wsum[0][k];
+#pragma unroll
+        for (int q = 1; q < BP_W; q++) // wave order
+            sum += wsum[q][k];
+        if (t < 36)
+            Hpp[36 * (size_t)p + t] = sum;
+        else
+            bp[6 * (size_t)p + (t - 36)] = sum;
     }
-    else if (t < 42)
-        bp[6 * (size_t)p + (t - 36)] = out[21 + (t - 36)];
 }
 
 // ---------------------------------------------------------------- max diagonal ---------
@@ -2223,8 +2249,7 @@ static void launch_build_t(hipStream_t s, const cugo_edges& e, const double* d_p
     if (d_chi)
         CUGO_LAUNCH(k_sum_partials, dim3(1), dim3(SP_BS), 0, s, rs.d_partials, nb, d_chi);
     if (ev.P > 0)
-        CUGO_LAUNCH(k_build_poses, dim3(ev.P), dim3(BS),
-                           (27 * RS + 32) * sizeof(double), s, ev, d_rec, d_Hpp, d_bp);
+        CUGO_LAUNCH(k_build_poses, dim3(ev.P), dim3(BS), 0, s, ev, d_rec, d_Hpp, d_bp);
 }
 
 void launch_build(hipStream_t s, const cugo_edges& e, const double* d_poses, const double* d_lms,

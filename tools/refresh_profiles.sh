@@ -3,7 +3,7 @@
 # trace domains besides --kernel-trace).  Afterwards: tools/collect_profiles.sh copies the summaries
 # into profiles/.   gpurun --timeout 1100 -- bash tools/refresh_profiles.sh
 set -e
-R=${R:-r03}
+R=${R:-r04}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests.log 2>&1

@@ -989,17 +989,31 @@ void Engine::initialize(FlatGraph& g)
                 if (src[i] >= 0)
                     h[ep[i]]++;
         });
-        for (int q = 0; q < m.Pall; q++)
-        {
-            int32_t run = m.h_pose_ptr[q];
-            for (unsigned t = 0; t < nt; t++)
+        // per pose: its total over the threads' histograms (parallel over poses), the prefix sum over poses, then the
+        // first output position of every (pose, thread) — thread order inside a pose keeps the slot order
+        parallel_chunks((size_t)m.Pall, 2048, [&](size_t qa, size_t qb, unsigned) {
+            for (size_t q = qa; q < qb; q++)
             {
-                const int32_t c = hist[t][q];
-                hist[t][q] = run; // first output position of thread t for pose q
-                run += c;
+                int32_t c = 0;
+                for (unsigned t = 0; t < nt; t++)
+                    c += hist[t][q];
+                m.h_pose_ptr[q + 1] = c;
             }
-            m.h_pose_ptr[q + 1] = run;
-        }
+        });
+        for (int q = 0; q < m.Pall; q++)
+            m.h_pose_ptr[q + 1] += m.h_pose_ptr[q];
+        parallel_chunks((size_t)m.Pall, 2048, [&](size_t qa, size_t qb, unsigned) {
+            for (size_t q = qa; q < qb; q++)
+            {
+                int32_t run = m.h_pose_ptr[q];
+                for (unsigned t = 0; t < nt; t++)
+                {
+                    const int32_t c = hist[t][q];
+                    hist[t][q] = run; // first output position of thread t for pose q
+                    run += c;
+                }
+            }
+        });
         parallel_chunks((size_t)E, serial_below, [&](size_t a, size_t b, unsigned t) {
             std::vector<int32_t>& pos = hist[t];
             for (size_t i = a; i < b; i++)

@@ -451,8 +451,8 @@ void CudaGraphOptimisationImpl::optimize(int niterations)
         es->setDirtyState(true);
     }
     // ref: finalize(): estimates go back into the user's vertex objects
-    std::vector<double> poses, lms;
-    engine_->download(poses, lms);
+    std::vector<double>&poses = downloadPoses_, &lms = downloadLms_; // (kept between calls: 24 MB of fresh pages per
+    engine_->download(poses, lms);                                    //  call on the 1 M-landmark graph otherwise)
     lap("outliers + download");
     for (BaseVertexSet* vs : vertexSets)
         vs->scatterEstimates(vs->isMarginilised() ? lms.data() : poses.data());

@@ -173,6 +173,7 @@ private:
     // edges handed to the engine at initialize(), in that order (outlier rejection maps back)
     std::vector<BaseEdge*> flatEdges_;
     std::vector<BaseEdgeSet*> flatEdgeSets_;
+    std::vector<double> downloadPoses_, downloadLms_; // staging of the estimates that optimize() writes back
 };
 
 } // namespace cugo

@@ -493,7 +493,7 @@ def main():
                       "fits": bool(gsum <= passA_ms * 1.001 and gsum <= elapsed / args.steps * 1e3 * 1.02),
                       "note": "groups: one event per group boundary in a pass of its own (their sum is the device time "
                               "between the first and the last event of optimize()); kernels: event pairs per launch in "
-                              "another pass, the measured cost of a pair taken off"}
+                              "another pass (upper bounds of the kernel durations: a pair brackets the dispatch as well)"}
         rated = {k: v for k, v in kernels.items() if "achieved" in v}
         if rated:
             dominant = max(rated, key=lambda k: rated[k]["total_ms"])

@@ -1775,10 +1775,12 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
                     cpu_relax();
                     if ((spin & 0x3FF) != 0)
                         continue;
-                    // a trial of a large graph takes milliseconds: after the first 200 us the core is offered to
-                    // others between polls, and every ~10 ms the stream is asked whether it is still working
+                    // a trial takes 1 ms (kitti_00 shape) to 3.5 ms (10k graph): the host spins through that — on a
+                    // loaded host a yield hands the core away for a scheduler quantum, longer than the trial —; a
+                    // wait that lasts longer than 2 ms offers the core to others between polls, and every ~10 ms
+                    // the stream is asked whether it is still working
                     const auto now = Clock::now();
-                    if (now - w0 > std::chrono::microseconds(200))
+                    if (now - w0 > std::chrono::milliseconds(2))
                         std::this_thread::yield();
                     if (now < next_query)
                         continue;

@@ -459,6 +459,36 @@ def test_structure_build_beside_initialize_is_the_synchronous_one(oracle_lib, mo
     assert runs[0][2][2]["hsc_blocks"] >= runs[0][0][2]["hsc_blocks"]
 
 
+def test_initialize_again_with_more_landmarks_while_the_helper_may_still_run(oracle_lib):
+    """initialize() starts a helper thread that reads the co-visibility lists, P and L; a second
+    initialize() right behind it — on a graph that has GROWN (more landmarks, more edges: every one of those arrays is
+    reallocated) — must wait for that helper before it touches them (join_pattern() is its first statement).  The
+    result is that of a fresh optimiser on the grown graph, bit for bit; repeated, because the window is a race."""
+    big = cugo.synth(120, 2600, 10800, seed=23, n_loop_closures=40)
+    cam = np.asarray(big["e_cam"], np.float64).reshape(-1, 5)
+    big["e_cam"] = cam if len(cam) > 1 else np.tile(cam, (len(big["e_pose"]), 1))
+    keep = big["e_lm"] < 1500
+    small = dict(big)
+    for k in ("e_pose", "e_lm", "e_stereo", "e_meas", "e_omega", "e_cam"):
+        small[k] = big[k][keep]
+    small["lm"], small["lm_fixed"] = big["lm"][:1500], big["lm_fixed"][:1500]
+    fresh = run_graph(big, 4)
+    rest = ~keep
+    for _ in range(5):
+        g = cugo.graph_from_arrays(small)
+        g.initialize()                                    # helper thread: pattern + symbolic for 1 500 landmarks
+        g.add_landmarks(np.arange(1500, 2600, dtype=np.int32), big["lm"][1500:], big["lm_fixed"][1500:])
+        for dim in (2, 3):
+            k = np.flatnonzero(rest & (big["e_stereo"].astype(bool) == (dim == 3)))
+            g.add_edges(dim, big["e_pose"][k], big["e_lm"][k], big["e_meas"][k][:, :dim], big["e_omega"][k], big["e_cam"][k])
+        g.initialize()                                    # at once: L changed from 1 500 to 2 600
+        g.optimize(4)
+        st, pose = g.stats(), g.poses()
+        g.close()
+        assert [s["chi2"] for s in st] == [s["chi2"] for s in fresh["stats"]]
+        assert np.array_equal(pose, fresh["pose"])
+
+
 @pytest.mark.parametrize("shape", ["mixed_fixed", "medium", "dense_ring", "all_landmarks_fixed"])
 def test_device_structure_build_equals_host_build(oracle_lib, shape, monkeypatch):
     """the Hsc pattern and the contribution lists built on the device (pairs per landmark, stable

@@ -181,42 +181,27 @@ def main():
                         # the refused init itself — every rank must then exit non-zero, see below)
         if os.environ.get("CUGO_BENCH_FORCE_GLOO") == "1":
             can = 0.0   # rehearsal of the fallback path on a box that could run RCCL
-        pre = torch.tensor([can])
-        dist.all_reduce(pre, op=dist.ReduceOp.MIN)
-        if float(pre.item()) < 0.5:
-            comm = None
+        box = [cugo.comm_unique_id() if (rank == 0 and can > 0.5) else None]
+        dist.broadcast_object_list(box, src=0)
+
+        def make_comm():
+            if os.environ.get("CUGO_BENCH_FAIL_RANK") == str(rank):   # test hook: this rank fails its init
+                raise RuntimeError("CUGO_BENCH_FAIL_RANK: induced failure")
+            if os.environ.get("CUGO_BENCH_HANG_RANK") == str(rank):   # test hook: this rank never returns
+                threading.Event().wait()
+            cugo.set_device(local_rank % ndev)   # (the current device is per thread)
+            return cugo.Comm(box[0], rank, world)
+        how, comm = cugo.create_comm_agreed(dist, rank, world, make_comm, can_try=can > 0.5,
+                                            deadline_s=float(os.environ.get("CUGO_BENCH_COMM_TIMEOUT", "180")),
+                                            log=lambda m: sys.stderr.write(m + "\n"))
+        if how == "failed":
+            sys.stderr.write("rank %d: not every rank has a communicator: all ranks exit\n" % rank)
+            sys.stderr.flush()
+            os._exit(3)
+        if how == "fallback":
             exchange_form = ("FALLBACK: callback + torch.distributed gloo through host memory (librccl or one GPU per "
                              "rank not available on every rank): a rehearsal of the sharded path, not a scaling point")
         else:
-            box = [cugo.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            result = {}
-
-            def init_comm():
-                try:
-                    if os.environ.get("CUGO_BENCH_FAIL_RANK") == str(rank):   # test hook: this rank fails its init
-                        raise RuntimeError("CUGO_BENCH_FAIL_RANK: induced failure")
-                    if os.environ.get("CUGO_BENCH_HANG_RANK") == str(rank):   # test hook: this rank never returns
-                        threading.Event().wait()
-                    cugo.set_device(local_rank % ndev)   # (the current device is per thread)
-                    result["comm"] = cugo.Comm(box[0], rank, world)
-                except Exception as e:  # noqa: BLE001
-                    result["error"] = e
-            deadline = float(os.environ.get("CUGO_BENCH_COMM_TIMEOUT", "180"))
-            th = threading.Thread(target=init_comm, daemon=True)
-            th.start()
-            th.join(deadline)
-            mine_ok = 1.0 if ("comm" in result and not th.is_alive()) else 0.0
-            if mine_ok < 0.5:
-                sys.stderr.write("rank %d: ncclCommInitRank %s\n" % (
-                    rank, "failed: %s" % result["error"] if "error" in result else "did not return within %.0f s" % deadline))
-            ok = torch.tensor([mine_ok])
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if float(ok.item()) < 0.5:
-                sys.stderr.write("rank %d: not every rank has a communicator: all ranks exit\n" % rank)
-                sys.stderr.flush()
-                os._exit(3)
-            comm = result["comm"]
             exchange_form = ("native: RCCL on the solver's stream inside libcugo_hip.so (ncclAllReduce; with rank-owned "
                              "elimination subtrees ncclReduceScatter + grouped ncclBroadcast)")
     views = {}

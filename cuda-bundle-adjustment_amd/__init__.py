@@ -119,6 +119,46 @@ class Comm:
             self._c = C.c_void_p()
 
 
+def create_comm_agreed(dist, rank, world, make_comm, can_try=True, deadline_s=180.0, log=None):
+    """Collective creation of the RCCL communicator of a multi-process job WITHOUT the two ways such a step hangs a
+    job: a rank that cannot even try (no librccl, no device of its own) while the others block inside
+    ncclCommInitRank waiting for it, and a rank whose init never returns.  `dist`: an initialised torch.distributed
+    group used as the rendezvous (gloo); `make_comm()`: creates this rank's communicator (cugo.Comm(...)), called in
+    a helper thread.  Every rank first reports — without entering a collective — whether it can try (`can_try`); only
+    if ALL can, they create their communicators, each with a deadline, and then agree on the outcome.
+
+    Returns ("native", comm) when every rank has a communicator, ("fallback", None) when some rank could not try
+    (nobody entered the collective: the job may go on with the host-staged exchange), ("failed", None) when some
+    rank's init raised or missed the deadline — the caller must then END THE PROCESS on every rank (os._exit: a
+    thread stuck inside RCCL cannot be joined, and the ranks that did get a communicator must not wait for the
+    others in the next collective)."""
+    import threading
+    import torch
+    pre = torch.tensor([1.0 if can_try else 0.0])
+    dist.all_reduce(pre, op=dist.ReduceOp.MIN)
+    if float(pre.item()) < 0.5:
+        return "fallback", None
+    result = {}
+
+    def run():
+        try:
+            result["comm"] = make_comm()
+        except BaseException as e:  # noqa: BLE001 (reported below; the agreement decides what happens)
+            result["error"] = e
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    th.join(deadline_s)
+    mine_ok = "comm" in result and not th.is_alive()
+    if not mine_ok and log is not None:
+        log("rank %d: communicator %s" % (rank, "failed: %s" % result["error"] if "error" in result
+                                          else "did not come back within %.0f s" % deadline_s))
+    ok = torch.tensor([1.0 if mine_ok else 0.0])
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if float(ok.item()) < 0.5:
+        return "failed", None
+    return "native", result["comm"]
+
+
 def comm_unique_id():
     """rank 0 of a multi-GPU job: the RCCL unique id to hand to every rank (bytes)"""
     buf = C.create_string_buffer(UNIQUE_ID_BYTES)

@@ -1137,6 +1137,35 @@ def test_native_comm_single_rank_runs_the_owned_form(oracle_lib, monkeypatch):
     assert xs["calls"] >= 3 + 3 * 6 and xs["calls"] <= 3 + 3 * trials + 3
 
 
+def test_kernel_group_times_add_up_to_the_device_time_of_optimize(oracle_lib):
+    """cugo_graph_set_kernel_timing(2) — one HIP event per group boundary (what bench.py's `kernel_groups` are made
+    of): a group's time runs to the next group's event, so the groups add up to the device time between the first and
+    the last event of optimize() and cannot exceed its wall time (round 3 summed event PAIRS per kernel into group
+    totals that exceeded the step).  Mode 1 (a pair round every launch) reports kernels, with the same launch counts
+    in every run."""
+    import time
+    d, _ = synth_problem(oracle_lib, 400, 8000, 33000, seed=11, lc=200)
+    g = cugo.graph_from_arrays(d)
+    g.initialize(); g.optimize(1)
+    g.set_poses(np.arange(400, dtype=np.int32), d["pose"]); g.set_landmarks(np.arange(8000, dtype=np.int32), d["lm"])
+    g.initialize()
+    g.set_kernel_timing(2)
+    t0 = time.perf_counter()
+    g.optimize(6)
+    wall_ms = (time.perf_counter() - t0) * 1e3
+    groups = g.kernel_times()
+    chi_timed = [s["chi2"] for s in g.stats()]
+    assert set(groups) >= {"build", "schur", "cholesky", "backsubst_update", "errors"} and not any(k.startswith("k_") for k in groups)
+    total = sum(v["ms"] for v in groups.values())
+    assert 0.3 * wall_ms < total <= wall_ms * 1.001, (total, wall_ms, groups)
+    assert groups["cholesky"]["ms"] > groups["errors"]["ms"]
+    g.set_kernel_timing(0)
+    g.set_poses(np.arange(400, dtype=np.int32), d["pose"]); g.set_landmarks(np.arange(8000, dtype=np.int32), d["lm"])
+    g.initialize(); g.optimize(6)
+    assert [s["chi2"] for s in g.stats()] == chi_timed      # timing changes nothing
+    g.close()
+
+
 def test_sharded_two_ranks_on_one_gpu_matches_single(oracle_lib):
     """landmark-sharded path with world=2 and world=3 emulated in ONE process: the graphs take turns
     and exchange through host memory. Exercises partial Hsc/bsc/chi/scale sums + replicated LL^T."""

@@ -96,3 +96,66 @@ def test_two_rank_gloo_exchange_matches_unsharded(tmp_path):
         assert vals[:4] == [1, 1, 1, 1] and vals[6] == 1, vals
         ranges.append(vals[4:6])
     assert ranges[0][0] == 0 and ranges[0][1] == ranges[1][0] and ranges[1][1] == 500
+
+
+def _agree_worker(rank, world, port, out_dir):
+    for p in (HERE, ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import threading
+    import time
+    import torch.distributed as dist
+    cugo = importlib.import_module("cuda-bundle-adjustment_amd")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = []
+    log = []
+
+    def ok_comm():
+        calls.append("ok")
+        return "comm-of-rank-%d" % rank
+
+    def failing():
+        calls.append("fail")
+        if rank == 1:
+            raise RuntimeError("induced")
+        return "comm-of-rank-%d" % rank
+
+    def hanging():
+        calls.append("hang")
+        if rank == 1:
+            threading.Event().wait()   # never comes back (a daemon thread: the process can still end)
+        return "comm-of-rank-%d" % rank
+    res = []
+    res.append(cugo.create_comm_agreed(dist, rank, world, ok_comm, can_try=True, deadline_s=20, log=log.append))
+    n_before = len(calls)
+    res.append(cugo.create_comm_agreed(dist, rank, world, ok_comm, can_try=(rank == 0), deadline_s=20, log=log.append))
+    not_entered = len(calls) == n_before          # nobody may enter the collective when a rank cannot try
+    res.append(cugo.create_comm_agreed(dist, rank, world, failing, can_try=True, deadline_s=20, log=log.append))
+    t0 = time.perf_counter()
+    res.append(cugo.create_comm_agreed(dist, rank, world, hanging, can_try=True, deadline_s=2.0, log=log.append))
+    waited = time.perf_counter() - t0
+    with open(os.path.join(out_dir, "agree%d.txt" % rank), "w") as f:
+        f.write("%s|%s|%s|%s|%d|%.2f|%d\n" % (res[0][0], res[1][0], res[2][0], res[3][0], not_entered, waited,
+                                              sum("rank 1" in m for m in log)))
+        f.write(repr(res[0][1]) + "\n")
+    dist.destroy_process_group()
+
+
+def test_communicator_creation_is_agreed_on_and_never_hangs(tmp_path):
+    """cugo.create_comm_agreed (what bench.py --gpus N puts round cugo_comm_create), world size 2 over gloo on the CPU
+    with stand-ins for the RCCL call: every rank gets a communicator -> "native" on both; one rank cannot even try ->
+    "fallback" on both and NOBODY enters the collective; one rank's init raises -> "failed" on both; one rank's init
+    never returns -> "failed" on both once the deadline has passed (the other rank is not left waiting)."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_agree_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        lines = open(tmp_path / ("agree%d.txt" % r)).read().splitlines()
+        a, b, c, d, not_entered, waited, rank1_msgs = lines[0].split("|")
+        assert (a, b, c, d) == ("native", "fallback", "failed", "failed"), lines
+        assert int(not_entered) == 1
+        assert 1.5 <= float(waited) < 15.0, waited
+        assert lines[1] == repr("comm-of-rank-%d" % r)
+        assert int(rank1_msgs) == (2 if r == 1 else 0)   # the failing rank says why, the other one has nothing to say

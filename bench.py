@@ -50,7 +50,7 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_PEAK_TFLOPS = 78.6    # MI355X fp64 vector / matrix peak
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 
 
 def survey_bytes(group, E, P, L, B):

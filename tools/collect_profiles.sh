@@ -10,7 +10,12 @@ for W in kitti00 synth10k; do
   cp gpurun_out/prof_${R}_${W}_summary.txt profiles/${R}_kernel_stats_summary$sfx.txt
   cp "$(ls -t gpurun_out/prof_${R}_$W/*/*_kernel_stats.csv | head -1)" profiles/${R}_kernel_stats$sfx.csv
 done
-for W in kitti00 synth10k; do for V in mfma gather strip rows; do cp gpurun_out/pmc_schur_${W}_${V}.txt profiles/${R}_pmc_schur_${W}_${V}.txt; done; done
+# (the Schur-form counter passes are a run of their own — tools/pmc_schur.sh; copied only if that run is newer than
+# the kernel trace of this round, so that a round that did not repeat them does not re-label old files)
+for W in kitti00 synth10k; do for V in mfma gather strip rows; do
+  f=gpurun_out/pmc_schur_${W}_${V}.txt
+  if [ -f $f ] && [ $f -nt gpurun_out/prof_${R}_kitti00_summary.txt ]; then cp $f profiles/${R}_pmc_schur_${W}_${V}.txt; fi
+done; done
 R=$R python - <<'PY'
 import json, os
 R = os.environ["R"]

@@ -35,7 +35,7 @@ class BaseEdgeSet;
 // edge order (and with it every floating-point sum) is then the same from run to run, which an unordered_set of
 // pointers does not give.  Storage: the edges in a vector; from 32 elements on an open-addressing index (pointer ->
 // position) answers find / count / the duplicate test of insert in O(1).  erase keeps the order (O(n) move) and
-// lets the index be rebuilt by the next lookup.
+// re-indexes; the index is maintained by the mutating members only, so lookups are const in fact as well as in name.
 class EdgeContainer
 {
 public:
@@ -56,8 +56,8 @@ public:
     {
         if (v_.size() < kIndexFrom)
             return std::find(v_.begin(), v_.end(), e);
-        if (!indexed_)
-            rebuild();
+        // (the index is kept by every mutating member: concurrent lookups on a const container are safe, as they
+        // are on the reference's std::unordered_set)
         const std::size_t mask = tab_.size() - 1;
         for (std::size_t h = hash(e) & mask;; h = (h + 1) & mask)
         {
@@ -77,7 +77,7 @@ public:
         v_.push_back(e);
         if (v_.size() >= kIndexFrom)
         {
-            if (!indexed_ || 2 * v_.size() > tab_.size())
+            if (tab_.empty() || 2 * v_.size() > tab_.size())
                 rebuild();
             else
                 put(e, (uint32_t)v_.size());
@@ -101,14 +101,18 @@ public:
     }
     iterator erase(iterator pos)
     {
-        indexed_ = false; // positions behind `pos` move: the next lookup rebuilds the index
-        return v_.erase(pos);
+        const std::size_t at = (std::size_t)(pos - v_.begin());
+        v_.erase(pos); // (keeps the order: O(n), like the re-indexing of the positions behind it)
+        if (v_.size() >= kIndexFrom)
+            rebuild();
+        else
+            tab_.clear();
+        return v_.begin() + at;
     }
     void clear() noexcept
     {
         v_.clear();
         tab_.clear();
-        indexed_ = false;
     }
     void reserve(size_type n) { v_.reserve(n); }
 
@@ -120,7 +124,7 @@ private:
         x ^= x >> 33, x *= 0xff51afd7ed558ccdull, x ^= x >> 29;
         return (std::size_t)x;
     }
-    void put(BaseEdge* e, uint32_t pos1) const
+    void put(BaseEdge* e, uint32_t pos1)
     {
         const std::size_t mask = tab_.size() - 1;
         std::size_t h = hash(e) & mask;
@@ -128,7 +132,7 @@ private:
             h = (h + 1) & mask;
         tab_[h] = pos1;
     }
-    void rebuild() const
+    void rebuild()
     {
         std::size_t cap = 64;
         while (cap < 4 * v_.size()) // load factor between 1/4 and 1/2
@@ -136,11 +140,9 @@ private:
         tab_.assign(cap, 0);
         for (std::size_t i = 0; i < v_.size(); i++)
             put(v_[i], (uint32_t)(i + 1));
-        indexed_ = true;
     }
     std::vector<BaseEdge*> v_;
-    mutable std::vector<uint32_t> tab_; // open addressing, linear probing: position + 1 of the edge, 0 = free
-    mutable bool indexed_ = false;
+    std::vector<uint32_t> tab_; // open addressing, linear probing: position + 1 of the edge, 0 = free; kept from 32 elements on
 };
 
 // ------------------------------------------------------------------ change tracking ----

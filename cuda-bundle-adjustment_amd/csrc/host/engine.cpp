@@ -120,6 +120,11 @@ struct Engine::Impl : cugo_k::LaunchHook
     DevBuf<double> d_poses[2], d_lms[2];
     int cur = 0;
     DevBuf<double> d_Hpp, d_b, d_Hll, d_Hpl, d_T, d_invHll, d_x, d_sys, d_tmp, d_scal;
+    // fused iteration (Options::pose_schur): {invHll, bl} of every landmark in a 128-byte slot for k_pose_schur; whether
+    // Hpp is the one of the current linearisation (a fused build skips its pose pass) and whether the build pass's
+    // records are still there (the error pass of a trial re-uses their memory)
+    DevBuf<double> d_lmrec;
+    bool hpp_valid = true, rec_valid = false;
     DevBuf<int32_t> d_hsc_rowptr, d_hsc_colind, d_off_ptr, d_off_ei, d_off_ej, d_fail;
     PinnedBuf<double> h_scal;
     PinnedBuf<int32_t> h_fail;
@@ -1604,6 +1609,9 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
         const bool fuse_allowed = m.opt.fuse_t;
         const bool can_fuse = fuse_allowed && !m.splan_on && m.lm_in_one_group;
         const bool fused_T = have_build ? (can_fuse && built_lambda == lambda) : (can_fuse && iteration > 0);
+        const bool ps_on = m.opt.pose_schur && can_fuse && !use_rows && !m.strip_on && !m.ev.block_f32;
+        if (ps_on && m.d_lmrec.size() < 16 * (size_t)std::max(m.L, 1))
+            m.d_lmrec.resize(16 * (size_t)std::max(m.L, 1));
         if (!have_build)
         m.timed("build", [&] {
             // chi2 of the build pass is only consumed in the first iteration (see below)
@@ -1611,7 +1619,8 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
                                  m.d_Hpp.data(), m.bp(), m.d_Hll.data(), m.bl(), m.d_Hpl.data(),
                                  m.rs(), iteration == 0 ? m.d_scal.data() : nullptr, fused_T ? lambda : -1.0,
                                  fused_T ? m.d_invHll.data() : nullptr,
-                                 fused_T && !use_rows ? m.d_T.data() : nullptr);
+                                 fused_T && !use_rows ? m.d_T.data() : nullptr, ps_on ? m.d_lmrec.data() : nullptr, ps_on);
+            m.hpp_valid = !(ps_on && fused_T), m.rec_valid = true;
         });
         have_build = false, built_lambda = -1.0;
         sync_prof(PROF_BUILD_SYSTEM, tb);
@@ -1656,8 +1665,24 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
                     cugo_k::launch_build(s, m.ev, m.d_poses[m.cur].data(), m.d_lms[m.cur].data(), m.rk,
                                          m.d_Hpp.data(), m.bp(), m.d_Hll.data(), m.bl(), m.d_Hpl.data(), m.rs(),
                                          nullptr, -1.0, nullptr, nullptr);
+                    m.hpp_valid = true, m.rec_valid = true;
                 });
                 spec_queued = false;
+            }
+            const bool trial_fused = fused_T && q == 0; // invHll and T of this lambda came with the build pass
+            if (!(trial_fused && ps_on) && !m.hpp_valid)
+            { // the build pass skipped its pose pass for a fused trial that is not this one (the predicted damping
+              // missed, or the fused trial was rejected with no speculative build behind it): Hpp and bp from the
+              // records if the error pass has not re-used their memory, else the whole build pass again
+                m.timed("build", [&] {
+                    if (m.rec_valid)
+                        cugo_k::launch_build_poses(s, m.ev, m.rs(), m.d_Hpp.data(), m.bp());
+                    else
+                        cugo_k::launch_build(s, m.ev, m.d_poses[m.cur].data(), m.d_lms[m.cur].data(), m.rk,
+                                             m.d_Hpp.data(), m.bp(), m.d_Hll.data(), m.bl(), m.d_Hpl.data(), m.rs(),
+                                             nullptr, -1.0, nullptr, nullptr);
+                    m.hpp_valid = true, m.rec_valid = true;
+                });
             }
             const size_t blkw = (m.ev.block_f32 ? 9 : 18) * (size_t)m.E;
             if (q == 0)
@@ -1671,10 +1696,12 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
             m.timed("schur", [&] {
                 cugo_k::launch_schur(s, m.ev, m.hs, lambda, 0, m.d_Hpp.data(), m.bp(),
                                      m.d_Hll.data(), m.bl(), m.d_Hpl.data(), m.d_invHll.data(),
-                                     m.splan_on || use_rows ? nullptr : m.d_T.data(), m.bsc(), m.Hsc(), fused_T && q == 0,
+                                     m.splan_on || use_rows ? nullptr : m.d_T.data(), m.bsc(), m.Hsc(), trial_fused,
                                      use_rows ? cugo_k::SchurRows{m.d_pose_rec.data(), m.max_row_nnz, nullptr, m.opt.hsc_mfma, m.opt.hsc_xcd}
                                               : cugo_k::SchurRows{nullptr, 0, m.strip_on ? m.d_off_pi.data() : nullptr,
-                                                                  m.opt.hsc_mfma, m.opt.hsc_xcd});
+                                                                  m.opt.hsc_mfma, m.opt.hsc_xcd,
+                                                                  trial_fused && ps_on ? m.d_lmrec.data() : nullptr,
+                                                                  m.d_poses[m.cur].data(), m.rs(), m.bp()});
             });
             if (sharded)
                 m.exchange_system();
@@ -1725,10 +1752,13 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
                     cugo_k::launch_errors(s, m.ev, m.d_poses[nxt].data(), m.d_lms[nxt].data(), m.rk,
                                           m.rs(), m.d_scal.data() + 2);
                 else
+                {
                     cugo_k::launch_errors_tail(s, m.ev, m.d_poses[nxt].data(), m.d_lms[nxt].data(), m.rk, m.rs(),
                                                n_scale_part, m.d_scal.data() + 2, m.d_scal.data() + 4,
                                                m.h_scal.data() + 2, (double)++m.trial_seq,
                                                reinterpret_cast<unsigned*>(m.d_fail.data() + 2));
+                    m.rec_valid = false; // (its partial sums go where the records of the build pass were)
+                }
             });
             m.last_err_buf = nxt;
             sync_prof(PROF_COMPUTE_ERROR, te);
@@ -1745,7 +1775,8 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
                     cugo_k::launch_build(s, m.ev, m.d_poses[nxt].data(), m.d_lms[nxt].data(), m.rk, m.d_Hpp.data(),
                                          m.bp(), m.d_Hll.data(), m.bl(), m.d_Hpl.data(), m.rs(), nullptr,
                                          can_fuse ? lambda_pred : -1.0, can_fuse ? m.d_invHll.data() : nullptr,
-                                         can_fuse && !use_rows ? m.d_T.data() : nullptr);
+                                         can_fuse && !use_rows ? m.d_T.data() : nullptr, ps_on ? m.d_lmrec.data() : nullptr, ps_on);
+                    m.hpp_valid = !(ps_on && can_fuse), m.rec_valid = true;
                 });
                 spec_queued = true;
             }

@@ -14,6 +14,7 @@ struct Options
     bool hsc_xcd = true;   // CUGO_HSC_XCD=0: Hsc blocks in dispatch order instead of contiguous ranges per XCD
     bool hsc_rows = false, hsc_strip = false, schur_plan = false; // CUGO_HSC_ROWS / CUGO_HSC_STRIP / CUGO_SCHUR_PLAN
     bool fuse_t = true;    // CUGO_FUSE_T=0: T = Hpl invHll always by the Schur edge kernel
+    bool pose_schur = true; // CUGO_POSE_SCHUR=0: Hsc's diagonal blocks always by k_build_poses + k_hsc_diag*, never by k_pose_schur
     bool float32 = false;  // CUGO_FLOAT32=1
     // ---- LM loop ----
     bool speculate = true, trial_event = true, trial_poll = true; // CUGO_SPECULATE / CUGO_TRIAL_EVENT / CUGO_TRIAL_POLL = 0
@@ -51,6 +52,7 @@ struct Options
         o.schur_plan = flag("CUGO_SCHUR_PLAN");
         o.hsc_rows = on("CUGO_HSC_ROWS"), o.hsc_strip = on("CUGO_HSC_STRIP");
         o.fuse_t = !off("CUGO_FUSE_T");
+        o.pose_schur = !off("CUGO_POSE_SCHUR");
         o.float32 = on("CUGO_FLOAT32");
         o.speculate = !off("CUGO_SPECULATE"), o.trial_event = !off("CUGO_TRIAL_EVENT"), o.trial_poll = !off("CUGO_TRIAL_POLL");
         o.profile = flag("CUGO_PROFILE");

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(BS) void k_build_edges(EV ev, const double* __restr
                                                     double* __restrict__ rec,
                                                     double* __restrict__ partials,
                                                     double fuse_lambda, double* __restrict__ invHll,
-                                                    S* __restrict__ T)
+                                                    S* __restrict__ T, double* __restrict__ lmrec)
 {
     // fuse_lambda >= 0 (the engine, whose slot layout keeps a landmark inside one workgroup, from the
     // second LM iteration on: the damping of the first trial is known when the build is queued): this
@@ -375,8 +375,11 @@ __global__ __launch_bounds__(BS) void k_build_edges(EV ev, const double* __restr
             chi = g.chi;
             r8[0] = g.Xc[0], r8[1] = g.Xc[1], r8[2] = g.Xc[2];
             r8[3] = g.e[0], r8[4] = g.e[1], r8[5] = g.e[2], r8[6] = g.w;
+            // {camera index, stereo bit, "takes part in the Schur complement" bit, landmark} (k_pose_schur)
+            const bool schur_act = !(fl & (CUGO_EDGE_FIXED_L | CUGO_EDGE_FIXED_P)) && l < ev.L;
             r8[7] = __longlong_as_double((long long)(ev.n_cams > 1 ? (int)ev.cam[e] : 0) |
-                                         ((long long)(in.stereo ? 1 : 0) << 16));
+                                         ((long long)(in.stereo ? 1 : 0) << 16) | ((long long)(schur_act ? 1 : 0) << 17) |
+                                         ((long long)(schur_act ? l : 0) << 32));
             double JL[3][3];
             jac_landmark(g.Xc, pose, in.cam, in.stereo, JL);
             lc = lm_contrib(JL, g, in.stereo);
@@ -465,6 +468,14 @@ __global__ __launch_bounds__(BS) void k_build_edges(EV ev, const double* __restr
             o[6] = iv.b02, o[7] = iv.b12, o[8] = iv.b22;
             double* q = ivs[threadIdx.x];
             q[0] = iv.b00, q[1] = iv.b01, q[2] = iv.b02, q[3] = iv.b11, q[4] = iv.b12, q[5] = iv.b22;
+            if (lmrec)
+            { // what the pose pass of the fused iteration (k_pose_schur) reads per edge: one 128-byte line
+                double* lr = lmrec + 16 * (size_t)l;
+                lr[0] = iv.b00, lr[1] = iv.b01, lr[2] = iv.b02, lr[3] = iv.b11, lr[4] = iv.b12, lr[5] = iv.b22;
+                lr[6] = iv.b00 * a[6] + iv.b01 * a[7] + iv.b02 * a[8]; // z = invHll bl
+                lr[7] = iv.b01 * a[6] + iv.b11 * a[7] + iv.b12 * a[8];
+                lr[8] = iv.b02 * a[6] + iv.b12 * a[7] + iv.b22 * a[8];
+            }
         }
     }
     if (e < ev.L && ev.lm_ptr[e] == ev.lm_ptr[e + 1])
@@ -686,6 +697,189 @@ __global__ __launch_bounds__(BS) void k_build_poses(EV ev, const double* __restr
             bp[6 * (size_t)p + (t - 36)] = sum;
     }
 }
+
+// ---------------------------------------------------------------- fused iteration: pose pass
+// From the second LM iteration on the build pass knows the damping of the first trial (launch_build: fuse_lambda) and
+// leaves invHll and T.  Then the diagonal block of the Schur complement, bp and bsc of a pose need no pass of their
+// own over the 144-byte T / Hpl blocks (k_hsc_diag*: two gathered blocks = four cache lines per edge) behind the pose
+// pass (k_build_poses: one 64-byte record per edge): everything about an edge follows from that record and ONE more
+// line of its landmark.  With Hpl_e = w JP^T JL (JL from the record's Xc and the rotation of the workgroup's own pose)
+// and T_e = Hpl_e invHll_l,
+//     w JP^T JP - T_e Hpl_e^T = JP^T N JP,   N = w I - w^2 JL invHll JL^T           (3 x 3, symmetric)
+//     w JP^T e  - T_e bl_l    = JP^T u,      u = w (e - JL z),  z = invHll bl       (z comes with the landmark's line)
+// so no 6 x 3 block is ever formed:  Hsc_pp = sum_e JP^T N JP,  bp = sum_e JP^T (w e),  bsc = sum_e JP^T u.
+// k_build_edges leaves {invHll (6), z (3)} of landmark l in a 128-byte slot lmrec[16 l] and the landmark index and an
+// "active" bit in the record.  One workgroup per pose, one lane per edge, eight waves: a pose of the kitti_00 shape
+// (~424 edges) is ONE round — list entry -> record -> landmark line -> arithmetic -> sums.  Replaces k_build_poses +
+// k_hsc_diag_mfma of that iteration (double storage only: the float mode rounds the stored blocks, which this form
+// never sees); Hpp is NOT written (the engine makes up for it where a rejected trial needs it).
+constexpr int PS_W = 4, PS_BS = 64 * PS_W;
+__global__ __launch_bounds__(PS_BS, 3) void k_pose_schur(EV ev, const double* __restrict__ rec,
+                                                      const double* __restrict__ lmrec,
+                                                      const double* __restrict__ poses,
+                                                      const int32_t* __restrict__ rowptr, double lambda_diag,
+                                                      double* __restrict__ Hsc, double* __restrict__ bp,
+                                                      double* __restrict__ bsc)
+{
+    __shared__ double stage_all[PS_W][64 * 9]; // per wave: 64 records x 9 doubles
+    __shared__ double wsum[PS_W][34];
+    const int p = xcd_contiguous_item(ev.P);
+    if (p >= ev.P)
+        return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double* stage = stage_all[w];
+    // the rotation of the pose: formed once, parked in LDS and re-read by every round (nine values per lane that would
+    // otherwise sit in registers for the whole kernel, next to 33 accumulators)
+    __shared__ double Rs[9];
+    if (threadIdx.x == 0)
+    {
+        double R0[3][3];
+        quat_to_rot(poses + 7 * (size_t)p, R0);
+#pragma unroll
+        for (int a = 0; a < 9; a++)
+            Rs[a] = R0[a / 3][a % 3];
+    }
+    __syncthreads();
+    double acc[32], acc32 = 0;
+#pragma unroll
+    for (int i = 0; i < 32; i++)
+        acc[i] = 0;
+    const int i0 = ev.pose_ptr[p], i1 = ev.pose_ptr[p + 1];
+    const double2* rec2 = reinterpret_cast<const double2*>(rec);
+    for (int ibase = i0 + 64 * w; ibase < i1; ibase += PS_BS)
+    { // wave-uniform loop
+        const int i = ibase + lane;
+        const int e = ev.pose_edge[min(i, i1 - 1)];
+        double2 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+        { // 16 records per instruction: lanes 4j..4j+3 read the 4 quarters of record 16q + j
+            const int j = 16 * q + (lane >> 2), part = lane & 3;
+            const int ej = __shfl(e, j, 64);
+            v[q] = rec2[4 * (size_t)ej + part];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            const int j = 16 * q + (lane >> 2), part = lane & 3;
+            stage[9 * j + 2 * part] = v[q].x;
+            stage[9 * j + 2 * part + 1] = v[q].y;
+        }
+        wave_sync_lds();
+        const double* r = stage + 9 * lane;
+        const double Xc[3] = {r[0], r[1], r[2]};
+        const double wgt = i < i1 ? r[6] : 0.0;
+        const double we[3] = {wgt * r[3], wgt * r[4], wgt * r[5]};
+        const long long meta = __double_as_longlong(r[7]);
+        wave_sync_lds(); // (the slot is refilled by the next round)
+        const bool stereo = ((meta >> 16) & 1) != 0;
+        const bool act = i < i1 && ((meta >> 17) & 1) != 0;
+        const double* cam = ev.cams + 5 * (int)(meta & 0xFFFF);
+        // the landmark's line (an inactive edge reads slot 0 and never uses it).  (Measured: a pose-major copy of the
+        // landmark indices, so that this line is requested together with the record instead of behind it, changes
+        // nothing — 34.5 vs 32.2 us: the kernel is bound by its 168 registers per edge, not by this chain.)
+        const double2* lr = reinterpret_cast<const double2*>(lmrec + 16 * (size_t)(act ? (int)(meta >> 32) : 0));
+        const double2 q01 = lr[0], q23 = lr[1], q45 = lr[2], z01 = lr[3];
+        const double z2 = lr[4].x;
+        double N[6], u[3]; // N: (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+        {
+            int zero = 0;
+            asm volatile("" : "+v"(zero)); // (keeps the nine reads inside the loop)
+            double R[3][3];
+#pragma unroll
+            for (int a = 0; a < 9; a++)
+                R[a / 3][a % 3] = Rs[a + zero];
+            double JL[3][3];
+            jac_landmark_R(Xc, R, cam, stereo, JL);
+            double K[3][3];
+#pragma unroll
+            for (int m = 0; m < 3; m++)
+            {
+                K[m][0] = JL[m][0] * q01.x + JL[m][1] * q01.y + JL[m][2] * q23.x;
+                K[m][1] = JL[m][0] * q01.y + JL[m][1] * q23.y + JL[m][2] * q45.x;
+                K[m][2] = JL[m][0] * q23.x + JL[m][1] * q45.x + JL[m][2] * q45.y;
+            }
+            // (an inactive edge has read slot 0 of the landmark lines — memory nobody may have written when no landmark
+            // is free: its terms are SELECTED away, 0 x whatever sits there would not do)
+            const double w2 = wgt * wgt;
+            int k = 0;
+#pragma unroll
+            for (int m = 0; m < 3; m++)
+#pragma unroll
+                for (int n = m; n < 3; n++)
+                {
+                    const double mm = K[m][0] * JL[n][0] + K[m][1] * JL[n][1] + K[m][2] * JL[n][2];
+                    N[k++] = (m == n ? wgt : 0.0) - (act ? w2 * mm : 0.0);
+                }
+#pragma unroll
+            for (int m = 0; m < 3; m++)
+            {
+                const double jz = JL[m][0] * z01.x + JL[m][1] * z01.y + JL[m][2] * z2;
+                u[m] = we[m] - (act ? wgt * jz : 0.0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0); // (JL, K and the landmark's line are dead before JP exists: registers)
+        double JP[3][6];
+        jac_pose(Xc, cam, stereo, JP);
+        // (the right-hand sides first: we and u are dead before the 21 block entries are formed)
+#pragma unroll
+        for (int rr = 0; rr < 6; rr++)
+        {
+            acc[21 + rr] += JP[0][rr] * we[0] + JP[1][rr] * we[1] + JP[2][rr] * we[2];
+            const double bs = JP[0][rr] * u[0] + JP[1][rr] * u[1] + JP[2][rr] * u[2];
+            if (rr < 5)
+                acc[27 + rr] += bs;
+            else
+                acc32 += bs;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        int k = 0;
+#pragma unroll
+        for (int c = 0; c < 6; c++)
+        { // column c of G = N JP, then the entries (r <= c) of JP^T G (accumulator c (c + 1) / 2 + r)
+            const double g0 = N[0] * JP[0][c] + N[1] * JP[1][c] + N[2] * JP[2][c];
+            const double g1 = N[1] * JP[0][c] + N[3] * JP[1][c] + N[4] * JP[2][c];
+            const double g2 = N[2] * JP[0][c] + N[4] * JP[1][c] + N[5] * JP[2][c];
+#pragma unroll
+            for (int rr = 0; rr <= c; rr++)
+                acc[k++] += JP[0][rr] * g0 + JP[1][rr] * g1 + JP[2][rr] * g2;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    wave_reduce32(acc);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        acc32 += __shfl_xor(acc32, off, 64);
+    if (!(lane & 1))
+        wsum[w][lane >> 1] = acc[0];
+    if (lane == 0)
+        wsum[w][32] = acc32;
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < 48)
+    {
+        int k;
+        if (t < 36)
+        { // accumulator of (r <= c): c (c + 1) / 2 + r
+            const int rr = t % 6, c = t / 6;
+            const int lo = rr < c ? rr : c, hi = rr < c ? c : rr;
+            k = hi * (hi + 1) / 2 + lo;
+        }
+        else
+            k = 21 + (t - 36);
+        double sum = wsum[0][k];
+#pragma unroll
+        for (int q = 1; q < PS_W; q++) // wave order
+            sum += wsum[q][k];
+        if (t < 36)
+            Hsc[36 * (size_t)rowptr[p] + t] = (t % 6 == t / 6) ? sum + lambda_diag : sum;
+        else if (t < 42)
+            bp[6 * (size_t)p + (t - 36)] = sum;
+        else
+            bsc[6 * (size_t)p + (t - 42)] = sum;
+    }
+}
+
 
 // ---------------------------------------------------------------- max diagonal ---------
 __global__ __launch_bounds__(BS) void k_max_diag(const double* __restrict__ Hpp, int nP,
@@ -2237,7 +2431,7 @@ template <typename S>
 static void launch_build_t(hipStream_t s, const cugo_edges& e, const double* d_poses, const double* d_lms,
                            cugo_robust rk, double* d_Hpp, double* d_bp, double* d_Hll, double* d_bl,
                            S* d_Hpl, ReduceScratch rs, double* d_chi, double fuse_lambda, double* d_invHll,
-                           S* d_T)
+                           S* d_T, double* d_lmrec, bool skip_poses)
 {
     const EV ev = make_ev(e);
     const Robust2 r{{rk.type, rk.delta}, {rk.type_stereo, rk.delta_stereo}};
@@ -2245,23 +2439,35 @@ static void launch_build_t(hipStream_t s, const cugo_edges& e, const double* d_p
     double* d_rec = rs.d_partials + scratch_partials(ev.E, ev.P, ev.L);
     if (nb > 0)
         CUGO_LAUNCH_T(k_build_edges, S, dim3(nb), dim3(BS), 0, s, ev, d_poses, d_lms, r, d_Hpl, d_Hll,
-                      d_bl, d_rec, rs.d_partials, d_invHll ? fuse_lambda : -1.0, d_invHll, d_T);
+                      d_bl, d_rec, rs.d_partials, d_invHll ? fuse_lambda : -1.0, d_invHll, d_T,
+                      d_invHll && d_T ? d_lmrec : nullptr);
     if (d_chi)
         CUGO_LAUNCH(k_sum_partials, dim3(1), dim3(SP_BS), 0, s, rs.d_partials, nb, d_chi);
-    if (ev.P > 0)
+    // skip_poses: the Schur complement of this lambda forms Hsc's diagonal blocks, bp and bsc from the records itself
+    // (launch_schur with SchurRows::d_lmrec); Hpp is then not written
+    if (ev.P > 0 && !(skip_poses && d_invHll && d_T && d_lmrec))
         CUGO_LAUNCH(k_build_poses, dim3(ev.P), dim3(BS), 0, s, ev, d_rec, d_Hpp, d_bp);
 }
 
 void launch_build(hipStream_t s, const cugo_edges& e, const double* d_poses, const double* d_lms,
                   cugo_robust rk, double* d_Hpp, double* d_bp, double* d_Hll, double* d_bl,
-                  void* d_Hpl, ReduceScratch rs, double* d_chi, double fuse_lambda, double* d_invHll, void* d_T)
+                  void* d_Hpl, ReduceScratch rs, double* d_chi, double fuse_lambda, double* d_invHll, void* d_T,
+                  double* d_lmrec, bool skip_poses)
 {
     if (e.block_f32)
         launch_build_t(s, e, d_poses, d_lms, rk, d_Hpp, d_bp, d_Hll, d_bl, static_cast<float*>(d_Hpl), rs, d_chi,
-                       fuse_lambda, d_invHll, static_cast<float*>(d_T));
+                       fuse_lambda, d_invHll, static_cast<float*>(d_T), d_lmrec, skip_poses);
     else
         launch_build_t(s, e, d_poses, d_lms, rk, d_Hpp, d_bp, d_Hll, d_bl, static_cast<double*>(d_Hpl), rs, d_chi,
-                       fuse_lambda, d_invHll, static_cast<double*>(d_T));
+                       fuse_lambda, d_invHll, static_cast<double*>(d_T), d_lmrec, skip_poses);
+}
+
+void launch_build_poses(hipStream_t s, const cugo_edges& e, ReduceScratch rs, double* d_Hpp, double* d_bp)
+{
+    const EV ev = make_ev(e);
+    const double* d_rec = rs.d_partials + scratch_partials(ev.E, ev.P, ev.L);
+    if (ev.P > 0)
+        CUGO_LAUNCH(k_build_poses, dim3(ev.P), dim3(BS), 0, s, ev, d_rec, d_Hpp, d_bp);
 }
 
 void launch_max_diagonal(hipStream_t s, const double* d_Hpp, int nP, const double* d_Hll, int nL,
@@ -2351,7 +2557,13 @@ static void launch_schur_t(hipStream_t s, const cugo_edges& e, const cugo_hsc_st
     else if (hs.n_blocks > 0)
         CUGO_LAUNCH_T(k_hsc_offdiag, S, dim3(div_up(hs.n_blocks, BS / 64)), dim3(BS), 0, s,
                       hs.n_blocks, hs.d_off_ptr, hs.d_off_ei, hs.d_off_ej, d_Hpl, (const S*)d_T, d_Hsc);
-    if (ev.P > 0 && rows.mfma == 1)
+    if (ev.P > 0 && have_T && rows.d_lmrec && sizeof(S) == 8)
+    { // fused iteration: diagonal blocks, bp and bsc from the build pass's records (its pose pass was skipped)
+        const double* d_rec = rows.rs.d_partials + scratch_partials(ev.E, ev.P, ev.L);
+        CUGO_LAUNCH(k_pose_schur, dim3(xcd_grid(ev.P)), dim3(PS_BS), 0, s, ev, d_rec, rows.d_lmrec, rows.d_poses,
+                      hs.d_rowptr, damp_hsc_diag ? lambda : 0.0, d_Hsc, rows.d_bp_out, d_bsc);
+    }
+    else if (ev.P > 0 && rows.mfma == 1)
         CUGO_LAUNCH_T(k_hsc_diag_mfma, S, dim3(xcd_grid(ev.P)), dim3(HM_BS), 0, s, ev,
                       hs.d_rowptr, damp_hsc_diag ? lambda : 0.0, d_Hpp, d_bp, d_bl, d_Hpl, (const S*)d_T,
                       d_Hsc, d_bsc);

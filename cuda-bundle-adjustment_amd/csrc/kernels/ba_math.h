@@ -167,13 +167,11 @@ __device__ __forceinline__ void jac_pose(const double* Xc, const double* __restr
     }
 }
 
-// Landmark Jacobian rows JL[m][3]. ref: .cu:508-513, 546-556
-__device__ __forceinline__ void jac_landmark(const double* Xc, const double* __restrict__ q,
-                                             const double* __restrict__ cam, bool stereo,
-                                             double JL[3][3])
+// Landmark Jacobian rows JL[m][3] from the rotation matrix of the pose. ref: .cu:508-513, 546-556
+__device__ __forceinline__ void jac_landmark_R(const double* Xc, const double R[3][3],
+                                               const double* __restrict__ cam, bool stereo,
+                                               double JL[3][3])
 {
-    double R[3][3];
-    quat_to_rot(q, R);
     const double X = Xc[0], Y = Xc[1], Z = Xc[2];
     const double invZ = 1.0 / Z;
     const double fu = cam[0], fv = cam[1];
@@ -200,6 +198,14 @@ __device__ __forceinline__ void jac_landmark(const double* Xc, const double* __r
             JL[2][j] = JL[0][j] - bf * R[2][j] * iZZ;
         }
     }
+}
+__device__ __forceinline__ void jac_landmark(const double* Xc, const double* __restrict__ q,
+                                             const double* __restrict__ cam, bool stereo,
+                                             double JL[3][3])
+{
+    double R[3][3];
+    quat_to_rot(q, R);
+    jac_landmark_R(Xc, R, cam, stereo, JL);
 }
 
 // symmetric 3x3 inverse by adjugate, A column-major 9 with lambda added to the diagonal.

@@ -61,7 +61,10 @@ void launch_errors(hipStream_t s, const cugo_edges& ev, const double* d_poses, c
 void launch_build(hipStream_t s, const cugo_edges& ev, const double* d_poses, const double* d_lms,
                   cugo_robust rk, double* d_Hpp, double* d_bp, double* d_Hll, double* d_bl,
                   void* d_Hpl, ReduceScratch rs, double* d_chi, double fuse_lambda = -1.0,
-                  double* d_invHll = nullptr, void* d_T = nullptr);
+                  double* d_invHll = nullptr, void* d_T = nullptr, double* d_lmrec = nullptr, bool skip_poses = false);
+
+// the pose pass of launch_build alone, from the records that pass left in the scratch (Hpp, bp)
+void launch_build_poses(hipStream_t s, const cugo_edges& ev, ReduceScratch rs, double* d_Hpp, double* d_bp);
 
 void launch_max_diagonal(hipStream_t s, const double* d_Hpp, int nP, const double* d_Hll, int nL,
                          ReduceScratch rs, double* d_out);
@@ -83,6 +86,12 @@ struct SchurRows
     // in contiguous ranges or in dispatch order
     int mfma = 1;
     bool xcd = true;
+    // fused iteration (launch_build left invHll, T and the landmark lines d_lmrec for this lambda, and skipped its pose
+    // pass): k_pose_schur forms the diagonal blocks, bp and bsc from the build pass's records in place of k_hsc_diag*
+    const double* d_lmrec = nullptr;
+    const double* d_poses = nullptr;
+    ReduceScratch rs{nullptr, 0};
+    double* d_bp_out = nullptr;
 };
 // d_pose_pos [n_edges] scratch/out: position of every slot in its pose's list; d_off_pi [M] out
 void launch_list_pos(hipStream_t s, const cugo_edges& ev, int n_list, size_t M, const int32_t* d_off_ei,

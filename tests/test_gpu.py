@@ -670,7 +670,9 @@ def test_build_pass_forming_T_on_the_side_is_bitwise_the_separate_kernel(oracle_
     first trial's damping (k_build_edges, fuse_lambda >= 0); CUGO_FUSE_T=0 keeps the separate edge
     kernel of the Schur complement.  Same arrays in, same arithmetic: bitwise the same run — also
     with float block storage (T is formed from the ROUNDED Hpl values there) and with rejected
-    trials in between (reject_8x60 takes the separate kernel for its retries)"""
+    trials in between (reject_8x60 takes the separate kernel for its retries).  (CUGO_POSE_SCHUR=0: the pose pass of the
+    fused iteration, which forms the diagonal blocks another way, has its own test below.)"""
+    monkeypatch.setenv("CUGO_POSE_SCHUR", "0")
     d, _ = synth_problem(oracle_lib, 200, 3000, 12500, seed=23, lc=100)
     g8 = np.load(golden_path("reject_8x60.npz"))
     cases = [d, {k: g8[k] for k in PROBLEM_KEYS}]
@@ -686,6 +688,36 @@ def test_build_pass_forming_T_on_the_side_is_bitwise_the_separate_kernel(oracle_
         assert [s["chi2"] for s in runs[0][0]] == [s["chi2"] for s in runs[1][0]]
         assert [s["trials"] for s in runs[0][0]] == [s["trials"] for s in runs[1][0]]
         assert np.array_equal(runs[0][1], runs[1][1]) and np.array_equal(runs[0][2], runs[1][2])
+
+
+@pytest.mark.parametrize("speculate", ["1", "0"])
+def test_fused_pose_pass_matches_the_separate_kernels(oracle_lib, speculate, monkeypatch):
+    """from the second LM iteration on, the diagonal blocks of Hsc, bp and bsc come from ONE pass over the build
+    pass's records (k_pose_schur: JP^T (w I - w^2 JL invHll JL^T) JP per edge) instead of k_build_poses +
+    k_hsc_diag_mfma over the stored T / Hpl blocks (CUGO_POSE_SCHUR=0).  Same sums in another order: chi2 of every
+    iteration within the parity tolerance of the fixture (1e-10 relative; the measured self-sensitivity for the stress
+    fixture), the same trial counts and damping, estimates within 1e-7 — on a graph with loop closures,
+    on the golden case whose trials get rejected (the retries need Hpp, which the fused build pass does not write:
+    with the speculative build switched off the whole build pass is repeated, with it the records are still there or
+    the rebuild happens anyway), and on golden cases with robust kernels, loop closures and stereo edges.  (Fixed
+    vertices, per-edge information and several cameras: the tests of those features run the fused iteration by default
+    and compare with the oracle.)"""
+    monkeypatch.setenv("CUGO_SPECULATE", speculate)
+    d, _ = synth_problem(oracle_lib, 200, 3000, 12500, seed=23, lc=100)
+    cases = [(None, d, (0, 0.0))]
+    for name in ("reject_8x60", "huber_8x80", "tukey_8x80", "loop_12x150", "small_10x200"):
+        g8 = np.load(golden_path(name + ".npz"))
+        cases.append((name, {k: g8[k] for k in PROBLEM_KEYS}, (int(g8["rk_type"]), float(g8["rk_delta"]))))
+    for name, dd, rk in cases:
+        # (the stress fixture amplifies round-off by itself: its bar is the measured one of conftest.py)
+        tol, etol = golden_tolerances(name, 8) if name else ([1e-10] * 8, 1e-9)
+        runs = []
+        for v in ("1", "0"):
+            monkeypatch.setenv("CUGO_POSE_SCHUR", v)
+            runs.append(run_graph(dd, 8, rk=rk))
+        assert_trajectories_match(runs[0]["stats"], runs[1]["stats"], tol[:len(runs[1]["stats"])])
+        np.testing.assert_allclose(runs[0]["pose"], runs[1]["pose"], rtol=0, atol=100 * etol)
+        np.testing.assert_allclose(runs[0]["lm"], runs[1]["lm"], rtol=0, atol=1000 * etol)
 
 
 def test_bitwise_reproducible(oracle_lib):

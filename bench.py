@@ -78,6 +78,9 @@ def compulsory_bytes(E, Em, Es, P, L, B, f32):
         # + write Hpl, the 64-byte edge record of the pose pass, Hll / bl
         "k_build_edges": 17.0 * E + meas + blk * E + 64.0 * E + 96.0 * L + 56.0 * P + 24.0 * L,
         "k_build_poses": 64.0 * E + 4.0 * E + 336.0 * P,
+        # the pose pass of the fused iteration: records + list entries + one {invHll, z} line per landmark;
+        # writes the diagonal block, bp and bsc of every pose
+        "k_pose_schur": 64.0 * E + 4.0 * E + 72.0 * L + 384.0 * P,
         # read Hpl, Hll, bl + write T, invHll
         "k_schur_edges": 2 * blk * E + 5.0 * E + 168.0 * L,
         # the H-side of the Schur complement reads T and Hpl of every edge once and writes B blocks;

@@ -8,5 +8,5 @@ timeout -k 10 300 python bench.py --steps 10 --warmup 2 --float32 --no-cpu-basel
 python -c "
 import json
 for f in ['kitti00','synth10k','kitti00_float32']:
-    d=json.loads(open('gpurun_out/bench_%s.json'%f).read().strip().splitlines()[-1]); print(f, d['ms_per_step'], d['config']['regimes_ms_per_step'])"
+    d=json.loads(open('gpurun_out/bench_%s.json'%f).read().strip().splitlines()[-1]); print(f, d['ms_per_step'], {k: v for k, v in d['config'].items() if k.startswith('regime_')})"
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')"

@@ -125,6 +125,7 @@ struct Engine::Impl : cugo_k::LaunchHook
     // records are still there (the error pass of a trial re-uses their memory)
     DevBuf<double> d_lmrec;
     bool hpp_valid = true, rec_valid = false;
+    PinnedBuf<double> h_pin_poses, h_pin_lms; // refresh_estimates_pinned / download_pinned
     DevBuf<int32_t> d_hsc_rowptr, d_hsc_colind, d_off_ptr, d_off_ei, d_off_ej, d_fail;
     PinnedBuf<double> h_scal;
     PinnedBuf<int32_t> h_fail;
@@ -1244,6 +1245,71 @@ void Engine::refresh_estimates(const FlatGraph& g)
         CUGO_HIP(hipStreamSynchronize(s)); // the staging vectors may change after return
     }
     prof_[PROF_INITIALIZE] += ms_since(t0);
+}
+
+double* Engine::pinned_poses()
+{
+    Impl& m = *impl_;
+    m.h_pin_poses.resize(7 * (size_t)std::max(m.Pall, 1));
+    return m.h_pin_poses.data();
+}
+double* Engine::pinned_lms()
+{
+    Impl& m = *impl_;
+    m.h_pin_lms.resize(3 * (size_t)std::max(m.Lall, 1));
+    return m.h_pin_lms.data();
+}
+
+void Engine::refresh_estimates_pinned()
+{
+    const auto t0 = Clock::now();
+    Impl& m = *impl_;
+    if (m.rank != m.init_rank || m.world != m.init_world)
+        throw std::runtime_error("cugo: refresh_estimates after the shard changed (a full initialize() is needed)");
+    m.last_err_buf = 0;
+    m.xchg_bytes = 0, m.xchg_calls = 0;
+    m.cur = 0;
+    if (!m.plan_only)
+    {
+        hipStream_t s = m.ctx.stream;
+        const size_t np = 7 * (size_t)m.Pall, nl = 3 * (size_t)m.Lall;
+        const double* hp = pinned_poses();
+        const double* hl = pinned_lms();
+        for (int b = 0; b < 2; b++)
+            m.d_poses[b].resize(np), m.d_lms[b].resize(nl);
+        if (np)
+        {
+            CUGO_HIP(hipMemcpyAsync(m.d_poses[0].data(), hp, np * sizeof(double), hipMemcpyHostToDevice, s));
+            CUGO_HIP(hipMemcpyAsync(m.d_poses[1].data(), m.d_poses[0].data(), np * sizeof(double), hipMemcpyDeviceToDevice, s));
+        }
+        if (nl)
+        {
+            CUGO_HIP(hipMemcpyAsync(m.d_lms[0].data(), hl, nl * sizeof(double), hipMemcpyHostToDevice, s));
+            CUGO_HIP(hipMemcpyAsync(m.d_lms[1].data(), m.d_lms[0].data(), nl * sizeof(double), hipMemcpyDeviceToDevice, s));
+        }
+        m.d_x.zero(s);
+        // no wait: the staging is the engine's own pinned memory; whoever gathers into it again before these copies
+        // have run queues a later copy of the whole array behind them (same stream), and that one is what counts
+    }
+    prof_[PROF_INITIALIZE] += ms_since(t0);
+}
+
+bool Engine::download_pinned(const double** poses, const double** lms)
+{
+    Impl& m = *impl_;
+    if (m.world > 1 || m.plan_only)
+        return false;
+    hipStream_t s = m.ctx.stream;
+    const size_t np = 7 * (size_t)m.Pall, nl = 3 * (size_t)m.Lall;
+    double* hp = pinned_poses();
+    double* hl = pinned_lms();
+    if (nl)
+        CUGO_HIP(hipMemcpyAsync(hl, m.d_lms[m.cur].data(), nl * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (np)
+        CUGO_HIP(hipMemcpyAsync(hp, m.d_poses[m.cur].data(), np * sizeof(double), hipMemcpyDeviceToHost, s));
+    CUGO_HIP(hipStreamSynchronize(s));
+    *poses = hp, *lms = hl;
+    return true;
 }
 
 // Hsc pattern from landmark co-visibility + contribution lists + Cholesky analysis

@@ -158,12 +158,19 @@ void CudaGraphOptimisationImpl::initialize()
             same = flattenCounts_[q].first == edgeSets[i] && flattenCounts_[q].second == edgeSets[i]->changeCount();
         if (same)
         {
+            // (straight into the engine's pinned staging: the copy to the device is then a DMA transfer nobody waits
+            // for; a plan-only optimiser has no device and no pinned memory)
+            double* hp = options.planOnly ? g.poses.data() : engine_->pinned_poses();
+            double* hl = options.planOnly ? g.lms.data() : engine_->pinned_lms();
             for (BaseVertexSet* vs : vertexSets)
-                vs->gatherEstimates(vs->isMarginilised() ? g.lms.data() : g.poses.data());
+                vs->gatherEstimates(vs->isMarginilised() ? hl : hp);
             lap("graph: estimates only");
             for (BaseEdgeSet* es : edgeSets)
                 es->setOutlierCount(0);
-            engine_->refresh_estimates(g);
+            if (options.planOnly)
+                engine_->refresh_estimates(g);
+            else
+                engine_->refresh_estimates_pinned();
             flattenReuses_++;
             lap("graph: engine refresh");
             stats_.clear();
@@ -432,6 +439,9 @@ void CudaGraphOptimisationImpl::optimize(int niterations)
         throw std::runtime_error("cugo: no HIP device in use: this optimiser is plan-only (GraphOptimisationOptions::planOnly)");
     std::vector<cugo_host::IterRecord> rec;
     engine_->optimize(niterations, rec, verbose);
+    // the walk that writes the estimates back into the vertex objects is ~0.1 ms away (behind the download): the
+    // workers of the host pool, parked during the optimisation, start waking up now
+    cugo_host::pool_prewake();
     lap("engine optimize");
     for (const auto& r : rec)
     {
@@ -451,11 +461,16 @@ void CudaGraphOptimisationImpl::optimize(int niterations)
         es->setDirtyState(true);
     }
     // ref: finalize(): estimates go back into the user's vertex objects
-    std::vector<double>&poses = downloadPoses_, &lms = downloadLms_; // (kept between calls: 24 MB of fresh pages per
-    engine_->download(poses, lms);                                    //  call on the 1 M-landmark graph otherwise)
+    const double *hp = nullptr, *hl = nullptr;
+    if (!engine_->download_pinned(&hp, &hl))
+    { // a landmark shard: the estimates are combined over the ranks first
+        std::vector<double>&poses = downloadPoses_, &lms = downloadLms_; // (kept between calls: 24 MB of fresh pages
+        engine_->download(poses, lms);                                    //  per call on the 1 M-landmark graph otherwise)
+        hp = poses.data(), hl = lms.data();
+    }
     lap("outliers + download");
     for (BaseVertexSet* vs : vertexSets)
-        vs->scatterEstimates(vs->isMarginilised() ? lms.data() : poses.data());
+        vs->scatterEstimates(vs->isMarginilised() ? hl : hp);
     lap("scatter estimates");
 }
 

@@ -9,6 +9,8 @@ namespace cugo_host
 unsigned pool_threads(); // chunks worth asking for: the CPUs of the share of this process (<= 64; CUGO_HOST_THREADS)
 // fn(ctx, c) for c in [0, chunks), spread over the pool; returns when all chunks are done
 void pool_run(unsigned chunks, void (*fn)(void*, unsigned), void* ctx);
+// announces a pool_run a few hundred microseconds ahead: parked workers wake up and wait for it spinning
+void pool_prewake();
 
 // f(begin, end, chunk) over [0, n) in contiguous chunks; a single chunk in the caller below
 // `serial_below` items.  Returns the number of chunks used.

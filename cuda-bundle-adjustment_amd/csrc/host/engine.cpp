@@ -126,6 +126,7 @@ struct Engine::Impl : cugo_k::LaunchHook
     DevBuf<double> d_lmrec;
     bool hpp_valid = true, rec_valid = false;
     PinnedBuf<double> h_pin_poses, h_pin_lms; // refresh_estimates_pinned / download_pinned
+    Clock::duration last_trial_wait{0};       // how long the host polled for the previous trial's result
     DevBuf<int32_t> d_hsc_rowptr, d_hsc_colind, d_off_ptr, d_off_ei, d_off_ej, d_fail;
     PinnedBuf<double> h_scal;
     PinnedBuf<int32_t> h_fail;
@@ -1658,6 +1659,14 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
     const bool trial_poll = !m.profile && m.opt.trial_poll;    // (CUGO_TRIAL_POLL=0: wait by event / stream synchronisation)
     bool have_build = false;      // the build pass of this iteration is already queued
     double built_lambda = -1.0;   // ... with invHll / T for this damping (< 0: none)
+    // ... and so is its Schur complement for this damping (< 0: not): the trial that ended the previous iteration took
+    // its chi2 from that build pass instead of an error pass of its own (Options::trial_from_build), and the Schur
+    // complement for the predicted damping was queued behind the reductions for the host to decide meanwhile
+    double schur_ready_lambda = -1.0;
+    // Only behind a trial whose predecessor's damping update hit the lower clamp (rho near 1: lambda / 3, the value the
+    // speculation predicts): right after a step with a smaller gain ratio the prediction usually misses, and a missed
+    // Schur complement costs more than the error pass saves (10k graph: 0.8 ms against 0.05).
+    bool prev_clamped = false;
 
     for (int iteration = 0; iteration < niterations; iteration++)
     {
@@ -1759,6 +1768,9 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
                 hash(iteration, 3, m.d_Hpl.data(), blkw);
             }
             auto ts = Clock::now();
+            const bool schur_queued = q == 0 && trial_fused && schur_ready_lambda == lambda;
+            schur_ready_lambda = -1.0;
+            if (!schur_queued)
             m.timed("schur", [&] {
                 cugo_k::launch_schur(s, m.ev, m.hs, lambda, 0, m.d_Hpp.data(), m.bp(),
                                      m.d_Hll.data(), m.bl(), m.d_Hpl.data(), m.d_invHll.data(),
@@ -1813,6 +1825,45 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
                 hash(iteration, 10, m.d_lms[nxt].data(), 3 * (size_t)m.Lall);
             }
             auto te = Clock::now();
+            const double lambda_pred = lambda * (1.0 / 3.0);
+            // the trial's chi2 out of the NEXT iteration's build pass: that pass is queued behind a first trial anyway
+            // (speculation) and computes the residuals of every edge at the trial's estimates — the error pass would
+            // compute them a launch earlier and throw them away
+            const bool from_build = m.opt.trial_from_build && speculate && !sharded && trial_poll && q == 0 &&
+                                    iteration + 1 < niterations && prev_clamped;
+            if (from_build)
+            {
+                m.timed("build", [&] {
+                    cugo_k::launch_build(s, m.ev, m.d_poses[nxt].data(), m.d_lms[nxt].data(), m.rk, m.d_Hpp.data(),
+                                         m.bp(), m.d_Hll.data(), m.bl(), m.d_Hpl.data(), m.rs(), nullptr,
+                                         can_fuse ? lambda_pred : -1.0, can_fuse ? m.d_invHll.data() : nullptr,
+                                         can_fuse && !use_rows ? m.d_T.data() : nullptr, ps_on ? m.d_lmrec.data() : nullptr, ps_on,
+                                         true);
+                    m.hpp_valid = !(ps_on && can_fuse), m.rec_valid = true;
+                });
+                m.timed("errors", [&] {
+                    cugo_k::launch_trial_tail_from_build(s, m.ev, m.rs(), n_scale_part, m.d_scal.data() + 2,
+                                                         m.d_scal.data() + 4, m.h_scal.data() + 2, (double)++m.trial_seq,
+                                                         reinterpret_cast<unsigned*>(m.d_fail.data() + 2));
+                });
+                if (can_fuse && !m.splan_on)
+                { // the Schur complement of the next iteration's first trial, should the damping be the predicted one:
+                  // the host decides while it runs
+                    m.timed("schur", [&] {
+                        cugo_k::launch_schur(s, m.ev, m.hs, lambda_pred, 0, m.d_Hpp.data(), m.bp(), m.d_Hll.data(), m.bl(),
+                                             m.d_Hpl.data(), m.d_invHll.data(), use_rows ? nullptr : m.d_T.data(), m.bsc(),
+                                             m.Hsc(), true,
+                                             use_rows ? cugo_k::SchurRows{m.d_pose_rec.data(), m.max_row_nnz, nullptr, m.opt.hsc_mfma, m.opt.hsc_xcd}
+                                                      : cugo_k::SchurRows{nullptr, 0, m.strip_on ? m.d_off_pi.data() : nullptr,
+                                                                          m.opt.hsc_mfma, m.opt.hsc_xcd,
+                                                                          ps_on ? m.d_lmrec.data() : nullptr,
+                                                                          m.d_poses[nxt].data(), m.rs(), m.bp()});
+                    });
+                    schur_ready_lambda = lambda_pred;
+                }
+                spec_queued = true;
+            }
+            else
             m.timed("errors", [&] {
                 if (sharded)
                     cugo_k::launch_errors(s, m.ev, m.d_poses[nxt].data(), m.d_lms[nxt].data(), m.rk,
@@ -1828,8 +1879,7 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
             });
             m.last_err_buf = nxt;
             sync_prof(PROF_COMPUTE_ERROR, te);
-            const double lambda_pred = lambda * (1.0 / 3.0);
-            if (speculate && q == 0 && iteration + 1 < niterations)
+            if (!from_build && speculate && q == 0 && iteration + 1 < niterations)
             {
                 if (!trial_poll && trial_event)
                 {
@@ -1867,6 +1917,7 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
                 const volatile double* seq = m.h_scal.data() + 5;
                 const auto w0 = Clock::now();
                 auto next_query = w0 + std::chrono::milliseconds(10);
+                const auto spin_limit = std::max<Clock::duration>(std::chrono::milliseconds(2), 2 * m.last_trial_wait);
                 for (unsigned long spin = 1; *seq != (double)m.trial_seq; spin++)
                 {
                     cpu_relax();
@@ -1874,10 +1925,10 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
                         continue;
                     // a trial takes 1 ms (kitti_00 shape) to 3.5 ms (10k graph): the host spins through that — on a
                     // loaded host a yield hands the core away for a scheduler quantum, longer than the trial —; a
-                    // wait that lasts longer than 2 ms offers the core to others between polls, and every ~10 ms
-                    // the stream is asked whether it is still working
+                    // wait that lasts longer than twice the previous one (at least 2 ms) offers the core to others
+                    // between polls, and every ~10 ms the stream is asked whether it is still working
                     const auto now = Clock::now();
-                    if (now - w0 > std::chrono::milliseconds(2))
+                    if (now - w0 > spin_limit)
                         std::this_thread::yield();
                     if (now < next_query)
                         continue;
@@ -1898,6 +1949,7 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
                     if (!there)
                         throw std::runtime_error("cugo: the result of an LM trial never arrived");
                 }
+                m.last_trial_wait = Clock::now() - w0;
                 std::atomic_thread_fence(std::memory_order_acquire);
             }
             else
@@ -1934,6 +1986,7 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
             {
                 const double a = 1 - std::pow(2 * rho - 1, 3);
                 lambda *= std::max(1.0 / 3.0, std::min(a, 2.0 / 3.0));
+                prev_clamped = a <= 1.0 / 3.0;
                 nu = 2.0;
                 F = Fhat;
                 m.cur = nxt; // accept: the trial buffer becomes the estimate (no pop needed)
@@ -1945,6 +1998,7 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
             {
                 lambda *= nu;
                 nu *= 2.0;
+                prev_clamped = false;
                 if (!std::isfinite(lambda) || (success && Fdiff < 1e-4))
                     break;
             }

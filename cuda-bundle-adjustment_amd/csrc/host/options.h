@@ -18,6 +18,7 @@ struct Options
     bool float32 = false;  // CUGO_FLOAT32=1
     // ---- LM loop ----
     bool speculate = true, trial_event = true, trial_poll = true; // CUGO_SPECULATE / CUGO_TRIAL_EVENT / CUGO_TRIAL_POLL = 0
+    bool trial_from_build = true; // CUGO_TRIAL_FROM_BUILD=0: every trial ends with an error pass of its own
     bool profile = false;  // CUGO_PROFILE
     // ---- initialize() / structure ----
     bool init_timing = false;       // CUGO_INIT_TIMING
@@ -55,6 +56,7 @@ struct Options
         o.pose_schur = !off("CUGO_POSE_SCHUR");
         o.float32 = on("CUGO_FLOAT32");
         o.speculate = !off("CUGO_SPECULATE"), o.trial_event = !off("CUGO_TRIAL_EVENT"), o.trial_poll = !off("CUGO_TRIAL_POLL");
+        o.trial_from_build = !off("CUGO_TRIAL_FROM_BUILD");
         o.profile = flag("CUGO_PROFILE");
         o.init_timing = flag("CUGO_INIT_TIMING");
         o.structure_reuse = !flag("CUGO_NO_STRUCTURE_REUSE");

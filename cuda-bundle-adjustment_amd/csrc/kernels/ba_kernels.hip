@@ -2372,9 +2372,16 @@ void set_launch_hook(LaunchHook* h) { g_hook = h; }
 LaunchHook* launch_hook() { return g_hook; }
 
 // scratch = [block partials | per-edge records of the build pass (8 doubles per slot)]
+// block partials: the scale partials of the update pass (one per 256 edge slots / landmarks + one per 256 poses) at the
+// start and, behind them (spec_chi_offset), the chi2 partials of a build pass that ends a trial (launch_build:
+// chi_behind_scale)
+static size_t spec_chi_offset(int n_edges, int n_poses, int n_landmarks)
+{
+    return (size_t)div_up(n_edges > n_landmarks ? n_edges : n_landmarks, BS) + div_up(n_poses, BS) + 64;
+}
 static size_t scratch_partials(int n_edges, int n_poses, int n_landmarks)
 {
-    const size_t n = (size_t)div_up(n_edges, BS) + div_up(n_poses, BS) + div_up(n_landmarks, BS) + 4096;
+    const size_t n = 2 * (size_t)div_up(n_edges > n_landmarks ? n_edges : n_landmarks, BS) + div_up(n_poses, BS) + 4096;
     return (n + 31) & ~size_t(31); // the records start 256-byte aligned
 }
 size_t reduce_scratch_doubles(int n_edges, int n_poses, int n_landmarks)
@@ -2431,18 +2438,21 @@ template <typename S>
 static void launch_build_t(hipStream_t s, const cugo_edges& e, const double* d_poses, const double* d_lms,
                            cugo_robust rk, double* d_Hpp, double* d_bp, double* d_Hll, double* d_bl,
                            S* d_Hpl, ReduceScratch rs, double* d_chi, double fuse_lambda, double* d_invHll,
-                           S* d_T, double* d_lmrec, bool skip_poses)
+                           S* d_T, double* d_lmrec, bool skip_poses, bool chi_behind_scale)
 {
     const EV ev = make_ev(e);
     const Robust2 r{{rk.type, rk.delta}, {rk.type_stereo, rk.delta_stereo}};
     const int nb = div_up(ev.E > ev.L ? ev.E : ev.L, BS); // also covers the edgeless landmarks
     double* d_rec = rs.d_partials + scratch_partials(ev.E, ev.P, ev.L);
+    // chi_behind_scale: this build pass ends a trial (launch_trial_tail_from_build sums its chi2 partials together with
+    // the scale partials of the update pass, which sit at the start of the scratch)
+    double* d_chi_part = rs.d_partials + (chi_behind_scale ? spec_chi_offset(ev.E, ev.P, ev.L) : 0);
     if (nb > 0)
         CUGO_LAUNCH_T(k_build_edges, S, dim3(nb), dim3(BS), 0, s, ev, d_poses, d_lms, r, d_Hpl, d_Hll,
-                      d_bl, d_rec, rs.d_partials, d_invHll ? fuse_lambda : -1.0, d_invHll, d_T,
+                      d_bl, d_rec, d_chi_part, d_invHll ? fuse_lambda : -1.0, d_invHll, d_T,
                       d_invHll && d_T ? d_lmrec : nullptr);
     if (d_chi)
-        CUGO_LAUNCH(k_sum_partials, dim3(1), dim3(SP_BS), 0, s, rs.d_partials, nb, d_chi);
+        CUGO_LAUNCH(k_sum_partials, dim3(1), dim3(SP_BS), 0, s, d_chi_part, nb, d_chi);
     // skip_poses: the Schur complement of this lambda forms Hsc's diagonal blocks, bp and bsc from the records itself
     // (launch_schur with SchurRows::d_lmrec); Hpp is then not written
     if (ev.P > 0 && !(skip_poses && d_invHll && d_T && d_lmrec))
@@ -2452,14 +2462,27 @@ static void launch_build_t(hipStream_t s, const cugo_edges& e, const double* d_p
 void launch_build(hipStream_t s, const cugo_edges& e, const double* d_poses, const double* d_lms,
                   cugo_robust rk, double* d_Hpp, double* d_bp, double* d_Hll, double* d_bl,
                   void* d_Hpl, ReduceScratch rs, double* d_chi, double fuse_lambda, double* d_invHll, void* d_T,
-                  double* d_lmrec, bool skip_poses)
+                  double* d_lmrec, bool skip_poses, bool chi_behind_scale)
 {
     if (e.block_f32)
         launch_build_t(s, e, d_poses, d_lms, rk, d_Hpp, d_bp, d_Hll, d_bl, static_cast<float*>(d_Hpl), rs, d_chi,
-                       fuse_lambda, d_invHll, static_cast<float*>(d_T), d_lmrec, skip_poses);
+                       fuse_lambda, d_invHll, static_cast<float*>(d_T), d_lmrec, skip_poses, chi_behind_scale);
     else
         launch_build_t(s, e, d_poses, d_lms, rk, d_Hpp, d_bp, d_Hll, d_bl, static_cast<double*>(d_Hpl), rs, d_chi,
-                       fuse_lambda, d_invHll, static_cast<double*>(d_T), d_lmrec, skip_poses);
+                       fuse_lambda, d_invHll, static_cast<double*>(d_T), d_lmrec, skip_poses, chi_behind_scale);
+}
+
+// The end of a trial whose chi2 comes out of the NEXT iteration's build pass (launch_build with chi_behind_scale, queued
+// at the trial's estimates before its result is known) instead of an error pass of its own: the same two-workgroup
+// reduction as launch_errors_tail — chi2 partials + scale partials -> F-hat, scale, flag, sequence number in pinned memory.
+// The partials are those k_errors would have written (same residual code, same 256-slot blocks, zeros behind them).
+void launch_trial_tail_from_build(hipStream_t s, const cugo_edges& e, ReduceScratch rs, int n_scale_partials,
+                                  double* d_out, const double* d_flag, double* h_out, double seq, unsigned* d_done)
+{
+    const EV ev = make_ev(e);
+    const int nb = div_up(ev.E > ev.L ? ev.E : ev.L, BS);
+    CUGO_LAUNCH(k_sum_partials2, dim3(2), dim3(SP_BS), 0, s, rs.d_partials + spec_chi_offset(ev.E, ev.P, ev.L), nb,
+                rs.d_partials, n_scale_partials, d_out, d_flag, h_out, seq, d_done);
 }
 
 void launch_build_poses(hipStream_t s, const cugo_edges& e, ReduceScratch rs, double* d_Hpp, double* d_bp)

@@ -61,7 +61,12 @@ void launch_errors(hipStream_t s, const cugo_edges& ev, const double* d_poses, c
 void launch_build(hipStream_t s, const cugo_edges& ev, const double* d_poses, const double* d_lms,
                   cugo_robust rk, double* d_Hpp, double* d_bp, double* d_Hll, double* d_bl,
                   void* d_Hpl, ReduceScratch rs, double* d_chi, double fuse_lambda = -1.0,
-                  double* d_invHll = nullptr, void* d_T = nullptr, double* d_lmrec = nullptr, bool skip_poses = false);
+                  double* d_invHll = nullptr, void* d_T = nullptr, double* d_lmrec = nullptr, bool skip_poses = false,
+                  bool chi_behind_scale = false);
+
+// the reductions that end a trial, with the chi2 partials of a build pass queued with chi_behind_scale (ba_kernels.hip)
+void launch_trial_tail_from_build(hipStream_t s, const cugo_edges& ev, ReduceScratch rs, int n_scale_partials,
+                                  double* d_out, const double* d_flag, double* h_out, double seq, unsigned* d_done);
 
 // the pose pass of launch_build alone, from the records that pass left in the scratch (Hpp, bp)
 void launch_build_poses(hipStream_t s, const cugo_edges& ev, ReduceScratch rs, double* d_Hpp, double* d_bp);

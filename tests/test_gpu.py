@@ -720,6 +720,28 @@ def test_fused_pose_pass_matches_the_separate_kernels(oracle_lib, speculate, mon
         np.testing.assert_allclose(runs[0]["lm"], runs[1]["lm"], rtol=0, atol=1000 * etol)
 
 
+def test_trial_chi2_out_of_the_next_build_pass_gives_the_same_bits(oracle_lib, monkeypatch):
+    """a first trial's chi2 comes out of the NEXT iteration's build pass — queued at the trial's estimates before the
+    result is known, followed by the trial's reductions and by the Schur complement for the predicted damping — instead
+    of an error pass of its own (CUGO_TRIAL_FROM_BUILD=0).  The same residuals summed in the same blocks: the same
+    F-hat, so the same decisions and the same bits at the end — on a graph whose trials are all accepted, on the
+    golden case whose trials get rejected (the speculative work is thrown away and H rebuilt) and with robust
+    kernels (whose dampings miss the prediction now and then: the queued Schur complement is redone for the real one)."""
+    d, _ = synth_problem(oracle_lib, 200, 3000, 12500, seed=31, lc=100)
+    cases = [(d, (0, 0.0))]
+    for name in ("reject_8x60", "huber_8x80", "loop_12x150"):
+        g8 = np.load(golden_path(name + ".npz"))
+        cases.append(({k: g8[k] for k in PROBLEM_KEYS}, (int(g8["rk_type"]), float(g8["rk_delta"]))))
+    for dd, rk in cases:
+        runs = []
+        for v in ("1", "0"):
+            monkeypatch.setenv("CUGO_TRIAL_FROM_BUILD", v)
+            runs.append(run_graph(dd, 8, rk=rk))
+        assert [(s["chi2"], s["lam"], s["trials"]) for s in runs[0]["stats"]] == \
+               [(s["chi2"], s["lam"], s["trials"]) for s in runs[1]["stats"]]
+        assert np.array_equal(runs[0]["pose"], runs[1]["pose"]) and np.array_equal(runs[0]["lm"], runs[1]["lm"])
+
+
 def test_bitwise_reproducible(oracle_lib):
     d, _ = synth_problem(oracle_lib, 200, 3000, 12500, seed=21, lc=100)
     a, b = run_graph(d, 8), run_graph(d, 8)

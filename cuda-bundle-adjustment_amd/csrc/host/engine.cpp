@@ -1684,7 +1684,7 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
         const bool fuse_allowed = m.opt.fuse_t;
         const bool can_fuse = fuse_allowed && !m.splan_on && m.lm_in_one_group;
         const bool fused_T = have_build ? (can_fuse && built_lambda == lambda) : (can_fuse && iteration > 0);
-        const bool ps_on = m.opt.pose_schur && can_fuse && !use_rows && !m.strip_on && !m.ev.block_f32;
+        const bool ps_on = m.opt.pose_schur && can_fuse && !use_rows && !m.strip_on;
         if (ps_on && m.d_lmrec.size() < 16 * (size_t)std::max(m.L, 1))
             m.d_lmrec.resize(16 * (size_t)std::max(m.L, 1));
         if (!have_build)

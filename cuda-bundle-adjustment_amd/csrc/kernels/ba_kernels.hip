@@ -711,8 +711,9 @@ __global__ __launch_bounds__(BS) void k_build_poses(EV ev, const double* __restr
 // k_build_edges leaves {invHll (6), z (3)} of landmark l in a 128-byte slot lmrec[16 l] and the landmark index and an
 // "active" bit in the record.  One workgroup per pose, one lane per edge, eight waves: a pose of the kitti_00 shape
 // (~424 edges) is ONE round — list entry -> record -> landmark line -> arithmetic -> sums.  Replaces k_build_poses +
-// k_hsc_diag_mfma of that iteration (double storage only: the float mode rounds the stored blocks, which this form
-// never sees); Hpp is NOT written (the engine makes up for it where a rejected trial needs it).
+// k_hsc_diag_mfma of that iteration; Hpp is NOT written (the engine makes up for it where a rejected trial needs it).
+// (In the float mode the stored T / Hpl blocks are rounded to float and the off-diagonal blocks are formed from
+// those; the diagonal blocks formed here never see a stored block and come out in full precision.)
 constexpr int PS_W = 4, PS_BS = 64 * PS_W;
 __global__ __launch_bounds__(PS_BS, 3) void k_pose_schur(EV ev, const double* __restrict__ rec,
                                                       const double* __restrict__ lmrec,
@@ -2580,7 +2581,7 @@ static void launch_schur_t(hipStream_t s, const cugo_edges& e, const cugo_hsc_st
     else if (hs.n_blocks > 0)
         CUGO_LAUNCH_T(k_hsc_offdiag, S, dim3(div_up(hs.n_blocks, BS / 64)), dim3(BS), 0, s,
                       hs.n_blocks, hs.d_off_ptr, hs.d_off_ei, hs.d_off_ej, d_Hpl, (const S*)d_T, d_Hsc);
-    if (ev.P > 0 && have_T && rows.d_lmrec && sizeof(S) == 8)
+    if (ev.P > 0 && have_T && rows.d_lmrec)
     { // fused iteration: diagonal blocks, bp and bsc from the build pass's records (its pose pass was skipped)
         const double* d_rec = rows.rs.d_partials + scratch_partials(ev.E, ev.P, ev.L);
         CUGO_LAUNCH(k_pose_schur, dim3(xcd_grid(ev.P)), dim3(PS_BS), 0, s, ev, d_rec, rows.d_lmrec, rows.d_poses,

@@ -76,7 +76,8 @@ def compulsory_bytes(E, Em, Es, P, L, B, f32):
         # idx 8 + meas + omega 8 + flag 1; poses / landmarks once; partial sums are negligible
         "k_errors": 17.0 * E + meas + 56.0 * P + 24.0 * L,
         # + write Hpl, the 64-byte edge record of the pose pass, Hll / bl
-        "k_build_edges": 17.0 * E + meas + blk * E + 64.0 * E + 96.0 * L + 56.0 * P + 24.0 * L,
+        "k_build_edges": 17.0 * E + meas + blk * E + 64.0 * E + 96.0 * L + 56.0 * P + 24.0 * L,  # (+ T, invHll and the
+        # landmark lines of the fused iterations: added where the line is assembled, by the share of such iterations)
         "k_build_poses": 64.0 * E + 4.0 * E + 336.0 * P,
         # the pose pass of the fused iteration: records + list entries + one {invHll, z} line per landmark;
         # writes the diagonal block, bp and bsc of every pose
@@ -418,7 +419,9 @@ def main():
         comp = compulsory_bytes(El, El - Es, Es, Pf, Ll, B, args.float32)
         if os.environ.get("CUGO_FUSE_T", "1") != "0" and not os.environ.get("CUGO_SCHUR_PLAN"):
             # from the second LM iteration on the build pass also writes T and invHll
-            comp["k_build_edges"] += ((72.0 if args.float32 else 144.0) * El + 72.0 * Ll) * (args.iters - 1) / args.iters
+            # (+ 72 bytes per landmark: the {invHll, z} line the pose pass of those iterations reads, k_pose_schur)
+            lm_line = 72.0 if os.environ.get("CUGO_POSE_SCHUR", "1") != "0" else 0.0
+            comp["k_build_edges"] += ((72.0 if args.float32 else 144.0) * El + (72.0 + lm_line) * Ll) * (args.iters - 1) / args.iters
         flops = {"k_up_potrf": sstats.get("up_potrf_flops", 0.0)}
         # the trsm / syrk work of a factorisation is spread over four kernels (fused 64x64 and 32x32 tiles,
         # and the two-phase pair of the wide levels): rated together, against the non-redundant flop count

@@ -120,11 +120,11 @@ struct Engine::Impl : cugo_k::LaunchHook
     DevBuf<double> d_poses[2], d_lms[2];
     int cur = 0;
     DevBuf<double> d_Hpp, d_b, d_Hll, d_Hpl, d_T, d_invHll, d_x, d_sys, d_tmp, d_scal;
-    // fused iteration (Options::pose_schur): {invHll, bl} of every landmark in a 128-byte slot for k_pose_schur; whether
-    // Hpp is the one of the current linearisation (a fused build skips its pose pass) and whether the build pass's
-    // records are still there (the error pass of a trial re-uses their memory)
+    // fused iteration (Options::pose_schur): {L^-1, L^-1 bl} of every landmark (Hll + lambda I = L L^T) in a 128-byte
+    // slot for k_pose_schur / k_backsubst_landmarks, and whether Hpp, Hpl and invHll are those of the current
+    // linearisation: a fused build pass writes ONE block stream (G = Hpl L^-T, into d_T) and none of the three
     DevBuf<double> d_lmrec;
-    bool hpp_valid = true, rec_valid = false;
+    bool hpp_valid = true;
     PinnedBuf<double> h_pin_poses, h_pin_lms; // refresh_estimates_pinned / download_pinned
     Clock::duration last_trial_wait{0};       // how long the host polled for the previous trial's result
     DevBuf<int32_t> d_hsc_rowptr, d_hsc_colind, d_off_ptr, d_off_ei, d_off_ej, d_fail;
@@ -1695,7 +1695,7 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
                                  m.rs(), iteration == 0 ? m.d_scal.data() : nullptr, fused_T ? lambda : -1.0,
                                  fused_T ? m.d_invHll.data() : nullptr,
                                  fused_T && !use_rows ? m.d_T.data() : nullptr, ps_on ? m.d_lmrec.data() : nullptr, ps_on);
-            m.hpp_valid = !(ps_on && fused_T), m.rec_valid = true;
+            m.hpp_valid = !(ps_on && fused_T);
         });
         have_build = false, built_lambda = -1.0;
         sync_prof(PROF_BUILD_SYSTEM, tb);
@@ -1740,23 +1740,20 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
                     cugo_k::launch_build(s, m.ev, m.d_poses[m.cur].data(), m.d_lms[m.cur].data(), m.rk,
                                          m.d_Hpp.data(), m.bp(), m.d_Hll.data(), m.bl(), m.d_Hpl.data(), m.rs(),
                                          nullptr, -1.0, nullptr, nullptr);
-                    m.hpp_valid = true, m.rec_valid = true;
+                    m.hpp_valid = true;
                 });
                 spec_queued = false;
             }
             const bool trial_fused = fused_T && q == 0; // invHll and T of this lambda came with the build pass
             if (!(trial_fused && ps_on) && !m.hpp_valid)
-            { // the build pass skipped its pose pass for a fused trial that is not this one (the predicted damping
-              // missed, or the fused trial was rejected with no speculative build behind it): Hpp and bp from the
-              // records if the error pass has not re-used their memory, else the whole build pass again
+            { // the build pass at hand was a fused one (one block stream, no Hpp / Hpl / invHll) and this trial is
+              // not the one it was for — the predicted damping missed, or the fused trial was rejected with no
+              // speculative build behind it: the two-stream build pass at the estimates in force
                 m.timed("build", [&] {
-                    if (m.rec_valid)
-                        cugo_k::launch_build_poses(s, m.ev, m.rs(), m.d_Hpp.data(), m.bp());
-                    else
-                        cugo_k::launch_build(s, m.ev, m.d_poses[m.cur].data(), m.d_lms[m.cur].data(), m.rk,
-                                             m.d_Hpp.data(), m.bp(), m.d_Hll.data(), m.bl(), m.d_Hpl.data(), m.rs(),
-                                             nullptr, -1.0, nullptr, nullptr);
-                    m.hpp_valid = true, m.rec_valid = true;
+                    cugo_k::launch_build(s, m.ev, m.d_poses[m.cur].data(), m.d_lms[m.cur].data(), m.rk,
+                                         m.d_Hpp.data(), m.bp(), m.d_Hll.data(), m.bl(), m.d_Hpl.data(), m.rs(),
+                                         nullptr, -1.0, nullptr, nullptr);
+                    m.hpp_valid = true;
                 });
             }
             const size_t blkw = (m.ev.block_f32 ? 9 : 18) * (size_t)m.E;
@@ -1812,10 +1809,12 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
             // the two sums first and keeps the separate launches and the read-back.
             int n_scale_part = 0;
             m.timed("backsubst_update", [&] {
+                const bool gform = trial_fused && ps_on; // (the build pass wrote G into d_T and the landmarks' lines)
                 n_scale_part = cugo_k::launch_backsubst_update(
                     s, m.ev, lambda, (m.rank == 0 ? lambda : 0.0), m.d_invHll.data(), m.bl(), m.bp(),
-                    m.d_Hpl.data(), m.xp(), m.xl(), m.d_poses[m.cur].data(), m.d_lms[m.cur].data(),
-                    m.d_poses[nxt].data(), m.d_lms[nxt].data(), m.rs(), sharded ? m.d_scal.data() + 3 : nullptr);
+                    gform ? m.d_T.data() : m.d_Hpl.data(), m.xp(), m.xl(), m.d_poses[m.cur].data(), m.d_lms[m.cur].data(),
+                    m.d_poses[nxt].data(), m.d_lms[nxt].data(), m.rs(), sharded ? m.d_scal.data() + 3 : nullptr,
+                    gform ? m.d_lmrec.data() : nullptr);
             });
             sync_prof(PROF_UPDATE, tu);
             if (q == 0)
@@ -1839,7 +1838,7 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
                                          can_fuse ? lambda_pred : -1.0, can_fuse ? m.d_invHll.data() : nullptr,
                                          can_fuse && !use_rows ? m.d_T.data() : nullptr, ps_on ? m.d_lmrec.data() : nullptr, ps_on,
                                          true);
-                    m.hpp_valid = !(ps_on && can_fuse), m.rec_valid = true;
+                    m.hpp_valid = !(ps_on && can_fuse);
                 });
                 m.timed("errors", [&] {
                     cugo_k::launch_trial_tail_from_build(s, m.ev, m.rs(), n_scale_part, m.d_scal.data() + 2,
@@ -1874,7 +1873,6 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
                                                n_scale_part, m.d_scal.data() + 2, m.d_scal.data() + 4,
                                                m.h_scal.data() + 2, (double)++m.trial_seq,
                                                reinterpret_cast<unsigned*>(m.d_fail.data() + 2));
-                    m.rec_valid = false; // (its partial sums go where the records of the build pass were)
                 }
             });
             m.last_err_buf = nxt;
@@ -1892,7 +1890,7 @@ void Engine::optimize(int niterations, std::vector<IterRecord>& records, bool ve
                                          m.bp(), m.d_Hll.data(), m.bl(), m.d_Hpl.data(), m.rs(), nullptr,
                                          can_fuse ? lambda_pred : -1.0, can_fuse ? m.d_invHll.data() : nullptr,
                                          can_fuse && !use_rows ? m.d_T.data() : nullptr, ps_on ? m.d_lmrec.data() : nullptr, ps_on);
-                    m.hpp_valid = !(ps_on && can_fuse), m.rec_valid = true;
+                    m.hpp_valid = !(ps_on && can_fuse);
                 });
                 spec_queued = true;
             }

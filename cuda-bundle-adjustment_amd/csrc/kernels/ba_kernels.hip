@@ -339,7 +339,12 @@ __global__ __launch_bounds__(BS) void k_build_edges(EV ev, const double* __restr
     // second LM iteration on: the damping of the first trial is known when the build is queued): this
     // pass also leaves invHll = (Hll + lambda I)^-1 and T = Hpl invHll — exactly what k_schur_edges
     // would compute from the arrays written here, without reading the Hpl stream again.
+    // lmrec != nullptr (with fuse and T): ONE block stream instead of two.  With Hll + lambda I = L L^T the pass
+    // writes G = Hpl L^-T into T and neither Hpl nor invHll: Hsc_ij = - sum G_i G_j^T (both operands of the
+    // off-diagonal kernel out of one array), dx_l = L^-T (y - sum G_e^T dx_p) with y = L^-1 bl (k_backsubst_landmarks),
+    // and the pose pass (k_pose_schur) needs L^-1 and y only: the landmark's line lmrec[16 l] = {L^-1 (6), y (3)}.
     const bool fuse = fuse_lambda >= 0.0;
+    const bool gform = fuse && T != nullptr && lmrec != nullptr;
     __shared__ double sm[BS / 64];
     // 36 KB used twice: first the landmark contributions cs[9][BS] and the per-edge records
     // rs_[BS*9] (9-double lane stride: conflict-free both ways), at the end the block's 256 Hpl
@@ -459,7 +464,30 @@ __global__ __launch_bounds__(BS) void k_build_edges(EV ev, const double* __restr
         for (int i = 0; i < 9; i++)
             Hg[i] = h9[i];
         bl[3 * (size_t)l] = a[6], bl[3 * (size_t)l + 1] = a[7], bl[3 * (size_t)l + 2] = a[8];
-        if (fuse)
+        if (gform)
+        {
+            // Hll + lambda I = L L^T (3 x 3; a pivot that is not positive gives NaNs, the factorisation of Hsc
+            // raises its flag on them and the trial is rejected: its retry takes the two-stream path), L^-1, y
+            const double l00 = sqrt(a[0] + fuse_lambda);
+            const double i00 = 1.0 / l00;
+            const double l10 = a[1] * i00, l20 = a[2] * i00;
+            const double l11 = sqrt(a[3] + fuse_lambda - l10 * l10);
+            const double i11 = 1.0 / l11;
+            const double l21 = (a[4] - l20 * l10) * i11;
+            const double l22 = sqrt(a[5] + fuse_lambda - l20 * l20 - l21 * l21);
+            const double i22 = 1.0 / l22;
+            const double i10 = -(l10 * i00) * i11;
+            const double i21 = -(l21 * i11) * i22;
+            const double i20 = -(l20 * i00 + l21 * i10) * i22;
+            double* q = ivs[threadIdx.x];
+            q[0] = i00, q[1] = i10, q[2] = i11, q[3] = i20, q[4] = i21, q[5] = i22;
+            double* lr = lmrec + 16 * (size_t)l; // one 128-byte line per landmark
+            lr[0] = i00, lr[1] = i10, lr[2] = i11, lr[3] = i20, lr[4] = i21, lr[5] = i22;
+            lr[6] = i00 * a[6];
+            lr[7] = i10 * a[6] + i11 * a[7];
+            lr[8] = i20 * a[6] + i21 * a[7] + i22 * a[8];
+        }
+        else if (fuse)
         {
             const Sym3 iv = sym3_inv(h9, fuse_lambda);
             double* o = invHll + 9 * (size_t)l;
@@ -468,14 +496,6 @@ __global__ __launch_bounds__(BS) void k_build_edges(EV ev, const double* __restr
             o[6] = iv.b02, o[7] = iv.b12, o[8] = iv.b22;
             double* q = ivs[threadIdx.x];
             q[0] = iv.b00, q[1] = iv.b01, q[2] = iv.b02, q[3] = iv.b11, q[4] = iv.b12, q[5] = iv.b22;
-            if (lmrec)
-            { // what the pose pass of the fused iteration (k_pose_schur) reads per edge: one 128-byte line
-                double* lr = lmrec + 16 * (size_t)l;
-                lr[0] = iv.b00, lr[1] = iv.b01, lr[2] = iv.b02, lr[3] = iv.b11, lr[4] = iv.b12, lr[5] = iv.b22;
-                lr[6] = iv.b00 * a[6] + iv.b01 * a[7] + iv.b02 * a[8]; // z = invHll bl
-                lr[7] = iv.b01 * a[6] + iv.b11 * a[7] + iv.b12 * a[8];
-                lr[8] = iv.b02 * a[6] + iv.b12 * a[7] + iv.b22 * a[8];
-            }
         }
     }
     if (e < ev.L && ev.lm_ptr[e] == ev.lm_ptr[e + 1])
@@ -504,6 +524,7 @@ __global__ __launch_bounds__(BS) void k_build_edges(EV ev, const double* __restr
     }
     if (fuse)
         __syncthreads(); // ivs has been read
+    if (!gform)
     {
         double* mine = reinterpret_cast<double*>(pool2) + 18 * threadIdx.x;
 #pragma unroll
@@ -514,24 +535,35 @@ __global__ __launch_bounds__(BS) void k_build_edges(EV ev, const double* __restr
     {
         const int ebase = blockIdx.x * BS;
         const long nvalid = 9L * max(0, min(BS, ev.E - ebase));
-#pragma unroll
-        for (int i = 0; i < 9; i++)
+        if (!gform)
         {
-            const int idx = i * BS + threadIdx.x;
-            if (idx < nvalid)
+#pragma unroll
+            for (int i = 0; i < 9; i++)
             {
-                const double2 v = pool2[idx];
-                st_pair(Hpl, 9 * (size_t)ebase + idx, v.x, v.y);
+                const int idx = i * BS + threadIdx.x;
+                if (idx < nvalid)
+                {
+                    const double2 v = pool2[idx];
+                    st_pair(Hpl, 9 * (size_t)ebase + idx, v.x, v.y);
+                }
             }
         }
         if (fuse && T != nullptr)
-        { // T = Hpl invHll of this block's slots, from the blocks still in registers
-            __syncthreads(); // the Hpl blocks have left the pool
+        { // T = Hpl invHll (or G = Hpl L^-T) of this block's slots, from the blocks still in registers
+            if (!gform)
+                __syncthreads(); // the Hpl blocks have left the pool
             double* mine = reinterpret_cast<double*>(pool2) + 18 * threadIdx.x;
 #pragma unroll
             for (int r = 0; r < 6; r++)
             { // the stored Hpl values (float storage rounds them) are what k_schur_edges would read
                 const double a = (double)(S)H[r], b = (double)(S)H[6 + r], c = (double)(S)H[12 + r];
+                if (gform)
+                { // q = L^-1: (0,0) (1,0) (1,1) (2,0) (2,1) (2,2);  G[:, m] = sum_{n <= m} H[:, n] L^-1[m][n]
+                    mine[r] = act ? H[r] * q[0] : 0.0;
+                    mine[6 + r] = act ? H[r] * q[1] + H[6 + r] * q[2] : 0.0;
+                    mine[12 + r] = act ? H[r] * q[3] + H[6 + r] * q[4] + H[12 + r] * q[5] : 0.0;
+                    continue;
+                }
                 mine[r] = act ? a * q[0] + b * q[1] + c * q[2] : 0.0;
                 mine[6 + r] = act ? a * q[1] + b * q[3] + c * q[4] : 0.0;
                 mine[12 + r] = act ? a * q[2] + b * q[4] + c * q[5] : 0.0;
@@ -780,7 +812,7 @@ __global__ __launch_bounds__(PS_BS, 3) void k_pose_schur(EV ev, const double* __
         // landmark indices, so that this line is requested together with the record instead of behind it, changes
         // nothing — 34.5 vs 32.2 us: the kernel is bound by its 168 registers per edge, not by this chain.)
         const double2* lr = reinterpret_cast<const double2*>(lmrec + 16 * (size_t)(act ? (int)(meta >> 32) : 0));
-        const double2 q01 = lr[0], q23 = lr[1], q45 = lr[2], z01 = lr[3];
+        const double2 q01 = lr[0], q23 = lr[1], q45 = lr[2], z01 = lr[3]; // L^-1: (0,0) (1,0) | (1,1) (2,0) | (2,1) (2,2); y
         const double z2 = lr[4].x;
         double N[6], u[3]; // N: (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
         {
@@ -792,13 +824,13 @@ __global__ __launch_bounds__(PS_BS, 3) void k_pose_schur(EV ev, const double* __
                 R[a / 3][a % 3] = Rs[a + zero];
             double JL[3][3];
             jac_landmark_R(Xc, R, cam, stereo, JL);
-            double K[3][3];
+            double K[3][3]; // A = JL L^-T:  A[m][j] = sum_{i <= j} JL[m][i] L^-1[j][i]
 #pragma unroll
             for (int m = 0; m < 3; m++)
             {
-                K[m][0] = JL[m][0] * q01.x + JL[m][1] * q01.y + JL[m][2] * q23.x;
-                K[m][1] = JL[m][0] * q01.y + JL[m][1] * q23.y + JL[m][2] * q45.x;
-                K[m][2] = JL[m][0] * q23.x + JL[m][1] * q45.x + JL[m][2] * q45.y;
+                K[m][0] = JL[m][0] * q01.x;
+                K[m][1] = JL[m][0] * q01.y + JL[m][1] * q23.x;
+                K[m][2] = JL[m][0] * q23.y + JL[m][1] * q45.x + JL[m][2] * q45.y;
             }
             // (an inactive edge has read slot 0 of the landmark lines — memory nobody may have written when no landmark
             // is free: its terms are SELECTED away, 0 x whatever sits there would not do)
@@ -809,13 +841,13 @@ __global__ __launch_bounds__(PS_BS, 3) void k_pose_schur(EV ev, const double* __
 #pragma unroll
                 for (int n = m; n < 3; n++)
                 {
-                    const double mm = K[m][0] * JL[n][0] + K[m][1] * JL[n][1] + K[m][2] * JL[n][2];
+                    const double mm = K[m][0] * K[n][0] + K[m][1] * K[n][1] + K[m][2] * K[n][2]; // (A A^T)[m][n]
                     N[k++] = (m == n ? wgt : 0.0) - (act ? w2 * mm : 0.0);
                 }
 #pragma unroll
             for (int m = 0; m < 3; m++)
             {
-                const double jz = JL[m][0] * z01.x + JL[m][1] * z01.y + JL[m][2] * z2;
+                const double jz = K[m][0] * z01.x + K[m][1] * z01.y + K[m][2] * z2; // JL z = A y
                 u[m] = we[m] - (act ? wgt * jz : 0.0);
             }
         }
@@ -2265,8 +2297,10 @@ __global__ __launch_bounds__(BS) void k_backsubst_landmarks(
     const S* __restrict__ Hpl, const double* __restrict__ xp, double* __restrict__ xl,
     const double* __restrict__ lms_in, double* __restrict__ lms_out,
     double* __restrict__ partials, int nbl, double lambda_pose, const double* __restrict__ bp,
-    const double* __restrict__ poses_in, double* __restrict__ poses_out)
+    const double* __restrict__ poses_in, double* __restrict__ poses_out, const double* __restrict__ lmrec)
 {
+    // lmrec != nullptr: the one-stream form of the fused iteration (k_build_edges): `Hpl` holds G = Hpl L^-T and the
+    // landmark's line {L^-1, y = L^-1 bl}:  dx_l = L^-T (y - sum G_e^T dx_p)  in place of  invHll (bl - sum Hpl_e^T dx_p)
     __shared__ double sm[BS / 64];
     __shared__ double2 hs[BS * 9 + 1];
     // the per-slot products Hpl^T x take the place of the staged blocks once every lane has consumed its own
@@ -2324,8 +2358,9 @@ __global__ __launch_bounds__(BS) void k_backsubst_landmarks(
     double sc = 0;
     if (l >= 0 && l < ev.L && ev.lm_ptr[l] == e)
     { // owner of landmark l
-        double c0 = bl[3 * (size_t)l], c1 = bl[3 * (size_t)l + 1], c2 = bl[3 * (size_t)l + 2];
-        const double b0 = c0, b1 = c1, b2 = c2;
+        const double b0 = bl[3 * (size_t)l], b1 = bl[3 * (size_t)l + 1], b2 = bl[3 * (size_t)l + 2];
+        const double* lr = lmrec ? lmrec + 16 * (size_t)l : nullptr;
+        double c0 = lr ? lr[6] : b0, c1 = lr ? lr[7] : b1, c2 = lr ? lr[8] : b2;
         const int e1 = ev.lm_ptr[l + 1];
         const int bend = min(e1, ebase + BS);
         for (int ee = e; ee < bend; ee++)
@@ -2339,10 +2374,20 @@ __global__ __launch_bounds__(BS) void k_backsubst_landmarks(
             hplT_x(Hpl + 18 * (size_t)ee, xp + 6 * (size_t)ev.pose[ee], s0, s1, s2);
             c0 -= s0, c1 -= s1, c2 -= s2;
         }
-        const double* iv = invHll + 9 * (size_t)l;
-        const double x0 = iv[0] * c0 + iv[3] * c1 + iv[6] * c2;
-        const double x1 = iv[1] * c0 + iv[4] * c1 + iv[7] * c2;
-        const double x2 = iv[2] * c0 + iv[5] * c1 + iv[8] * c2;
+        double x0, x1, x2;
+        if (lr)
+        { // L^-T c;  L^-1: (0,0) (1,0) (1,1) (2,0) (2,1) (2,2)
+            x0 = lr[0] * c0 + lr[1] * c1 + lr[3] * c2;
+            x1 = lr[2] * c1 + lr[4] * c2;
+            x2 = lr[5] * c2;
+        }
+        else
+        {
+            const double* iv = invHll + 9 * (size_t)l;
+            x0 = iv[0] * c0 + iv[3] * c1 + iv[6] * c2;
+            x1 = iv[1] * c0 + iv[4] * c1 + iv[7] * c2;
+            x2 = iv[2] * c0 + iv[5] * c1 + iv[8] * c2;
+        }
         xl[3 * (size_t)l] = x0, xl[3 * (size_t)l + 1] = x1, xl[3 * (size_t)l + 2] = x2;
         lms_out[3 * (size_t)l] = lms_in[3 * (size_t)l] + x0;
         lms_out[3 * (size_t)l + 1] = lms_in[3 * (size_t)l + 1] + x1;
@@ -2486,14 +2531,6 @@ void launch_trial_tail_from_build(hipStream_t s, const cugo_edges& e, ReduceScra
                 rs.d_partials, n_scale_partials, d_out, d_flag, h_out, seq, d_done);
 }
 
-void launch_build_poses(hipStream_t s, const cugo_edges& e, ReduceScratch rs, double* d_Hpp, double* d_bp)
-{
-    const EV ev = make_ev(e);
-    const double* d_rec = rs.d_partials + scratch_partials(ev.E, ev.P, ev.L);
-    if (ev.P > 0)
-        CUGO_LAUNCH(k_build_poses, dim3(ev.P), dim3(BS), 0, s, ev, d_rec, d_Hpp, d_bp);
-}
-
 void launch_max_diagonal(hipStream_t s, const double* d_Hpp, int nP, const double* d_Hll, int nL,
                          ReduceScratch rs, double* d_out)
 {
@@ -2571,6 +2608,8 @@ static void launch_schur_t(hipStream_t s, const cugo_edges& e, const cugo_hsc_st
         // way the kernel is bound by its L2 misses, and rows that share T operands now meet in one L2 (the
         // vector-lane kernel, bound by LDS reads, was slower with this mapping: 123 vs 112 us)
         ::cugo_k::LaunchScope _scope("k_hsc_offdiag_mfma", s);
+        if (have_T && rows.d_lmrec) // one-stream form (k_build_edges with lmrec): T holds G, Hsc_ij = - sum G_i G_j^T
+            d_Hpl = (const S*)d_T;
         if (rows.xcd)
             hipLaunchKernelGGL((k_hsc_offdiag_mfma<S, true>), dim3(xcd_grid(div_up(hs.n_blocks, BS / 64))), dim3(BS), 0, s,
                                hs.n_blocks, hs.d_off_ptr, hs.d_off_ei, hs.d_off_ej, d_Hpl, (const S*)d_T, d_Hsc);
@@ -2639,14 +2678,14 @@ static int launch_backsubst_update_t(hipStream_t s, const cugo_edges& e, double 
                                       const double* d_invHll, const double* d_bl, const double* d_bp,
                                       const S* d_Hpl, const double* d_xp, double* d_xl,
                                       const double* d_poses_in, const double* d_lms_in, double* d_poses_out,
-                                      double* d_lms_out, ReduceScratch rs, double* d_scale)
+                                      double* d_lms_out, ReduceScratch rs, double* d_scale, const double* d_lmrec)
 {
     const EV ev = make_ev(e);
     const int nbl = div_up(ev.E > ev.L ? ev.E : ev.L, BS), nbp = div_up(ev.P, BS);
     if (nbl + nbp > 0)
         CUGO_LAUNCH_T(k_backsubst_landmarks, S, dim3(nbl + nbp), dim3(BS), 0, s, ev, lambda, d_invHll,
                       d_bl, d_Hpl, d_xp, d_xl, d_lms_in, d_lms_out, rs.d_partials, nbl,
-                      lambda_pose, d_bp, d_poses_in, d_poses_out);
+                      lambda_pose, d_bp, d_poses_in, d_poses_out, d_lmrec);
     if (d_scale) // nullptr: the partials stay in the scratch for launch_errors_tail
         CUGO_LAUNCH(k_sum_partials, dim3(1), dim3(SP_BS), 0, s, rs.d_partials, nbl + nbp, d_scale);
     return nbl + nbp;
@@ -2656,13 +2695,13 @@ int launch_backsubst_update(hipStream_t s, const cugo_edges& e, double lambda, d
                             const double* d_invHll, const double* d_bl, const double* d_bp,
                             const void* d_Hpl, const double* d_xp, double* d_xl,
                             const double* d_poses_in, const double* d_lms_in, double* d_poses_out,
-                            double* d_lms_out, ReduceScratch rs, double* d_scale)
+                            double* d_lms_out, ReduceScratch rs, double* d_scale, const double* d_lmrec)
 {
     if (e.block_f32)
         return launch_backsubst_update_t(s, e, lambda, lambda_pose, d_invHll, d_bl, d_bp, static_cast<const float*>(d_Hpl),
-                                  d_xp, d_xl, d_poses_in, d_lms_in, d_poses_out, d_lms_out, rs, d_scale);
+                                  d_xp, d_xl, d_poses_in, d_lms_in, d_poses_out, d_lms_out, rs, d_scale, d_lmrec);
     return launch_backsubst_update_t(s, e, lambda, lambda_pose, d_invHll, d_bl, d_bp, static_cast<const double*>(d_Hpl),
-                                  d_xp, d_xl, d_poses_in, d_lms_in, d_poses_out, d_lms_out, rs, d_scale);
+                                  d_xp, d_xl, d_poses_in, d_lms_in, d_poses_out, d_lms_out, rs, d_scale, d_lmrec);
 }
 
 } // namespace cugo_k

@@ -68,9 +68,6 @@ void launch_build(hipStream_t s, const cugo_edges& ev, const double* d_poses, co
 void launch_trial_tail_from_build(hipStream_t s, const cugo_edges& ev, ReduceScratch rs, int n_scale_partials,
                                   double* d_out, const double* d_flag, double* h_out, double seq, unsigned* d_done);
 
-// the pose pass of launch_build alone, from the records that pass left in the scratch (Hpp, bp)
-void launch_build_poses(hipStream_t s, const cugo_edges& ev, ReduceScratch rs, double* d_Hpp, double* d_bp);
-
 void launch_max_diagonal(hipStream_t s, const double* d_Hpp, int nP, const double* d_Hll, int nL,
                          ReduceScratch rs, double* d_out);
 
@@ -118,7 +115,8 @@ int launch_backsubst_update(hipStream_t s, const cugo_edges& ev, double lambda, 
                             const double* d_invHll, const double* d_bl, const double* d_bp,
                             const void* d_Hpl, const double* d_xp, double* d_xl,
                             const double* d_poses_in, const double* d_lms_in, double* d_poses_out,
-                            double* d_lms_out, ReduceScratch rs, double* d_scale);
+                            double* d_lms_out, ReduceScratch rs, double* d_scale,
+                            const double* d_lmrec = nullptr); // d_lmrec: d_Hpl holds G, see k_backsubst_landmarks
 // error pass of an LM trial + BOTH final reductions in one launch: d_out[0] = chi2, d_out[1] = scale
 // (from the n_scale_partials left by launch_backsubst_update); h_out (pinned host memory, may be
 // null) receives {chi2, scale, the 8 bytes at d_flag}: readable after the stream has been waited for

@@ -419,9 +419,12 @@ def main():
         comp = compulsory_bytes(El, El - Es, Es, Pf, Ll, B, args.float32)
         if os.environ.get("CUGO_FUSE_T", "1") != "0" and not os.environ.get("CUGO_SCHUR_PLAN"):
             # from the second LM iteration on the build pass also writes T and invHll
-            # (+ 72 bytes per landmark: the {invHll, z} line the pose pass of those iterations reads, k_pose_schur)
-            lm_line = 72.0 if os.environ.get("CUGO_POSE_SCHUR", "1") != "0" else 0.0
-            comp["k_build_edges"] += ((72.0 if args.float32 else 144.0) * El + (72.0 + lm_line) * Ll) * (args.iters - 1) / args.iters
+            # two-stream form (CUGO_POSE_SCHUR=0): + T and invHll; one-stream form (the default): G in place of Hpl — no
+            # block bytes on top — and the 72-byte line {L^-1, y} per landmark in place of invHll
+            if os.environ.get("CUGO_POSE_SCHUR", "1") != "0":
+                comp["k_build_edges"] += 72.0 * Ll * (args.iters - 1) / args.iters
+            else:
+                comp["k_build_edges"] += ((72.0 if args.float32 else 144.0) * El + 72.0 * Ll) * (args.iters - 1) / args.iters
         flops = {"k_up_potrf": sstats.get("up_potrf_flops", 0.0)}
         # the trsm / syrk work of a factorisation is spread over four kernels (fused 64x64 and 32x32 tiles,
         # and the two-phase pair of the wide levels): rated together, against the non-redundant flop count

@@ -58,6 +58,12 @@ void launch_errors(hipStream_t s, const cugo_edges& ev, const double* d_poses, c
 // fuse_lambda >= 0 with d_invHll and d_T given: the pass also leaves invHll = (Hll + lambda I)^-1 and
 // T = Hpl invHll (what launch_schur's edge kernel computes; pass have_T = true there).  Only for slot
 // layouts that keep every landmark's edges inside one 256-slot group (the engine's).
+// With d_lmrec as well (16 doubles per free landmark) the pass writes ONE block stream instead: G = Hpl L^-T into d_T
+// (Hll + lambda I = L L^T), the line {L^-1 (6), L^-1 bl (3)} of every landmark into d_lmrec, and neither d_Hpl nor
+// d_invHll; skip_poses then also leaves out the pose pass (d_Hpp, d_bp).  launch_schur and launch_backsubst_update take
+// the same d_lmrec and d_T for that form (SchurRows::d_lmrec).
+// chi_behind_scale: the chi2 partials of the pass go behind the scale partials of the update pass in the scratch, for
+// launch_trial_tail_from_build.
 void launch_build(hipStream_t s, const cugo_edges& ev, const double* d_poses, const double* d_lms,
                   cugo_robust rk, double* d_Hpp, double* d_bp, double* d_Hll, double* d_bl,
                   void* d_Hpl, ReduceScratch rs, double* d_chi, double fuse_lambda = -1.0,
@@ -88,8 +94,9 @@ struct SchurRows
     // in contiguous ranges or in dispatch order
     int mfma = 1;
     bool xcd = true;
-    // fused iteration (launch_build left invHll, T and the landmark lines d_lmrec for this lambda, and skipped its pose
-    // pass): k_pose_schur forms the diagonal blocks, bp and bsc from the build pass's records in place of k_hsc_diag*
+    // fused iteration in the one-stream form (launch_build with d_lmrec and skip_poses for this lambda: d_T holds G):
+    // the off-diagonal kernel takes both operands from d_T, and k_pose_schur forms the diagonal blocks, bp (d_bp_out) and
+    // bsc from the build pass's records, the landmarks' lines and the poses the pass linearised at (d_poses)
     const double* d_lmrec = nullptr;
     const double* d_poses = nullptr;
     ReduceScratch rs{nullptr, 0};

@@ -6,8 +6,9 @@ through 11 landmarks: the Schur system is singular up to the damping); there a d
 bar is accepted only if the oracle ALONE moves by as much when it sums in another order
 (tests/oracle.self_sensitivity), and is printed.
 
-    python tools/fuzz.py [cases] [seed] [medium]  (needs an MI355X; `medium`: 60-500 poses, many-level
-                                                   Cholesky plans with both tile sizes instead of tiny graphs)
+    python tools/fuzz.py [cases] [seed] [medium|sparse]  (needs an MI355X; `medium`: 60-500 poses, many-level
+                                                   Cholesky plans with both tile sizes instead of tiny graphs;
+                                                   `sparse`: 1 - 2.2 observations per landmark)
 """
 import importlib
 import os
@@ -30,6 +31,9 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     worst, worst_excused, excused = 0.0, 0.0, 0
     medium = len(sys.argv) > 3 and sys.argv[3] == "medium"
+    # `sparse`: 1.0 - 2.2 observations per landmark — landmarks seen once (Hll of rank 2, regular only through the
+    # damping): the 3 x 3 factorisation of the one-stream form against the oracle's adjugate inverse
+    sparse = len(sys.argv) > 3 and sys.argv[3] == "sparse"
     for c in range(cases):
         P = int(rng.integers(60, 500)) if medium else int(rng.integers(3, 48))
         L = int(rng.integers(4 * P, 14 * P)) if medium else int(rng.integers(8, 500))
@@ -37,7 +41,7 @@ def main():
         fixed_p = tuple(sorted(rng.choice(P, nfix_p, replace=False).tolist()))
         nfix_l = int(rng.integers(0, max(1, L // 10)))
         fixed_l = tuple(sorted(rng.choice(L, nfix_l, replace=False).tolist()))
-        d = synth.make_problem(n_poses=P, n_landmarks=L, mean_obs=float(rng.uniform(2.2, 6.0)),
+        d = synth.make_problem(n_poses=P, n_landmarks=L, mean_obs=float(rng.uniform(1.0, 2.2) if sparse else rng.uniform(2.2, 6.0)),
                                stereo_frac=float(rng.choice([0.0, 0.5, 1.0])), seed=int(rng.integers(1 << 30)),
                                fixed_poses=fixed_p, fixed_landmarks=fixed_l,
                                loop_closure=bool(rng.integers(0, 2)), pose_noise=(0.005, 0.03))

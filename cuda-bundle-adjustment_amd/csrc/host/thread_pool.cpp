@@ -163,6 +163,13 @@ unsigned wanted_threads()
         CPU_ZERO(&set);
         if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0)
             cpus = std::min<unsigned>(cpus ? cpus : 1u, (unsigned)CPU_COUNT(&set));
+        // one process per GPU on a node (torchrun sets LOCAL_WORLD_SIZE): the ranks share the CPUs of the mask
+        if (const char* e = std::getenv("LOCAL_WORLD_SIZE"))
+        {
+            const int ranks = std::atoi(e);
+            if (ranks > 1)
+                cpus = std::max(1u, cpus / (unsigned)ranks);
+        }
         unsigned want = std::min(kPoolCap, cpus);
         if (const char* e = std::getenv("CUGO_HOST_THREADS"))
             want = std::min(kPoolCap, (unsigned)std::max(1, std::atoi(e)));

@@ -1123,9 +1123,15 @@ __device__ __forceinline__ void dev_potrf16(int ncp, double* __restrict__ lds, d
                 p16_unstage(Ls, stage, j0);
             if (dbg_delay == 3 && (w & 1))
                 dbg_sleep();
-            if (s + 1 + ta < nblk)
+            // (hooks build, CUGO_DEBUG_DELAY=20..27: parts of the kernel LEFT OUT — wrong results, right timing; what
+            // each part costs: profiles/r04_potrf_cost_by_omission.txt.  20: the tiles of phase A, 21: and its barrier,
+            // 22: the U tasks, 23: the trailing tiles of phase B, 24: the panels of the slots, 25 = 22 + 23,
+            // 26 = 22 + 24, 27 = 20 + 22 + 23 + 24)
+            const bool skip_a = dbg_delay == 20 || dbg_delay == 21 || dbg_delay == 27;
+            if (!skip_a && s + 1 + ta < nblk)
                 panel16_update_tile(Ls, invd, j0, 16 * (s + 1 + ta), jn);
-            __syncthreads();
+            if (dbg_delay != 21)
+                __syncthreads();
         }
         if (s == 1)
             stamp(5, 1);
@@ -1141,7 +1147,8 @@ __device__ __forceinline__ void dev_potrf16(int ncp, double* __restrict__ lds, d
             __builtin_amdgcn_s_setprio(3);
             if ((dbg_delay == 7 || dbg_delay == 8) && w == 1)
                 dbg_sleep();
-            panel16_factor(Ls, ncp, jn, invd, w, stage, park);
+            if (dbg_delay != 24 && dbg_delay != 26 && dbg_delay != 27)
+                panel16_factor(Ls, ncp, jn, invd, w, stage, park);
             __builtin_amdgcn_s_setprio(0);
             if (s == 1)
                 stamp(5, 2);
@@ -1166,7 +1173,8 @@ __device__ __forceinline__ void dev_potrf16(int ncp, double* __restrict__ lds, d
             int t = tw;
             if (t <= s)
             {
-                p16_utask(Ls, invd, rsv, Ub, s, t, Wg, ncp, fail);
+                if (dbg_delay != 22 && dbg_delay != 25 && dbg_delay != 26 && dbg_delay != 27)
+                    p16_utask(Ls, invd, rsv, Ub, s, t, Wg, ncp, fail);
                 if (s == 1 && t == 0)
                     stamp_wave(5, 4);
                 if (s == 4 && t == 0)
@@ -1184,7 +1192,8 @@ __device__ __forceinline__ void dev_potrf16(int ncp, double* __restrict__ lds, d
                         rem -= nt - tj;
                         tj++;
                     }
-                    panel16_update_tile(Ls, invd, j0, 16 * (s + 2 + tj + rem), 16 * (s + 2 + tj));
+                    if (dbg_delay != 23 && dbg_delay != 25 && dbg_delay != 27)
+                        panel16_update_tile(Ls, invd, j0, 16 * (s + 2 + tj + rem), 16 * (s + 2 + tj));
                 }
             }
         }

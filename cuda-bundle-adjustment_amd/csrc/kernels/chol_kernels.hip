@@ -1127,7 +1127,7 @@ __device__ __forceinline__ void dev_potrf16(int ncp, double* __restrict__ lds, d
             // each part costs: profiles/r04_potrf_cost_by_omission.txt.  20: the tiles of phase A, 21: and its barrier,
             // 22: the U tasks, 23: the trailing tiles of phase B, 24: the panels of the slots, 25 = 22 + 23,
             // 26 = 22 + 24, 27 = 20 + 22 + 23 + 24)
-            const bool skip_a = dbg_delay == 20 || dbg_delay == 21 || dbg_delay == 27;
+            const bool skip_a = dbg_delay == 20 || dbg_delay == 21 || dbg_delay == 27 || dbg_delay == 28;
             if (!skip_a && s + 1 + ta < nblk)
                 panel16_update_tile(Ls, invd, j0, 16 * (s + 1 + ta), jn);
             if (dbg_delay != 21)
@@ -1147,7 +1147,7 @@ __device__ __forceinline__ void dev_potrf16(int ncp, double* __restrict__ lds, d
             __builtin_amdgcn_s_setprio(3);
             if ((dbg_delay == 7 || dbg_delay == 8) && w == 1)
                 dbg_sleep();
-            if (dbg_delay != 24 && dbg_delay != 26 && dbg_delay != 27)
+            if (dbg_delay != 24 && dbg_delay != 26 && dbg_delay != 27 && dbg_delay != 28)
                 panel16_factor(Ls, ncp, jn, invd, w, stage, park);
             __builtin_amdgcn_s_setprio(0);
             if (s == 1)
@@ -1173,7 +1173,7 @@ __device__ __forceinline__ void dev_potrf16(int ncp, double* __restrict__ lds, d
             int t = tw;
             if (t <= s)
             {
-                if (dbg_delay != 22 && dbg_delay != 25 && dbg_delay != 26 && dbg_delay != 27)
+                if (dbg_delay != 22 && dbg_delay != 25 && dbg_delay != 26 && dbg_delay != 27 && dbg_delay != 28)
                     p16_utask(Ls, invd, rsv, Ub, s, t, Wg, ncp, fail);
                 if (s == 1 && t == 0)
                     stamp_wave(5, 4);
@@ -1192,7 +1192,7 @@ __device__ __forceinline__ void dev_potrf16(int ncp, double* __restrict__ lds, d
                         rem -= nt - tj;
                         tj++;
                     }
-                    if (dbg_delay != 23 && dbg_delay != 25 && dbg_delay != 27)
+                    if (dbg_delay != 23 && dbg_delay != 25 && dbg_delay != 27 && dbg_delay != 28)
                         panel16_update_tile(Ls, invd, j0, 16 * (s + 2 + tj + rem), 16 * (s + 2 + tj));
                 }
             }
@@ -2239,6 +2239,8 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
         const int b = blockIdx.x - npotrf;
         if (DBG_DELAY(p) == 6)
             dbg_sleep();
+        if (DBG_DELAY(p) == 28) // (omission patterns, see dev_potrf16: 28 = the floor of the potrf workgroups alone,
+            return;             //  29 = these extend-add workgroups alone)
         const int32_t* it = b < neap ? wl_eap + 3 * b : wl_eab + 3 * (b - neap);
         dev_extend_add(p, fronts, it[0], it[1], it[2], 2); // everything below the parents' F11
         kernel_release(p);
@@ -2247,6 +2249,8 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
     stamp(0, 0);
     if (DBG_DELAY(p) == 5)
         dbg_sleep();
+    if (DBG_DELAY(p) == 29)
+        return;
     dbg_fill_lds(p, lds);
     // the front's scalars from the task's 64-byte record (one scalar load instead of task -> front -> arrays)
     const int32_t* tm = p.tmeta + cugo_k::TMETA * (task0 + blockIdx.x);

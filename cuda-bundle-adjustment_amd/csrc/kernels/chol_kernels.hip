@@ -2286,7 +2286,12 @@ __global__ __launch_bounds__(BIG) void k_up_potrf(CholPlanDev p, double* __restr
       // graph.  The phase is not bound by the latency of its loads.)
         // (a second attempt — the NEXT child's rel and update-block entries fetched into registers while the current
         // child's are added, nothing else changed — was slower as well: 11.14 vs 10.97 ms, 38.6 vs 37.9 ms)
-        dev_extend_add_lead(p, fronts, tm[16], tm[17], Ls, Vs + threadIdx.x);
+        // (a third attempt, round 4: the child links as ONE 128-byte line each — record + the 16 rel entries its leading
+        // rows can use — fetched beside F11 and kept in LDS, i.e. one dependent global round trip less per child and
+        // none for the first record: 20.2 vs 20.1 us per launch, nothing.  Without this call altogether — omission
+        // pattern 30 — the ten levels with children run 3 - 5 us shorter, 44 us per factorisation.)
+        if (DBG_DELAY(p) != 30)
+            dev_extend_add_lead(p, fronts, tm[16], tm[17], Ls, Vs + threadIdx.x);
     }
     if (p.panel16)
     { // 16-column L D L^T panels, W built behind them (dev_potrf16)
